@@ -1,0 +1,111 @@
+"""Deterministic synthetic weights and inputs for the denoising hot path.
+
+There is no network for checkpoints or datasets, so benchmarks, parity tests and the
+golden-vector generator all draw weights and inputs from the same name-keyed, seed-keyed
+CPU generators.  Everything here is plain CPU torch so the same bytes are produced in the
+build container (where the reference is importable) and on the GPU box (where it is not).
+
+Shapes follow the reference call sites:
+  x_T / noise   (B, 1536, 1, 32)   diffusion_rvqvae_trainer.py:444
+  audio         (B, 68224, 2)      diffusion_rvqvae_trainer.py:422  (16000//30 * 128 samples)
+  word          (B, 128) int64     diffusion_rvqvae_trainer.py:433-442
+  seed          (B, 4, 1536)       diffusion_rvqvae_trainer.py:428-431
+  style_feature (B, 512) zeros for denoiser.MDM (:442) / (B, 256) for denoiser_h3d.MDM
+  mask          (B, 1, 1, 32) bool diffusion_rvqvae_trainer.py:347
+"""
+from __future__ import annotations
+
+import zlib
+from types import SimpleNamespace
+
+import torch
+
+LATENT_C = 1536      # 3 body parts x 512 RVQ latent channels
+LATENT_T = 32        # 128 pose frames / vqvae_squeeze_scale 4
+AUDIO_LEN = 16000 // 30 * 128   # 68224, test-path length
+VOCAB = 11195
+WORD_DIM = 300
+
+
+def default_args(**over):
+    """The argparse keys MDM.__init__ reads (models/denoiser.py:36-71), yaml defaults of
+    configs/diffusion_rvqvae_128.yaml."""
+    a = dict(vqvae_type="rvqvae", use_motionclip=False, audio_rep="onset+amplitude",
+             audio_f=256, word_f=256, data_path="", t_fix_pre=False, vqvae_squeeze_scale=4)
+    a.update(over)
+    return SimpleNamespace(**a)
+
+
+def _gen(name: str, seed: int) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    return g
+
+
+def synth_tensor(name: str, shape, seed: int = 0) -> torch.Tensor | None:
+    """Value for one state_dict entry, or None to leave the module's own value (deterministic
+    buffers: positional table, rotary inv_freq, BatchNorm counters)."""
+    shape = tuple(shape)
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf in ("pe", "inv_freq", "num_batches_tracked"):
+        return None
+    g = _gen(name, seed)
+    if leaf == "running_var":
+        return 0.5 + torch.rand(shape, generator=g)
+    if leaf == "running_mean":
+        return 0.1 * torch.randn(shape, generator=g)
+    if name.startswith("uncon_"):
+        return 0.5 * torch.randn(shape, generator=g)
+    if name == "text_pre_encoder_body.weight":
+        return 0.3 * torch.randn(shape, generator=g)
+    if len(shape) == 1:
+        is_norm_scale = leaf == "weight"
+        if is_norm_scale:               # LayerNorm / BatchNorm gamma
+            return 1.0 + 0.1 * torch.randn(shape, generator=g)
+        return 0.05 * torch.randn(shape, generator=g)   # every bias / beta
+    fan_in = 1
+    for s in shape[1:]:
+        fan_in *= s
+    return torch.randn(shape, generator=g) * (fan_in ** -0.5)
+
+
+@torch.no_grad()
+def synth_fill_(module_or_sd, seed: int = 0):
+    """Overwrite every entry of a state_dict (or a module's) in place with synth_tensor()."""
+    sd = module_or_sd if isinstance(module_or_sd, dict) else module_or_sd.state_dict()
+    for k, v in sd.items():
+        t = synth_tensor(k, v.shape, seed)
+        if t is not None:
+            v.copy_(t.to(v.dtype))
+    return module_or_sd
+
+
+def synth_clip_inputs(batch: int, seed: int = 0, style_dim: int = 512, style_zero: bool = True,
+                      mask_batch: int | None = None):
+    """model_kwargs['y'] exactly as the trainers build it, on CPU."""
+    g = _gen("inputs", seed)
+    y = {
+        "audio": torch.randn(batch, AUDIO_LEN, 2, generator=g),
+        "word": torch.randint(0, VOCAB, (batch, 128), generator=g),
+        "id": torch.zeros(batch, 1, dtype=torch.long),
+        "seed": torch.randn(batch, 4, LATENT_C, generator=g),
+        "mask": torch.ones(mask_batch or batch, 1, 1, LATENT_T, dtype=torch.bool),
+    }
+    if style_zero:
+        y["style_feature"] = torch.zeros(batch, style_dim)
+    else:
+        y["style_feature"] = torch.randn(batch, style_dim, generator=g)
+    return y
+
+
+def synth_latent(batch: int, seed: int = 0, name: str = "x_T") -> torch.Tensor:
+    return torch.randn(batch, LATENT_C, 1, LATENT_T, generator=_gen(name, seed))
+
+
+def synth_step_noise(steps: int, batch: int, seed: int = 0) -> torch.Tensor:
+    """Pre-drawn per-step noise (K, B, 1536, 1, 32); row k is used by the k-th executed step."""
+    return torch.randn(steps, batch, LATENT_C, 1, LATENT_T, generator=_gen("step_noise", seed))
+
+
+def to_device(y: dict, device):
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in y.items()}

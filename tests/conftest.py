@@ -1,0 +1,41 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long CPU test")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a).double().flatten()
+    b = torch.as_tensor(b).double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return np.load(os.path.join(GOLDEN, "reference_outputs.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_tables():
+    return np.load(os.path.join(GOLDEN, "tables.npz"))

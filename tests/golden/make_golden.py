@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself on CPU.
+
+Runs only in the build container, where /root/reference exists (it never travels to the GPU
+box).  Recipe from SURVEY.md §8(c): stub the three import-time-only modules, synthesise
+weights/vocab.pkl, build the reference modules, load the name-keyed deterministic weights from
+syntalker_amd.synth, feed seeded synthetic inputs, save outputs as fp32 .npz.
+
+Only inputs' seeds and the reference's OUTPUTS are stored; no reference source is copied.
+    python tests/golden/make_golden.py
+"""
+import os
+import pickle
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+from syntalker_amd import synth  # noqa: E402
+
+
+def import_reference():
+    for m in ("lmdb", "fasttext", "loguru"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+
+    class _Quiet:
+        def __getattr__(self, k):
+            return lambda *a, **kw: None
+    sys.modules["loguru"].logger = _Quiet()
+    tmp = tempfile.mkdtemp(prefix="syn_vocab_")
+    os.makedirs(os.path.join(tmp, "weights"))
+    with open(os.path.join(tmp, "weights", "vocab.pkl"), "wb") as f:
+        pickle.dump(types.SimpleNamespace(
+            word_embedding_weights=np.zeros((synth.VOCAB, synth.WORD_DIM), np.float32)), f)
+    from models.denoiser import MDM as RefMDM
+    from models.denoiser_h3d import MDM as RefMDMH3D
+    from diffusion.model_util import create_gaussian_diffusion
+    from diffusion import cfg_sampler
+    return RefMDM, RefMDMH3D, create_gaussian_diffusion, cfg_sampler, tmp + "/"
+
+
+class InjectNoise:
+    """Make the reference's internal th.randn_like (gaussian_diffusion.py:541,782) pop pre-drawn rows."""
+
+    def __init__(self, rows):
+        self.rows, self.k = rows, 0
+
+    def __enter__(self):
+        self._orig = torch.randn_like
+
+        def fake(x, *a, **kw):
+            r = self.rows[self.k]
+            self.k += 1
+            assert r.shape == x.shape
+            return r.clone()
+        torch.randn_like = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.randn_like = self._orig
+
+
+def f32(t):
+    return t.detach().to(torch.float32).cpu().numpy()
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    RefMDM, RefMDMH3D, make_diff, cfgmod, data_path = import_reference()
+    torch.Tensor.cuda = lambda self, *a, **k: self      # *_Bodypart wrappers call .cuda()
+    args = synth.default_args(data_path=data_path)
+    out = {}
+
+    # ---- a1-a3: schedule tables -------------------------------------------------------
+    names = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next",
+             "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod",
+             "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+             "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"]
+    tabs = {}
+    for tag, ddim in (("ddpm", False), ("ddim", True)):
+        d = make_diff(use_ddim=ddim)
+        for n in names:
+            tabs[f"{tag}.{n}"] = np.asarray(getattr(d, n), dtype=np.float64)
+        tabs[f"{tag}.timestep_map"] = np.asarray(d.timestep_map, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "tables.npz"), **tabs)
+
+    # ---- a12-a20: denoiser forward (beatx) --------------------------------------------
+    model = synth.synth_fill_(RefMDM(args).eval(), seed=0)
+    y2 = synth.synth_clip_inputs(2, seed=1)
+    x2 = synth.synth_latent(2, seed=1)
+    taps = {}
+    hooks = [model.mytimmblocks[0].register_forward_pre_hook(lambda m, a: taps.__setitem__("h0", a[0].clone()))]
+    for i, b in enumerate(model.mytimmblocks):
+        hooks.append(b.register_forward_hook(lambda m, a, o, i=i: taps.__setitem__(f"h{i + 1}", o.clone())))
+    with torch.no_grad():
+        out["beatx.fwd.t0_3"] = f32(model(x2, torch.tensor([0, 3]), y2))
+        out["beatx.fwd.t500_999"] = f32(model(x2, torch.tensor([500, 999]), y2))
+    for k, v in taps.items():                       # taps of the (500, 999) call
+        out[f"beatx.tap.{k}"] = f32(v)
+    for h in hooks:
+        h.remove()
+
+    # ---- a6-a9: loops with injected noise ----------------------------------------------
+    y1 = synth.synth_clip_inputs(1, seed=2)
+    xT = synth.synth_latent(1, seed=2)
+    ddpm = make_diff(use_ddim=False)
+    sn = synth.synth_step_noise(10, 1, seed=3)
+    with InjectNoise(list(sn)):
+        s = ddpm.p_sample_loop(model, (1, 1536, 1, 32), noise=xT.clone(), clip_denoised=False,
+                               model_kwargs={"y": y1}, skip_timesteps=990)
+    out["beatx.ddpm10.sample"] = f32(s)
+    ddim = make_diff(use_ddim=True)
+    sn = synth.synth_step_noise(50, 1, seed=4)
+    with InjectNoise(list(sn)):
+        s = ddim.ddim_sample_loop(model, (1, 1536, 1, 32), noise=xT.clone(), clip_denoised=False,
+                                  model_kwargs={"y": y1})
+    out["beatx.ddim50.sample"] = f32(s)
+
+    # ---- a10: training_losses (eval-mode model so BN/DropPath are deterministic) -------
+    y4 = synth.synth_clip_inputs(4, seed=5)
+    x0 = synth.synth_latent(4, seed=5, name="x0")
+    eps = synth.synth_latent(4, seed=6, name="eps")
+    t4 = torch.tensor([0, 17, 500, 999])
+    model.zero_grad()
+    terms = ddpm.training_losses(model, x0, t4, model_kwargs={"y": y4}, noise=eps)
+    out["beatx.train.loss"] = f32(terms["loss"])
+    terms["loss"].mean().backward()
+    gn = {}
+    for n in ["mytimmblocks.0.attn.qkv.weight", "mytimmblocks.7.mlp.fc2.weight",
+              "input_process.poseEmbedding.weight", "output_process.poseFinal.bias",
+              "embed_timestep.time_embed.0.weight", "WavEncoder.feat_extractor.0.conv1.weight"]:
+        gn[n] = dict(model.named_parameters())[n].grad.norm().item()
+    out["beatx.train.gradnorm"] = np.array(list(gn.values()), np.float64)
+    out["beatx.train.gradnorm_names"] = np.array(list(gn.keys()))
+
+    # ---- h3d variant: flags + CFG wrappers ----------------------------------------------
+    mh = synth.synth_fill_(RefMDMH3D(args).eval(), seed=0)
+    yh = synth.synth_clip_inputs(2, seed=7, style_dim=256, style_zero=False)
+    xh = synth.synth_latent(2, seed=7)
+    th = torch.tensor([10, 700])
+    with torch.no_grad():
+        for tag, fl in (("cond", {}), ("uncond", {"uncond": True}), ("noaudio", {"uncond_audio": True}),
+                        ("both", {"uncond": True, "uncond_audio": True})):
+            out[f"h3d.fwd.{tag}"] = f32(mh(xh, th, dict(yh, **fl)))
+        yc = dict(yh, scale=torch.ones(1) * 2.5)
+        out["h3d.cfg"] = f32(cfgmod.ClassifierFreeSampleModel(mh)(xh, th, yc))
+        yc = dict(yh, scale_audio=torch.ones(1) * 1.0, scale_prompt=torch.ones(1) * 4.0)
+        out["h3d.twocfg"] = f32(cfgmod.TwoClassifierFreeSampleModel(mh)(xh, th, yc))
+        # body-part wrappers are batch-1 in the reference (zeros([1,256]) style, cfg_sampler.py:84)
+        yb = synth.synth_clip_inputs(1, seed=8, style_dim=256, style_zero=False)
+        xb = synth.synth_latent(1, seed=8)
+        g = synth._gen("part_prompts", 8)
+        parts = {"upper_mask": torch.randn(1, 256, generator=g), "hands_mask": None,
+                 "lower_mask": torch.randn(1, 256, generator=g)}
+        tb = torch.tensor([321])
+        out["h3d.twocfg_bodypart"] = f32(cfgmod.TwoClassifierFreeSampleModel_Bodypart(mh)(
+            xb, tb, dict(yb, style_feature=parts)))
+        out["h3d.cfg_bodypart"] = f32(cfgmod.ClassifierFreeSampleModel_Bodypart(mh)(
+            xb, tb, dict(yb, style_feature=parts, scale=torch.ones(1) * 2.5)))
+        # one DDIM-50 guided loop, B=1 (h3d_diffusion_new_trainer.py:468-471,560-572)
+        sn = synth.synth_step_noise(50, 1, seed=9)
+        wrapped = cfgmod.TwoClassifierFreeSampleModel_Bodypart(mh)
+        with InjectNoise(list(sn)):
+            s = make_diff(use_ddim=True).ddim_sample_loop(
+                wrapped, (1, 1536, 1, 32), noise=xb.clone(), clip_denoised=False,
+                model_kwargs={"y": dict(yb, style_feature=parts)})
+        out["h3d.ddim50_bodypart.sample"] = f32(s)
+
+    np.savez_compressed(os.path.join(HERE, "reference_outputs.npz"), **out)
+    for k, v in out.items():
+        print(f"{k:34s} {tuple(v.shape)}")
+    print("checksum of synth weights:", float(sum(v.double().abs().sum() for v in model.state_dict().values())))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+"""Pin the oracle (oracle/*.py) against outputs of the reference itself (tests/golden/*.npz,
+produced by tests/golden/make_golden.py in the build container).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser_ref as dr
+from oracle import guidance_ref as gr
+from oracle import schedule_ref as sr
+from oracle.process_ref import RefProcess
+from syntalker_amd import synth
+from tests.conftest import rel_l2
+from tests.refmodel import synth_state_dict
+
+FP32_TOL = 2e-6      # fp32 reference vs fp32 restatement: op order differs slightly, nothing else
+
+
+@pytest.mark.parametrize("tag,spec", [("ddpm", None), ("ddim", "ddim50")])
+def test_schedule_tables_bitexact(golden_tables, tag, spec):
+    tab, tmap = sr.respaced(1000, spec)
+    assert np.array_equal(np.asarray(tmap), golden_tables[f"{tag}.timestep_map"])
+    for k, v in tab.items():
+        assert np.array_equal(v, golden_tables[f"{tag}.{k}"]), k
+
+
+def test_schedule_known_answers():
+    tab, tmap = sr.respaced(1000, "ddim50")
+    assert tmap[:4] == [0, 20, 40, 60] and tmap[-1] == 980 and len(tmap) == 50
+    b = sr.cosine_betas(1000)
+    assert b.shape == (1000,) and b.max() == 0.999 and 0 < b.min() < 1e-4
+
+
+def _model_fn(sd, variant="beatx"):
+    return lambda x, t, y: dr.mdm_forward(sd, x, t, y, variant=variant)
+
+
+def test_forward_as_written_matches_reference(golden):
+    sd = synth_state_dict("beatx")
+    y, x = synth.synth_clip_inputs(2, seed=1), synth.synth_latent(2, seed=1)
+    with torch.no_grad():
+        o1 = dr.mdm_forward(sd, x, torch.tensor([0, 3]), y)
+        taps = {}
+        o2 = dr.mdm_forward(sd, x, torch.tensor([500, 999]), y, taps=taps)
+    assert rel_l2(o1, golden["beatx.fwd.t0_3"]) < FP32_TOL
+    assert rel_l2(o2, golden["beatx.fwd.t500_999"]) < FP32_TOL
+    for k, v in taps.items():
+        assert rel_l2(v, golden[f"beatx.tap.{k}"]) < FP32_TOL, k
+
+
+def test_forward_folded_matches_reference(golden):
+    """The hoisted + folded algebra (what the kernels compute), in fp64, vs the fp32 reference."""
+    sd = dr.cast_sd(synth_state_dict("beatx"), torch.float64)
+    y, x = synth.synth_clip_inputs(2, seed=1), synth.synth_latent(2, seed=1).double()
+    y = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in y.items()}
+    with torch.no_grad():
+        fw = dr.fold_weights(sd)
+        cond, te = dr.clip_conditioning(sd, y, fw), dr.time_table(sd, fw)
+        o = dr.mdm_forward_folded(sd, fw, cond, te, x, torch.tensor([500, 999]))
+    assert rel_l2(o, golden["beatx.fwd.t500_999"]) < 5e-6
+
+
+def test_ddpm10_and_ddim50_loops(golden):
+    sd = synth_state_dict("beatx")
+    y, xT = synth.synth_clip_inputs(1, seed=2), synth.synth_latent(1, seed=2)
+    s = RefProcess(False).p_sample_loop(_model_fn(sd), (1, 1536, 1, 32), y, noise=xT.clone(),
+                                        step_noise=synth.synth_step_noise(10, 1, seed=3), skip_timesteps=990)
+    assert rel_l2(s, golden["beatx.ddpm10.sample"]) < 5e-6
+    s = RefProcess(True).ddim_sample_loop(_model_fn(sd), (1, 1536, 1, 32), y, noise=xT.clone(),
+                                          step_noise=synth.synth_step_noise(50, 1, seed=4))
+    assert rel_l2(s, golden["beatx.ddim50.sample"]) < 2e-5
+
+
+def test_training_loss_value(golden):
+    sd = synth_state_dict("beatx")
+    y = synth.synth_clip_inputs(4, seed=5)
+    x0, eps = synth.synth_latent(4, seed=5, name="x0"), synth.synth_latent(4, seed=6, name="eps")
+    with torch.no_grad():
+        terms = RefProcess(False).training_losses(_model_fn(sd), x0, torch.tensor([0, 17, 500, 999]), y, eps)
+    assert np.allclose(terms["loss"].numpy(), golden["beatx.train.loss"], rtol=2e-6, atol=0)
+
+
+def test_h3d_flags_and_guidance(golden):
+    sd = synth_state_dict("h3d")
+    fn = _model_fn(sd, "h3d")
+    y = synth.synth_clip_inputs(2, seed=7, style_dim=256, style_zero=False)
+    x, t = synth.synth_latent(2, seed=7), torch.tensor([10, 700])
+    with torch.no_grad():
+        for tag, fl in (("cond", {}), ("uncond", {"uncond": True}), ("noaudio", {"uncond_audio": True}),
+                        ("both", {"uncond": True, "uncond_audio": True})):
+            assert rel_l2(fn(x, t, dict(y, **fl)), golden[f"h3d.fwd.{tag}"]) < FP32_TOL, tag
+        o = gr.cfg(fn, x, t, dict(y, scale=torch.ones(1) * 2.5))
+        assert rel_l2(o, golden["h3d.cfg"]) < 5e-6
+        o = gr.two_cfg(fn, x, t, dict(y, scale_audio=torch.ones(1), scale_prompt=torch.ones(1) * 4.0))
+        assert rel_l2(o, golden["h3d.twocfg"]) < 5e-6
+
+
+def _bodypart_case():
+    y = synth.synth_clip_inputs(1, seed=8, style_dim=256, style_zero=False)
+    g = synth._gen("part_prompts", 8)
+    parts = {"upper_mask": torch.randn(1, 256, generator=g), "hands_mask": None,
+             "lower_mask": torch.randn(1, 256, generator=g)}
+    return y, synth.synth_latent(1, seed=8), parts
+
+
+def test_h3d_bodypart_guidance(golden):
+    sd = synth_state_dict("h3d")
+    fn = _model_fn(sd, "h3d")
+    y, x, parts = _bodypart_case()
+    t = torch.tensor([321])
+    with torch.no_grad():
+        o = gr.two_cfg_bodypart(fn, x, t, dict(y, style_feature=parts))
+        assert rel_l2(o, golden["h3d.twocfg_bodypart"]) < 5e-6
+        o = gr.cfg_bodypart(fn, x, t, dict(y, style_feature=parts, scale=torch.ones(1) * 2.5))
+        assert rel_l2(o, golden["h3d.cfg_bodypart"]) < 5e-6
+
+
+@pytest.mark.slow
+def test_h3d_ddim50_bodypart_loop(golden):
+    sd = synth_state_dict("h3d")
+    fn = _model_fn(sd, "h3d")
+    y, x, parts = _bodypart_case()
+    guided = lambda xx, tt, yy: gr.two_cfg_bodypart(fn, xx, tt, yy)
+    s = RefProcess(True).ddim_sample_loop(guided, (1, 1536, 1, 32), dict(y, style_feature=parts), noise=x.clone(),
+                                          step_noise=synth.synth_step_noise(50, 1, seed=9))
+    assert rel_l2(s, golden["h3d.ddim50_bodypart.sample"]) < 5e-5
