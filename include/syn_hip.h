@@ -1,0 +1,131 @@
+/*
+ * syn_hip.h — C ABI of libsyn_hip.so: the MI355X (gfx950) denoising-step kernels for SynTalker.
+ *
+ * The reference (RobinWitch/SynTalker) is pure Python: it has no FFI of its own.  This ABI sits
+ * beneath the two Python seams the reference's drivers use:
+ *     models/denoiser.py:132      MDM.forward(x, timesteps, y)            -> syn_denoise_step (c_x0=1, c_xt=0, sigma=0)
+ *     diffusion/gaussian_diffusion.py:505   GaussianDiffusion.p_sample    -> syn_denoise_step (DDPM coefficients)
+ *     diffusion/gaussian_diffusion.py:741   GaussianDiffusion.ddim_sample -> syn_denoise_step (DDIM coefficients)
+ *     diffusion/cfg_sampler.py:10-167       the four CFG wrappers         -> syn_denoise_step with n_variants > 1
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no exceptions; every entry point returns 0 on success, <0 on error;
+ *     syn_last_error() returns a thread-local message for the last failure.
+ *   - every pointer is a DEVICE pointer owned by the caller unless stated otherwise;
+ *     nothing is allocated, freed or synchronised inside an entry point, so all of them can be
+ *     captured in a hipGraph.  `stream` is a hipStream_t (NULL = default stream).
+ *   - "token-major" latent = [clip][frame 0..31][channel 0..1535]; the reference's layout
+ *     (B, 1536, 1, 32) is "channel-major".  The sampling loop keeps x token-major across steps.
+ *   - bf16 buffers are passed as void*; "packed" weights are in MFMA fragment order, produced
+ *     by syn_pack_weight.
+ */
+#ifndef SYN_HIP_H
+#define SYN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SYN_ABI_VERSION 1
+#define SYN_D        512   /* hidden width               (models/denoiser.py:19)  */
+#define SYN_T        32    /* latent frames per clip     (128 pose frames / 4)    */
+#define SYN_C        1536  /* latent channels            (models/denoiser.py:37)  */
+#define SYN_FF       1024  /* MLP width                  (models/denoiser.py:20)  */
+#define SYN_HEADS    4     /* attention heads x 128      (models/denoiser.py:22)  */
+#define SYN_LAYERS   8     /* transformer blocks         (models/denoiser.py:21)  */
+
+int         syn_version(void);
+const char* syn_last_error(void);
+
+/* One transformer block (models/timm_transformer/transformer.py:154-198). */
+typedef struct syn_layer {
+    const float* ln1_g;  const float* ln1_b;      /* norm1 (512)                               */
+    const void*  w_qkv;                           /* packed bf16, attn.qkv.weight (1536 x 512)  */
+    const void*  w_proj; const float* b_proj;     /* packed bf16 (512 x 512), bias (512)        */
+    const float* ln2_g;  const float* ln2_b;      /* norm2 (512)                                */
+    const void*  w_fc1;  const float* b_fc1;      /* packed bf16 (1024 x 512), bias (1024)      */
+    const void*  w_fc2;  const float* b_fc2;      /* packed bf16 (512 x 1024), bias (512)       */
+} syn_layer;
+
+/* Everything the step needs that depends only on the weights. */
+typedef struct syn_model {
+    const void*  w_in;      /* packed bf16 (512 x 1536): folded input matrix A   */
+    const float* te;        /* [n_te][512] time_embed(pe[t]) . W2a^T, row = ORIGINAL timestep    */
+    int32_t      n_te;
+    const float* rot_cos;   /* [32][32] cos(pos * inv_freq[j])   (models/denoiser.py:324-343)    */
+    const float* rot_sin;   /* [32][32]                                                          */
+    syn_layer    layer[SYN_LAYERS];
+    const void*  w_out;     /* packed bf16 (1536 x 512): output_process.poseFinal.weight         */
+    const float* b_out;     /* (1536)                                                            */
+} syn_model;
+
+/* One denoising step over n_clips clips, each evaluated under n_variants conditionings
+ * (classifier-free guidance as ONE fused batch of n_variants*n_clips sequences). */
+typedef struct syn_step {
+    int32_t n_clips;        /* B                                                                 */
+    int32_t n_variants;     /* V >= 1                                                            */
+    int32_t m_tile;         /* rows per workgroup: 0 = auto, else 32 / 64 / 128                  */
+    int32_t reserved;
+    /* conditioning, row (v*B + b)*32 + frame */
+    const float*   cond;    /* [V*B*32][512] per-clip term: cbias + c_frame + seed/style term    */
+    const int32_t* t_model; /* [V*B] ORIGINAL timestep -> row of syn_model.te                    */
+    const float*   cfg_w;   /* [3][V] weights of the variants for output channels 0:512, 512:1024,
+                               1024:1536; NULL iff V == 1                                        */
+    /* state, token-major */
+    const float*   x_t;       /* [B*32][1536] fp32                                               */
+    const void*    x_t_bf16;  /* [B*32][1536] bf16 copy of x_t (GEMM operand)                    */
+    const float*   noise;     /* [B*32][1536] fp32 N(0,1), or NULL for no noise term             */
+    const float*   coef;      /* [n][4] rows (c_x0, c_xt, sigma, unused)                         */
+    const int32_t* t_coef;    /* [B] row of coef used by each clip                               */
+    float*         x_next;      /* [B*32][1536] = c_x0*x0_hat + c_xt*x_t + sigma*noise; may alias x_t */
+    void*          x_next_bf16; /* bf16 copy of x_next; may alias x_t_bf16                       */
+    float*         pred_x0;     /* [B*32][1536] x0_hat, or NULL                                  */
+    /* workspace (caller-owned, contents undefined on return); R = V*B*32 rows */
+    float* ws_h;      /* [R][512]  fp32 residual stream                                          */
+    void*  ws_xn;     /* [R][512]  bf16 normalised activations                                   */
+    void*  ws_q;      /* [R][512]  bf16                                                          */
+    void*  ws_k;      /* [R][512]  bf16                                                          */
+    void*  ws_vt;     /* [V*B*4*128][32] bf16, V transposed per (clip, head)                     */
+    void*  ws_o;      /* [R][512]  bf16 attention output                                         */
+    void*  ws_hid;    /* [R][1024] bf16 MLP hidden                                               */
+    void*  ws_hc;     /* [3][B*32][512] bf16 guidance-combined stream (only if V > 1)            */
+} syn_step;
+
+/* Enqueue one full step (42 kernels) on `stream`. */
+int syn_denoise_step(const syn_model* model, const syn_step* step, void* stream);
+
+/* ---- load-time helpers -------------------------------------------------------------------- */
+/* fp32 row-major W[n][k] (nn.Linear.weight layout) -> packed bf16 fragments (n*k*2 bytes).
+ * n % 16 == 0, k % 32 == 0. */
+int syn_pack_weight(const float* w, int32_t n, int32_t k, void* out_packed, void* stream);
+
+/* ---- layout at loop entry / exit ----------------------------------------------------------- */
+/* (B,1536,1,32) fp32 -> token-major fp32 (nullable) and bf16 (nullable). */
+int syn_to_token_major(const float* x_bct, int32_t n_clips, float* out_f32, void* out_bf16, void* stream);
+/* token-major fp32 -> (B,1536,1,32) fp32. */
+int syn_from_token_major(const float* x_btc, int32_t n_clips, float* out_bct, void* stream);
+
+/* q_sample / generic axpby on flat fp32 buffers: out = a[t_row[clip]]*x + b[t_row[clip]]*y, clip = i / per_clip.
+ * (diffusion/gaussian_diffusion.py:235-253). */
+int syn_axpby_rows(const float* x, const float* y, const float* coef_ab /*[n][2]*/, const int32_t* t_row,
+                   int32_t n_clips, int32_t per_clip, float* out, void* stream);
+
+/* Philox4x32-10 + Box-Muller N(0,1): out[i] depends only on (seed, stream_id, i) — the same values
+ * for any batch sharding across GPUs.  n % 4 == 0. */
+int syn_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t first_index, void* stream);
+
+/* ---- single stages, exported for unit tests and bisecting ----------------------------------- */
+/* Y[m][n] = sum_k X[m][k] * W[n][k] (+ bias[n]); X bf16 [m_rows][k], W packed, Y fp32 [m_rows][n]. n % 512 == 0. */
+int syn_test_gemm(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k,
+                  int32_t m_tile, float* y, void* stream);
+/* attention over ws_q/ws_k/ws_vt -> ws_o for n_seq sequences of 32 tokens, 4 heads x 128. */
+int syn_test_attention(const void* q, const void* k, const void* vt, int32_t n_seq, void* o, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYN_HIP_H */

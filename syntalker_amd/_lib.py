@@ -1,0 +1,89 @@
+"""ctypes binding of libsyn_hip.so (C ABI: include/syn_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``syntalker_amd/csrc/build.sh`` with
+``hipcc --offload-arch=gfx950``.  There is NO fallback: if the shared object is missing or an entry
+point fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsyn_hip.so")
+
+SYN_LAYERS = 8
+EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_pack_weight", "syn_to_token_major",
+           "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_test_gemm", "syn_test_attention")
+
+vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
+
+
+class SynLayer(C.Structure):
+    _fields_ = [("ln1_g", vp), ("ln1_b", vp), ("w_qkv", vp), ("w_proj", vp), ("b_proj", vp),
+                ("ln2_g", vp), ("ln2_b", vp), ("w_fc1", vp), ("b_fc1", vp), ("w_fc2", vp), ("b_fc2", vp)]
+
+
+class SynModel(C.Structure):
+    _fields_ = [("w_in", vp), ("te", vp), ("n_te", i32), ("rot_cos", vp), ("rot_sin", vp),
+                ("layer", SynLayer * SYN_LAYERS), ("w_out", vp), ("b_out", vp)]
+
+
+class SynStep(C.Structure):
+    _fields_ = [("n_clips", i32), ("n_variants", i32), ("m_tile", i32), ("reserved", i32),
+                ("cond", vp), ("t_model", vp), ("cfg_w", vp),
+                ("x_t", vp), ("x_t_bf16", vp), ("noise", vp), ("coef", vp), ("t_coef", vp),
+                ("x_next", vp), ("x_next_bf16", vp), ("pred_x0", vp),
+                ("ws_h", vp), ("ws_xn", vp), ("ws_q", vp), ("ws_k", vp), ("ws_vt", vp), ("ws_o", vp),
+                ("ws_hid", vp), ("ws_hc", vp)]
+
+
+class SynHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises SynHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SynHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback for the denoising path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.syn_version.restype = C.c_int
+    lib.syn_last_error.restype = C.c_char_p
+    lib.syn_denoise_step.argtypes = [C.POINTER(SynModel), C.POINTER(SynStep), vp]
+    lib.syn_pack_weight.argtypes = [vp, i32, i32, vp, vp]
+    lib.syn_to_token_major.argtypes = [vp, i32, vp, vp, vp]
+    lib.syn_from_token_major.argtypes = [vp, i32, vp, vp]
+    lib.syn_axpby_rows.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
+    lib.syn_randn.argtypes = [vp, i64, u64, u64, i64, vp]
+    lib.syn_test_gemm.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.syn_test_attention.argtypes = [vp, vp, vp, i32, vp, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("syn_version", "syn_last_error"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().syn_last_error()
+        raise SynHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

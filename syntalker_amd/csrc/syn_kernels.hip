@@ -1,0 +1,742 @@
+// syn_kernels.hip — hand-written CDNA4 (gfx950) kernels for the SynTalker denoising step.
+//
+// What one step computes (reference models/denoiser.py:132-196 after hoisting the timestep-
+// independent conditioning and folding the affine input stage, SURVEY.md §8 a17-a20, followed by the
+// posterior update of diffusion/gaussian_diffusion.py:505-557 / :741-791):
+//
+//   h   = rotary( x_t . A^T + cond[clip] + te[t] )                    k_gemm<EPI_IN>
+//   8 x { qkv = LN1(h) . Wqkv^T                                        k_gemm<EPI_QKV>
+//         o   = softmax(q k^T / sqrt(128)) v       (4 heads, 32x32)    k_attn
+//         h  += o . Wproj^T + b                                        k_gemm<EPI_RESID>  (+ LN2 -> xn)
+//         hid = gelu(LN2(h) . W1^T + b1)                               k_gemm<EPI_GELU>
+//         h  += hid . W2^T + b2 }                                      k_gemm<EPI_RESID>  (+ LN1' -> xn)
+//   x0  = h . Wout^T + bout ;  x_{t-1} = c0*x0 + c1*x_t + sigma*eps    k_gemm<EPI_OUT>
+//
+// GEMM structure (one template, five epilogues).  A workgroup of 8 waves owns MT rows (whole clips)
+// x 512 output columns; wave w owns columns [64w, 64w+64) for ALL MT rows, so
+//   * the weight operand is never shared between waves: each wave streams its own MFMA fragments
+//     straight from L2 into VGPRs (weights are pre-packed so one fragment = one coalesced 1 KiB read);
+//   * the activation operand (MT x 64 bf16 K-tile) is shared by all 8 waves: staged through LDS,
+//     double-buffered, 16-byte slots XOR-swizzled by (row & 7) so ds_read_b128 is conflict-free;
+//   * a full 512-wide row lives inside one workgroup, so LayerNorm of the NEXT op is an epilogue.
+// MFMA orientation: D[n][m] = sum_k W[n][k] X[m][k]  (weights = A operand, tokens = B operand), so a
+// lane ends up with 4 CONSECUTIVE output features of one token -> 16 B (fp32) / 8 B (bf16) stores into
+// row-major [token][feature] tensors.  v_mfma_f32_16x16x32_bf16 layouts (gfx950):
+//   A: lane l holds A[i = l&15][k = 8*(l>>4) .. +7]     B: lane l holds B[k = 8*(l>>4) .. +7][j = l&15]
+//   D: lane l, reg r holds D[i = 4*(l>>4) + r][j = l&15]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "syn_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+namespace {
+
+constexpr int kThreads = 512;   // 8 waves: 2 per SIMD, 256-VGPR budget each
+constexpr int kKT = 64;         // K tile staged through LDS (128 B per row)
+constexpr int kNT = 512;        // output columns per workgroup (64 per wave)
+
+enum Epi { EPI_PLAIN = 0, EPI_IN = 1, EPI_QKV = 2, EPI_RESID = 3, EPI_GELU = 4, EPI_OUT = 5 };
+
+struct GArgs {
+    // operands
+    const __bf16* X; long x_chunk_stride; int ldx; int x_rows;   // activation row = m % x_rows
+    const uint4* W; int K; int M;
+    const float* bias;
+    // residual + LayerNorm epilogues
+    float* H; __bf16* Y; int ldy; const float* ln_g; const float* ln_b;
+    // input epilogue
+    const float* cond; const float* te; const int* t_model; const float* rcos; const float* rsin;
+    // qkv epilogue
+    __bf16* Q; __bf16* Kb; __bf16* Vt;
+    // posterior epilogue
+    const float* Xt; const float* noise; const float* coef; const int* t_coef;
+    float* Xn; __bf16* Xnb; float* X0;
+    // plain fp32 output (unit tests)
+    float* Yf; int ldyf;
+};
+
+__device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
+    bf16x4 r;
+    r[0] = (__bf16)v[0]; r[1] = (__bf16)v[1]; r[2] = (__bf16)v[2]; r[3] = (__bf16)v[3];
+    return r;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {   // nn.GELU() default: exact erf form
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Main loop: acc[nf][mf] += W-frag(nf) x X-frag(mf) over K.
+//   SWAP=false: acc[nf][mf][r] = out[m = 16mf + (l&15)][n = 16nf + 4(l>>4) + r]
+//   SWAP=true : acc[nf][mf][r] = out[m = 16mf + 4(l>>4) + r][n = 16nf + (l&15)]
+template <int MT, bool SWAP>
+__device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[4][MT / 16], const __bf16* __restrict__ X, int ldx,
+                                              int x_rows, int m0, int M, int K, const uint4* __restrict__ Wq,
+                                              char* smem) {
+    constexpr int MF = MT / 16;
+    constexpr int NLD = (MT * 8 + kThreads - 1) / kThreads;   // 16-byte staging loads per thread per K tile
+    constexpr int BUF = MT * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int KS = K / 32, NKT = K / kKT;
+
+    // staging assignment: 16-byte slot `slot` of tile row `row`
+    const __bf16* src[NLD];
+    int dst[NLD];
+    bool live[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * kThreads;
+        const int row = idx >> 3, slot = idx & 7;
+        const int m = m0 + row;
+        live[i] = (idx < MT * 8) && (m < M);
+        src[i] = X + (size_t)(live[i] ? (m % x_rows) : 0) * ldx + slot * 8;
+        dst[i] = row * 128 + ((slot ^ (row & 7)) << 4);
+    }
+    uint4 st[NLD];
+    auto stage_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            st[i] = live[i] ? *reinterpret_cast<const uint4*>(src[i] + kt * kKT) : make_uint4(0, 0, 0, 0);
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (NLD * kThreads == MT * 8 || tid + i * kThreads < MT * 8)
+                *reinterpret_cast<uint4*>(smem + buf * BUF + dst[i]) = st[i];
+    };
+    // fragment read offsets (row = 16mf + (l&15) -> row&7 = l&7; slot = 4ks + (l>>4))
+    int xoff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) xoff[ks] = (lane & 15) * 128 + ((((4 * ks) + (lane >> 4)) ^ (lane & 7)) << 4);
+
+    // Weight fragments: two register sets, each prefetched one k-step (32 MFMAs ~ 500 cycles) ahead.
+    uint4 wa[4], wb[4];
+    auto w_load = [&](uint4 (&w)[4], int kstep) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) w[nf] = Wq[((size_t)nf * KS + kstep) * 64];
+    };
+    auto compute = [&](const uint4 (&w)[4], int buf, int ks) {
+        bf16x8 xf[MF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+            xf[mf] = *reinterpret_cast<const bf16x8*>(smem + buf * BUF + mf * 2048 + xoff[ks]);
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, w[nf]);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+                acc[nf][mf] = SWAP ? MFMA16(xf[mf], wf, acc[nf][mf]) : MFMA16(wf, xf[mf], acc[nf][mf]);
+        }
+    };
+
+    stage_load(0);
+    w_load(wa, 0);
+    stage_store(0);
+    __syncthreads();
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < NKT;
+        if (more) stage_load(kt + 1);
+        w_load(wb, kt * 2 + 1);
+        compute(wa, buf, 0);
+        if (more) w_load(wa, kt * 2 + 2);
+        compute(wb, buf, 1);
+        if (more) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// Row mean / rstd over the 512 columns a workgroup owns (8 waves x 64), two-pass for accuracy.
+// v[nf][mf][r] in the SWAP=false layout.  red: MT*8 floats, stat: 2*MT floats (LDS).
+template <int MT>
+__device__ __forceinline__ void row_stats(const f32x4 (&v)[4][MT / 16], float* red, float* stat,
+                                          float (&mean)[MT / 16], float (&rstd)[MT / 16]) {
+    constexpr int MF = MT / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lr = lane & 15;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        float s = 0.f;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) s += (v[nf][mf][0] + v[nf][mf][1]) + (v[nf][mf][2] + v[nf][mf][3]);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (g == 0) red[(mf * 16 + lr) * 8 + wave] = s;
+    }
+    __syncthreads();
+    if (tid < MT) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += red[tid * 8 + w];
+        stat[tid] = s * (1.0f / 512.0f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) mean[mf] = stat[mf * 16 + lr];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        float s = 0.f;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = v[nf][mf][r] - mean[mf];
+                s += d * d;
+            }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (g == 0) red[(mf * 16 + lr) * 8 + wave] = s;
+    }
+    __syncthreads();
+    if (tid < MT) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += red[tid * 8 + w];
+        stat[MT + tid] = rsqrtf(s * (1.0f / 512.0f) + 1e-5f);   // nn.LayerNorm: biased variance, eps 1e-5
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) rstd[mf] = stat[MT + mf * 16 + lr];
+}
+
+// h (fp32) is final in v; write H, then Y = LN(v)*g + b (or plain bf16(v) when ln_g == nullptr).
+template <int MT>
+__device__ __forceinline__ void store_h_and_norm(const GArgs& a, f32x4 (&v)[4][MT / 16], int m0, char* smem) {
+    constexpr int MF = MT / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int m = m0 + mf * 16 + lr;
+        if (m < a.M)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+                *reinterpret_cast<f32x4*>(a.H + (size_t)m * kNT + wave * 64 + nf * 16 + g * 4) = v[nf][mf];
+    }
+    float mean[MF], rstd[MF];
+    if (a.ln_g != nullptr) {
+        float* red = reinterpret_cast<float*>(smem);
+        row_stats<MT>(v, red, red + MT * 8, mean, rstd);
+    }
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+        const int n = wave * 64 + nf * 16 + g * 4;
+        f32x4 gg = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f};
+        if (a.ln_g != nullptr) {
+            gg = *reinterpret_cast<const f32x4*>(a.ln_g + n);
+            bb = *reinterpret_cast<const f32x4*>(a.ln_b + n);
+        }
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int m = m0 + mf * 16 + lr;
+            f32x4 y = v[nf][mf];
+            if (a.ln_g != nullptr) y = (y - mean[mf]) * rstd[mf] * gg + bb;
+            if (m < a.M) *reinterpret_cast<bf16x4*>(a.Y + (size_t)m * a.ldy + n) = to_bf16x4(y);
+        }
+    }
+}
+
+template <int MT, int EPI>
+__global__ __launch_bounds__(kThreads) void k_gemm(const GArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MF = MT / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lr = lane & 15;
+    const int m0 = blockIdx.x * MT, chunk = blockIdx.y;
+    const int KS = a.K / 32;
+
+    // Accumulators start from the additive epilogue terms (residual + bias, or conditioning + time row):
+    // no extra registers after the loop and the loads overlap the pipeline prologue.
+    f32x4 acc[4][MF];
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = wave * 64 + nf * 16 + g * 4;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int m = m0 + mf * 16 + lr;
+                f32x4 h = {0.f, 0.f, 0.f, 0.f};
+                if (m < a.M) h = *reinterpret_cast<const f32x4*>(a.H + (size_t)m * kNT + n);
+                acc[nf][mf] = h + b;
+            }
+        }
+    } else if constexpr (EPI == EPI_IN) {
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int m = m0 + mf * 16 + lr;
+            const bool ok = m < a.M;
+            const int ts = ok ? a.t_model[m >> 5] : 0;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const int n = wave * 64 + nf * 16 + g * 4;
+                f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                if (ok) c = *reinterpret_cast<const f32x4*>(a.cond + (size_t)m * kNT + n);
+                acc[nf][mf] = c + *reinterpret_cast<const f32x4*>(a.te + (size_t)ts * kNT + n);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    const uint4* Wq = a.W + ((size_t)(chunk * 32 + wave * 4) * KS) * 64 + lane;
+    const __bf16* X = a.X + (size_t)chunk * a.x_chunk_stride;
+    const bool swap = (EPI == EPI_QKV) && (chunk == 2);
+    if (swap)
+        gemm_mainloop<MT, true>(acc, X, a.ldx, a.x_rows, m0, a.M, a.K, Wq, smem);
+    else
+        gemm_mainloop<MT, false>(acc, X, a.ldx, a.x_rows, m0, a.M, a.K, Wq, smem);
+
+    const int ncol = chunk * kNT + wave * 64;   // first global output column of this wave
+
+    if constexpr (EPI == EPI_PLAIN) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = ncol + nf * 16 + g * 4;
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) b = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int m = m0 + mf * 16 + lr;
+                if (m < a.M) *reinterpret_cast<f32x4*>(a.Yf + (size_t)m * a.ldyf + n) = acc[nf][mf] + b;
+            }
+        }
+    } else if constexpr (EPI == EPI_IN) {
+        // (conditioning + time row were the accumulator's initial value.)  Rotary on the (j, j+32) pairs
+        // of this wave's 64-wide group (models/denoiser.py:178-186): frags nf=0,1 hold j<32, nf=2,3 j+32.
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int pos = (m0 + mf * 16 + lr) & 31;
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                const int j = nf * 16 + g * 4;
+                const f32x4 cs = *reinterpret_cast<const f32x4*>(a.rcos + pos * 32 + j);
+                const f32x4 sn = *reinterpret_cast<const f32x4*>(a.rsin + pos * 32 + j);
+                const f32x4 u = acc[nf][mf], w = acc[nf + 2][mf];
+                acc[nf][mf] = u * cs - w * sn;
+                acc[nf + 2][mf] = w * cs + u * sn;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        store_h_and_norm<MT>(a, acc, m0, smem);
+    } else if constexpr (EPI == EPI_QKV) {
+        if (!swap) {
+            __bf16* dst = chunk == 0 ? a.Q : a.Kb;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int m = m0 + mf * 16 + lr;
+                if (m < a.M)
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf)
+                        *reinterpret_cast<bf16x4*>(dst + (size_t)m * kNT + wave * 64 + nf * 16 + g * 4) =
+                            to_bf16x4(acc[nf][mf]);
+            }
+        } else {
+            // V, transposed per (sequence, head): Vt[((seq*4 + head)*128 + d)*32 + token]
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int mb = m0 + mf * 16;            // 16 rows of one sequence
+                const int seq = mb >> 5, tok = (mb & 31) + g * 4;
+                if (mb < a.M)
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf) {
+                        const int n = wave * 64 + nf * 16 + lr;   // 0..511 = head*128 + d
+                        *reinterpret_cast<bf16x4*>(a.Vt + ((size_t)seq * 512 + n) * 32 + tok) = to_bf16x4(acc[nf][mf]);
+                    }
+            }
+        }
+    } else if constexpr (EPI == EPI_RESID) {
+        store_h_and_norm<MT>(a, acc, m0, smem);
+    } else if constexpr (EPI == EPI_GELU) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = ncol + nf * 16 + g * 4;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int m = m0 + mf * 16 + lr;
+                f32x4 v = acc[nf][mf] + b;
+                v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+                if (m < a.M) *reinterpret_cast<bf16x4*>(a.Y + (size_t)m * a.ldy + n) = to_bf16x4(v);
+            }
+        }
+    } else if constexpr (EPI == EPI_OUT) {
+        // x0 = acc + bias;  x_next = c0*x0 + c1*x_t + sigma*eps   (p_sample / ddim_sample)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int m = m0 + mf * 16 + lr;
+            if (m >= a.M) continue;
+            const f32x4 cf = *reinterpret_cast<const f32x4*>(a.coef + (size_t)a.t_coef[m >> 5] * 4);
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const int n = ncol + nf * 16 + g * 4;
+                const size_t off = (size_t)m * SYN_C + n;
+                const f32x4 x0 = acc[nf][mf] + *reinterpret_cast<const f32x4*>(a.bias + n);
+                const f32x4 xt = *reinterpret_cast<const f32x4*>(a.Xt + off);
+                f32x4 xn = x0 * cf[0] + xt * cf[1];
+                if (a.noise) xn = xn + *reinterpret_cast<const f32x4*>(a.noise + off) * cf[2];
+                *reinterpret_cast<f32x4*>(a.Xn + off) = xn;
+                *reinterpret_cast<bf16x4*>(a.Xnb + off) = to_bf16x4(xn);
+                if (a.X0) *reinterpret_cast<f32x4*>(a.X0 + off) = x0;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention: one wave per (sequence, head); 32 tokens x 128 dims, non-causal
+// (models/timm_transformer/transformer.py:89-93).  Everything stays in registers:
+//   S^T[key][q] = K Q^T  (A = K rows, B = Q rows)   -> lane owns one q column, 8 keys
+//   softmax over keys = 8 in-lane values + 2 xor-shuffles (lanes l, l^16, l^32, l^48)
+//   O^T[d][q]   = Vt P^T (A = Vt rows, B = P^T)     -> the S^T accumulator IS the B fragment after
+//   permuting the contraction index: slot 8g+e <-> key (e<4 ? 4g+e : 16+4g+e-4), applied to Vt loads.
+__global__ __launch_bounds__(256) void k_attn(const __bf16* __restrict__ Q, const __bf16* __restrict__ K,
+                                               const __bf16* __restrict__ Vt, __bf16* __restrict__ O, int n_seq) {
+    const int lane = threadIdx.x & 63, head = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
+    const int seq = blockIdx.x;
+    if (seq >= n_seq) return;
+    const __bf16* q = Q + (size_t)seq * 32 * 512 + head * 128;
+    const __bf16* k = K + (size_t)seq * 32 * 512 + head * 128;
+    f32x4 s[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 kf[2], qf[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            kf[f] = *reinterpret_cast<const bf16x8*>(k + (size_t)(16 * f + lr) * 512 + 32 * ks + 8 * g);
+            qf[f] = *reinterpret_cast<const bf16x8*>(q + (size_t)(16 * f + lr) * 512 + 32 * ks + 8 * g);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) s[i][j] = MFMA16(kf[i], qf[j], s[i][j]);
+    }
+    // s[kf][qf][r] = S[q = 16qf + lr][key = 16kf + 4g + r]
+    const float sc = 0.08838834764831845f * 1.4426950408889634f;   // 128^-0.5 * log2(e)
+    bf16x8 pf[2];
+    float inv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float mx = fmaxf(fmaxf(fmaxf(s[0][j][0], s[0][j][1]), fmaxf(s[0][j][2], s[0][j][3])),
+                         fmaxf(fmaxf(s[1][j][0], s[1][j][1]), fmaxf(s[1][j][2], s[1][j][3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const __bf16 p = (__bf16)exp2f((s[i][j][r] - mx) * sc);
+                pf[j][i * 4 + r] = p;
+                sum += (float)p;
+            }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        inv[j] = 1.0f / sum;
+    }
+    const __bf16* vt = Vt + (size_t)(seq * 4 + head) * 128 * 32;
+    __bf16* o = O + (size_t)seq * 32 * 512 + head * 128;
+#pragma unroll
+    for (int df = 0; df < 8; ++df) {
+        const __bf16* vr = vt + (size_t)(16 * df + lr) * 32 + 4 * g;
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + 16);
+        bf16x8 vf;
+        vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+        vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 acc = MFMA16(vf, pf[j], (f32x4{0.f, 0.f, 0.f, 0.f}));
+            // acc[r] = O[q = 16j + lr][d = 16df + 4g + r]
+            *reinterpret_cast<bf16x4*>(o + (size_t)(16 * j + lr) * 512 + 16 * df + 4 * g) = to_bf16x4(acc * inv[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Guidance combine: hc[c][m][:] = sum_v w[c][v] * H[v*Mb + m][:]  -> bf16 (operand of the output GEMM)
+__global__ void k_combine(const float* __restrict__ H, const float* __restrict__ w, int V, int Mb,
+                          __bf16* __restrict__ hc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 each
+    const size_t per = (size_t)Mb * kNT / 4;
+    if (i >= per * 3) return;
+    const int c = (int)(i / per);
+    const size_t e = (i % per) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < V; ++v) s = s + *reinterpret_cast<const f32x4*>(H + (size_t)v * Mb * kNT + e) * w[c * V + v];
+    *reinterpret_cast<bf16x4*>(hc + (size_t)c * Mb * kNT + e) = to_bf16x4(s);
+}
+
+// fp32 W[n][k] -> packed bf16 fragments: out[((nf*KS + ks)*64 + lane)*8 + e] = W[16nf + (lane&15)][32ks + 8(lane>>4) + e]
+__global__ void k_pack(const float* __restrict__ W, int N, int K, uint4* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int KS = K / 32;
+    if (idx >= (N / 16) * KS * 64) return;
+    const int lane = idx & 63, f = idx >> 6, ks = f % KS, nf = f / KS;
+    const float* src = W + (size_t)(16 * nf + (lane & 15)) * K + 32 * ks + 8 * (lane >> 4);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+    bf16x8 r;
+    r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+    r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+    out[idx] = __builtin_bit_cast(uint4, r);
+}
+
+// (B,1536,32) <-> (B,32,1536): 64 channels x 32 frames per block through a padded LDS tile.
+__global__ __launch_bounds__(256) void k_to_token_major(const float* __restrict__ x, float* __restrict__ of,
+                                                         __bf16* __restrict__ ob) {
+    __shared__ float tile[64][33];
+    const int b = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * 256, c = idx >> 5, t = idx & 31;
+        tile[c][t] = x[((size_t)b * SYN_C + c0 + c) * 32 + t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * 256, t = idx >> 6, c = idx & 63;
+        const float v = tile[c][t];
+        const size_t o = ((size_t)b * 32 + t) * SYN_C + c0 + c;
+        if (of) of[o] = v;
+        if (ob) ob[o] = (__bf16)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_from_token_major(const float* __restrict__ x, float* __restrict__ out) {
+    __shared__ float tile[64][33];
+    const int b = blockIdx.x, c0 = blockIdx.y * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * 256, t = idx >> 6, c = idx & 63;
+        tile[c][t] = x[((size_t)b * 32 + t) * SYN_C + c0 + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + i * 256, c = idx >> 5, t = idx & 31;
+        out[((size_t)b * SYN_C + c0 + c) * 32 + t] = tile[c][t];
+    }
+}
+
+__global__ void k_axpby_rows(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ ab,
+                             const int* __restrict__ t_row, long n4, int per_clip4, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int r = t_row[i / per_clip4];
+    const float a = ab[2 * r], b = ab[2 * r + 1];
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i], yv = reinterpret_cast<const f32x4*>(y)[i];
+    reinterpret_cast<f32x4*>(out)[i] = xv * a + yv * b;
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter = (index/4, stream_id), key = seed; Box-Muller pairs.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+
+__global__ void k_randn(float* __restrict__ out, long n4, uint64_t seed, uint64_t stream_id, long first4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const uint64_t ctr = (uint64_t)(first4 + i);
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    const float inv32 = 2.3283064365386963e-10f;   // 2^-32
+    f32x4 z;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float u1 = ((float)c[2 * p] + 0.5f) * inv32;           // (0,1)
+        const float u2 = ((float)c[2 * p + 1] + 0.5f) * inv32;
+        const float rad = sqrtf(-2.0f * __logf(u1));
+        float sn, cs;
+        __sincosf(6.283185307179586f * u2, &sn, &cs);
+        z[2 * p] = rad * cs;
+        z[2 * p + 1] = rad * sn;
+    }
+    reinterpret_cast<f32x4*>(out)[i] = z;
+}
+
+// ------------------------------------------------------------------------------------------------
+thread_local char g_err[256] = "";
+
+int fail(const char* what, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return -1;
+}
+int fail_msg(const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s", what);
+    return -2;
+}
+
+template <int EPI>
+int launch_gemm(const GArgs& a, int mt, int chunks, hipStream_t s) {
+    if (a.K % kKT != 0 || a.M <= 0) return fail_msg("gemm: K must be a multiple of 64 and M > 0");
+    dim3 grid((a.M + mt - 1) / mt, chunks), block(kThreads);
+    switch (mt) {
+        case 128: hipLaunchKernelGGL((k_gemm<128, EPI>), grid, block, 2 * 128 * 128, s, a); break;
+        case 64:  hipLaunchKernelGGL((k_gemm<64, EPI>), grid, block, 2 * 64 * 128, s, a); break;
+        case 32:  hipLaunchKernelGGL((k_gemm<32, EPI>), grid, block, 2 * 32 * 128 + 1024, s, a); break;
+        default:  return fail_msg("gemm: m_tile must be 32, 64 or 128");
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_gemm launch", e);
+}
+
+int pick_tile(int rows) {
+    // enough workgroups to cover the 256 CUs first, then the largest tile (weight reuse per L2 byte)
+    if (rows / 128 >= 192) return 128;
+    if (rows / 64 >= 192) return 64;
+    return 32;
+}
+
+}  // namespace
+
+extern "C" {
+
+int syn_version(void) { return SYN_ABI_VERSION; }
+const char* syn_last_error(void) { return g_err; }
+
+int syn_pack_weight(const float* w, int32_t n, int32_t k, void* out_packed, void* stream) {
+    if (!w || !out_packed || n % 16 || k % 32) return fail_msg("syn_pack_weight: need n%16==0, k%32==0, non-null pointers");
+    const int total = (n / 16) * (k / 32) * 64;
+    hipLaunchKernelGGL(k_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, n, k, (uint4*)out_packed);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_pack launch", e);
+}
+
+int syn_to_token_major(const float* x_bct, int32_t n_clips, float* out_f32, void* out_bf16, void* stream) {
+    if (!x_bct || n_clips <= 0) return fail_msg("syn_to_token_major: bad arguments");
+    hipLaunchKernelGGL(k_to_token_major, dim3(n_clips, SYN_C / 64), dim3(256), 0, (hipStream_t)stream, x_bct, out_f32,
+                       (__bf16*)out_bf16);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_to_token_major launch", e);
+}
+
+int syn_from_token_major(const float* x_btc, int32_t n_clips, float* out_bct, void* stream) {
+    if (!x_btc || !out_bct || n_clips <= 0) return fail_msg("syn_from_token_major: bad arguments");
+    hipLaunchKernelGGL(k_from_token_major, dim3(n_clips, SYN_C / 64), dim3(256), 0, (hipStream_t)stream, x_btc, out_bct);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_from_token_major launch", e);
+}
+
+int syn_axpby_rows(const float* x, const float* y, const float* coef_ab, const int32_t* t_row, int32_t n_clips,
+                   int32_t per_clip, float* out, void* stream) {
+    if (!x || !y || !coef_ab || !t_row || !out || n_clips <= 0 || per_clip % 4) return fail_msg("syn_axpby_rows: bad arguments");
+    const long n4 = (long)n_clips * per_clip / 4;
+    hipLaunchKernelGGL(k_axpby_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, coef_ab,
+                       t_row, n4, per_clip / 4, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_axpby_rows launch", e);
+}
+
+int syn_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t first_index, void* stream) {
+    if (!out || n <= 0 || n % 4 || first_index % 4) return fail_msg("syn_randn: n and first_index must be multiples of 4");
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(k_randn, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n4, seed,
+                       stream_id, (long)(first_index / 4));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_randn launch", e);
+}
+
+int syn_test_gemm(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k,
+                  int32_t m_tile, float* y, void* stream) {
+    if (!x_bf16 || !w_packed || !y || n % kNT) return fail_msg("syn_test_gemm: n must be a multiple of 512");
+    GArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = (const __bf16*)x_bf16; a.ldx = k; a.x_rows = m_rows; a.W = (const uint4*)w_packed; a.K = k; a.M = m_rows;
+    a.bias = bias; a.Yf = y; a.ldyf = n;
+    return launch_gemm<EPI_PLAIN>(a, m_tile ? m_tile : pick_tile(m_rows), n / kNT, (hipStream_t)stream);
+}
+
+int syn_test_attention(const void* q, const void* k, const void* vt, int32_t n_seq, void* o, void* stream) {
+    if (!q || !k || !vt || !o || n_seq <= 0) return fail_msg("syn_test_attention: bad arguments");
+    hipLaunchKernelGGL(k_attn, dim3(n_seq), dim3(256), 0, (hipStream_t)stream, (const __bf16*)q, (const __bf16*)k,
+                       (const __bf16*)vt, (__bf16*)o, n_seq);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_attn launch", e);
+}
+
+int syn_denoise_step(const syn_model* md, const syn_step* st, void* stream) {
+    if (!md || !st) return fail_msg("syn_denoise_step: null model/step");
+    const int B = st->n_clips, V = st->n_variants;
+    if (B <= 0 || V <= 0) return fail_msg("syn_denoise_step: n_clips and n_variants must be positive");
+    if (V > 1 && (!st->cfg_w || !st->ws_hc)) return fail_msg("syn_denoise_step: n_variants > 1 needs cfg_w and ws_hc");
+    if (!st->cond || !st->t_model || !st->x_t || !st->x_t_bf16 || !st->coef || !st->t_coef || !st->x_next ||
+        !st->x_next_bf16 || !st->ws_h || !st->ws_xn || !st->ws_q || !st->ws_k || !st->ws_vt || !st->ws_o || !st->ws_hid)
+        return fail_msg("syn_denoise_step: null state/workspace pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int Mb = B * SYN_T, R = V * Mb;
+    const int mt = st->m_tile ? st->m_tile : pick_tile(R);
+    int rc;
+    GArgs a;
+
+    // input stage: h = rotary(x_t A^T + cond + te[t]); xn = LN1_0(h)
+    memset(&a, 0, sizeof(a));
+    a.X = (const __bf16*)st->x_t_bf16; a.ldx = SYN_C; a.x_rows = Mb; a.W = (const uint4*)md->w_in; a.K = SYN_C; a.M = R;
+    a.cond = st->cond; a.te = md->te; a.t_model = st->t_model; a.rcos = md->rot_cos; a.rsin = md->rot_sin;
+    a.H = st->ws_h; a.Y = (__bf16*)st->ws_xn; a.ldy = SYN_D; a.ln_g = md->layer[0].ln1_g; a.ln_b = md->layer[0].ln1_b;
+    if ((rc = launch_gemm<EPI_IN>(a, mt, 1, s))) return rc;
+
+    for (int l = 0; l < SYN_LAYERS; ++l) {
+        const syn_layer& L = md->layer[l];
+        // qkv
+        memset(&a, 0, sizeof(a));
+        a.X = (const __bf16*)st->ws_xn; a.ldx = SYN_D; a.x_rows = R; a.W = (const uint4*)L.w_qkv; a.K = SYN_D; a.M = R;
+        a.Q = (__bf16*)st->ws_q; a.Kb = (__bf16*)st->ws_k; a.Vt = (__bf16*)st->ws_vt;
+        if ((rc = launch_gemm<EPI_QKV>(a, mt, 3, s))) return rc;
+        // attention
+        hipLaunchKernelGGL(k_attn, dim3(R / SYN_T), dim3(256), 0, s, (const __bf16*)st->ws_q, (const __bf16*)st->ws_k,
+                           (const __bf16*)st->ws_vt, (__bf16*)st->ws_o, R / SYN_T);
+        // proj + residual, LN2 -> xn
+        memset(&a, 0, sizeof(a));
+        a.X = (const __bf16*)st->ws_o; a.ldx = SYN_D; a.x_rows = R; a.W = (const uint4*)L.w_proj; a.K = SYN_D; a.M = R;
+        a.bias = L.b_proj; a.H = st->ws_h; a.Y = (__bf16*)st->ws_xn; a.ldy = SYN_D; a.ln_g = L.ln2_g; a.ln_b = L.ln2_b;
+        if ((rc = launch_gemm<EPI_RESID>(a, mt, 1, s))) return rc;
+        // fc1 + gelu
+        memset(&a, 0, sizeof(a));
+        a.X = (const __bf16*)st->ws_xn; a.ldx = SYN_D; a.x_rows = R; a.W = (const uint4*)L.w_fc1; a.K = SYN_D; a.M = R;
+        a.bias = L.b_fc1; a.Y = (__bf16*)st->ws_hid; a.ldy = SYN_FF;
+        if ((rc = launch_gemm<EPI_GELU>(a, mt, 2, s))) return rc;
+        // fc2 + residual, next block's LN1 -> xn (last block: plain bf16 copy, there is no final norm)
+        memset(&a, 0, sizeof(a));
+        a.X = (const __bf16*)st->ws_hid; a.ldx = SYN_FF; a.x_rows = R; a.W = (const uint4*)L.w_fc2; a.K = SYN_FF; a.M = R;
+        a.bias = L.b_fc2; a.H = st->ws_h; a.Y = (__bf16*)st->ws_xn; a.ldy = SYN_D;
+        if (l + 1 < SYN_LAYERS) { a.ln_g = md->layer[l + 1].ln1_g; a.ln_b = md->layer[l + 1].ln1_b; }
+        if ((rc = launch_gemm<EPI_RESID>(a, mt, 1, s))) return rc;
+    }
+
+    // output stage (+ guidance combination of the variants, linear so it commutes with the GEMM)
+    memset(&a, 0, sizeof(a));
+    if (V > 1) {
+        const size_t n4 = (size_t)3 * Mb * kNT / 4;
+        hipLaunchKernelGGL(k_combine, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, st->ws_h, st->cfg_w, V, Mb,
+                           (__bf16*)st->ws_hc);
+        a.X = (const __bf16*)st->ws_hc; a.x_chunk_stride = (long)Mb * kNT;
+    } else {
+        a.X = (const __bf16*)st->ws_xn;
+    }
+    a.ldx = SYN_D; a.x_rows = Mb; a.W = (const uint4*)md->w_out; a.K = SYN_D; a.M = Mb; a.bias = md->b_out;
+    a.Xt = st->x_t; a.noise = st->noise; a.coef = st->coef; a.t_coef = st->t_coef;
+    a.Xn = st->x_next; a.Xnb = (__bf16*)st->x_next_bf16; a.X0 = st->pred_x0;
+    if ((rc = launch_gemm<EPI_OUT>(a, st->m_tile ? st->m_tile : pick_tile(Mb), 3, s))) return rc;
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_denoise_step", e);
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+"""Device-side engine: packed weights, workspaces and the fused denoising step / sampling loop.
+
+Layout in HBM (one GPU, everything resident for the whole loop):
+    packed weights   bf16 MFMA-fragment order, 19.1 M params = 38 MB          (syn_pack_weight)
+    x                token-major fp32 [B*32][1536] + bf16 shadow copy (GEMM operand), updated in place
+    cond             fp32 [V*B*32][512], computed once per clip (conditioning.py)
+    workspace        h fp32 [R][512]; xn/q/k/o bf16 [R][512]; vt bf16 [R*512]; hid bf16 [R][1024]   (R = V*B*32)
+One step = one ``syn_denoise_step`` call = 42 kernel launches, hipGraph-captured and replayed; the
+timestep enters through two device int32 vectors so the same graph serves every step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .conditioning import ClipConditioner, fold_input_stage, rotary_tables, time_table
+
+T, CH, D, FF, LAYERS = 32, 1536, 512, 1024, 8
+
+
+def _require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _lib.SynHipError(
+            f"{what} is on {t.device}: the denoising path runs only on the MI355X HIP kernels "
+            "(no CPU fallback). Move the model and inputs to a cuda device.")
+
+
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """fp32 (n, k) nn.Linear weight -> packed bf16 MFMA fragments (uint8 view of n*k*2 bytes)."""
+    _require_cuda(w, "weight")
+    w = w.detach().float().contiguous()
+    n, k = w.shape
+    out = torch.empty(n * k * 2, dtype=torch.uint8, device=w.device)
+    _lib.check(_lib.load().syn_pack_weight(w.data_ptr(), n, k, out.data_ptr(), _lib.current_stream()), "syn_pack_weight")
+    return out
+
+
+class PackedModel:
+    """Folded + packed, step-resident view of an MDM state_dict (inference; eval-mode semantics)."""
+
+    def __init__(self, sd: dict, variant: str, use_style: bool, n_te: int = 1000):
+        dev = sd["input_process2.weight"].device
+        _require_cuda(sd["input_process2.weight"], "model")
+        self.device, self.variant, self.use_style = dev, variant, use_style
+        f32 = lambda t: t.detach().float().contiguous()
+        folded = fold_input_stage(sd, use_style)
+        self.folded = folded
+        self.keep = []                       # every tensor the C struct points at
+        m = _lib.SynModel()
+
+        def hold(t):
+            self.keep.append(t)
+            return t.data_ptr()
+
+        m.w_in = hold(pack_weight(folded["A"].float()))
+        self.te = time_table(sd, folded["W2a"], n_te)
+        m.te, m.n_te = hold(self.te), n_te
+        rc, rs = rotary_tables(f32(sd["rel_pos.inv_freq"]), T)
+        m.rot_cos, m.rot_sin = hold(rc), hold(rs)
+        for i in range(LAYERS):
+            p, L = f"mytimmblocks.{i}.", m.layer[i]
+            L.ln1_g, L.ln1_b = hold(f32(sd[p + "norm1.weight"])), hold(f32(sd[p + "norm1.bias"]))
+            L.w_qkv = hold(pack_weight(sd[p + "attn.qkv.weight"]))
+            L.w_proj, L.b_proj = hold(pack_weight(sd[p + "attn.proj.weight"])), hold(f32(sd[p + "attn.proj.bias"]))
+            L.ln2_g, L.ln2_b = hold(f32(sd[p + "norm2.weight"])), hold(f32(sd[p + "norm2.bias"]))
+            L.w_fc1, L.b_fc1 = hold(pack_weight(sd[p + "mlp.fc1.weight"])), hold(f32(sd[p + "mlp.fc1.bias"]))
+            L.w_fc2, L.b_fc2 = hold(pack_weight(sd[p + "mlp.fc2.weight"])), hold(f32(sd[p + "mlp.fc2.bias"]))
+        m.w_out = hold(pack_weight(sd["output_process.poseFinal.weight"]))
+        m.b_out = hold(f32(sd["output_process.poseFinal.bias"]))
+        self.c = m
+        self.conditioner = ClipConditioner({k: (v.detach() if torch.is_tensor(v) else v) for k, v in sd.items()},
+                                           folded, variant, use_style)
+        torch.cuda.current_stream(dev).synchronize()
+
+
+class StepBuffers:
+    """State + workspace for B clips x V conditioning variants; owns the syn_step struct."""
+
+    def __init__(self, B: int, V: int, device, want_x0: bool = False, m_tile: int = 0):
+        self.B, self.V = B, V
+        R, Mb = V * B * T, B * T
+        e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=device)
+        bf = torch.bfloat16
+        self.x, self.xb = e(Mb, CH), e(Mb, CH, dt=bf)
+        self.noise = e(Mb, CH)
+        self.x0 = e(Mb, CH) if want_x0 else None
+        self.cond = e(R, D)
+        self.t_model = torch.zeros(V * B, dtype=torch.int32, device=device)
+        self.t_coef = torch.zeros(B, dtype=torch.int32, device=device)
+        self.cfg_w = e(3, V) if V > 1 else None
+        self.h = e(R, D)
+        self.xn, self.q, self.k, self.o = e(R, D, dt=bf), e(R, D, dt=bf), e(R, D, dt=bf), e(R, D, dt=bf)
+        self.vt, self.hid = e(R * D, dt=bf), e(R, FF, dt=bf)
+        self.hc = e(3, Mb, D, dt=bf) if V > 1 else None
+        s = _lib.SynStep()
+        s.n_clips, s.n_variants, s.m_tile = B, V, m_tile
+        s.cond, s.t_model, s.cfg_w = self.cond.data_ptr(), self.t_model.data_ptr(), _lib.ptr(self.cfg_w)
+        s.x_t, s.x_t_bf16, s.noise = self.x.data_ptr(), self.xb.data_ptr(), self.noise.data_ptr()
+        s.t_coef = self.t_coef.data_ptr()
+        s.x_next, s.x_next_bf16, s.pred_x0 = self.x.data_ptr(), self.xb.data_ptr(), _lib.ptr(self.x0)
+        s.ws_h, s.ws_xn, s.ws_q, s.ws_k = self.h.data_ptr(), self.xn.data_ptr(), self.q.data_ptr(), self.k.data_ptr()
+        s.ws_vt, s.ws_o, s.ws_hid, s.ws_hc = self.vt.data_ptr(), self.o.data_ptr(), self.hid.data_ptr(), _lib.ptr(self.hc)
+        self.c = s
+
+    # layout ------------------------------------------------------------------------------------
+    def load_x(self, x_bct: torch.Tensor):
+        """(B,1536,1,32) fp32 -> token-major x + bf16 shadow."""
+        x_bct = x_bct.detach().float().contiguous()
+        _lib.check(_lib.load().syn_to_token_major(x_bct.data_ptr(), self.B, self.x.data_ptr(), self.xb.data_ptr(),
+                                                  _lib.current_stream()), "syn_to_token_major")
+
+    def load_noise(self, eps_bct: torch.Tensor):
+        eps_bct = eps_bct.detach().float().contiguous()
+        _lib.check(_lib.load().syn_to_token_major(eps_bct.data_ptr(), self.B, self.noise.data_ptr(), None,
+                                                  _lib.current_stream()), "syn_to_token_major")
+
+    def draw_noise(self, seed: int, step: int, first_clip: int = 0):
+        """N(0,1) keyed by (seed, step, global element index): identical for any sharding of the batch."""
+        n = self.B * T * CH
+        _lib.check(_lib.load().syn_randn(self.noise.data_ptr(), n, seed, step, first_clip * T * CH,
+                                         _lib.current_stream()), "syn_randn")
+
+    def read(self, src: torch.Tensor) -> torch.Tensor:
+        out = torch.empty(self.B, CH, 1, T, dtype=torch.float32, device=src.device)
+        _lib.check(_lib.load().syn_from_token_major(src.data_ptr(), self.B, out.data_ptr(), _lib.current_stream()),
+                   "syn_from_token_major")
+        return out
+
+
+def run_step(pm: PackedModel, sb: StepBuffers, coef: torch.Tensor, use_noise: bool = True):
+    sb.c.coef = coef.data_ptr()
+    sb.c.noise = sb.noise.data_ptr() if use_noise else None
+    _lib.check(_lib.load().syn_denoise_step(C.byref(pm.c), C.byref(sb.c), _lib.current_stream()), "syn_denoise_step")
+
+
+class StepGraph:
+    """hipGraph of one step; replays read the timestep from sb.t_model / sb.t_coef (device memory)."""
+
+    def __init__(self, pm: PackedModel, sb: StepBuffers, coef: torch.Tensor, use_noise: bool = True):
+        self.pm, self.sb, self.coef = pm, sb, coef
+        side = torch.cuda.Stream(device=pm.device)
+        side.wait_stream(torch.cuda.current_stream(pm.device))
+        with torch.cuda.stream(side):          # warm-up launch outside capture (module load, etc.)
+            x_save, xb_save = sb.x.clone(), sb.xb.clone()
+            run_step(pm, sb, coef, use_noise)
+            sb.x.copy_(x_save); sb.xb.copy_(xb_save)
+        torch.cuda.current_stream(pm.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            run_step(pm, sb, coef, use_noise)
+
+    def replay(self):
+        self.graph.replay()
+
+
+# ---------------------------------------------------------------------------------------------
+def posterior_coefs(tab: dict, device) -> torch.Tensor:
+    """DDPM ancestral step as x_next = c0*x0 + c1*x_t + sigma*eps (gaussian_diffusion.py:255-277, 546-556)."""
+    n = len(tab["betas"])
+    c = np.zeros((n, 4), np.float64)
+    c[:, 0], c[:, 1] = tab["posterior_mean_coef1"], tab["posterior_mean_coef2"]
+    c[:, 2] = np.exp(0.5 * tab["posterior_log_variance_clipped"])
+    c[0, 2] = 0.0                                         # nonzero_mask: no noise at t == 0
+    return torch.tensor(c, dtype=torch.float32, device=device)
+
+
+def ddim_coefs(tab: dict, eta: float, device) -> torch.Tensor:
+    """DDIM step in the same linear form (gaussian_diffusion.py:771-791):
+         eps_hat = (sqrt(1/ab) x_t - x0) / sqrt(1/ab - 1)
+         x_next  = sqrt(ab_prev) x0 + sqrt(1 - ab_prev - sigma^2) eps_hat + sigma eps."""
+    ab, abp = tab["alphas_cumprod"], tab["alphas_cumprod_prev"]
+    sigma = eta * np.sqrt((1 - abp) / (1 - ab)) * np.sqrt(1 - ab / abp)
+    dirc = np.sqrt(1 - abp - sigma ** 2)
+    r, rm1 = tab["sqrt_recip_alphas_cumprod"], tab["sqrt_recipm1_alphas_cumprod"]
+    c = np.zeros((len(ab), 4), np.float64)
+    c[:, 0] = np.sqrt(abp) - dirc / rm1
+    c[:, 1] = dirc * r / rm1
+    c[:, 2] = sigma
+    c[0, 2] = 0.0
+    return torch.tensor(c, dtype=torch.float32, device=device)
+
+
+def identity_coefs(device) -> torch.Tensor:
+    """x_next = x0: a bare model evaluation (MDM.forward)."""
+    return torch.tensor([[1.0, 0.0, 0.0, 0.0]], dtype=torch.float32, device=device)

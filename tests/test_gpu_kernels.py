@@ -1,0 +1,96 @@
+"""Unit parity of the individual HIP stages, through the C ABI, vs plain fp32 torch on the same
+bf16-rounded operands.  Asymmetric random data so a transposed MFMA fragment cannot pass."""
+import pytest
+import torch
+
+from tests.conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from syntalker_amd import _lib
+    return _lib
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("mt", [32, 64, 128])
+@pytest.mark.parametrize("m,n,k", [(32, 512, 512), (96, 1536, 512), (160, 512, 1024), (288, 1024, 1536)])
+def test_gemm_matches_fp32_matmul(lib, mt, m, n, k):
+    from syntalker_amd import engine
+    g = torch.Generator().manual_seed(m * 7 + n + k)
+    x = torch.randn(m, k, generator=g).cuda()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    xb = _bf(x).contiguous()
+    wp = engine.pack_weight(w)
+    y = torch.empty(m, n, device="cuda")
+    lib.check(lib.load().syn_test_gemm(xb.data_ptr(), wp.data_ptr(), b.data_ptr(), m, n, k, mt, y.data_ptr(),
+                                       lib.current_stream()), "syn_test_gemm")
+    torch.cuda.synchronize()
+    want = xb.float() @ _bf(w).float().T + b
+    # same bf16 operands, fp32 accumulate on both sides: only summation order differs
+    assert rel_l2(y.cpu(), want.cpu()) < 2e-6
+    assert torch.isfinite(y).all()
+
+
+def test_gemm_tile_sizes_agree_bitwise(lib):
+    """The per-element K-summation order does not depend on the M tile."""
+    from syntalker_amd import engine
+    g = torch.Generator().manual_seed(5)
+    x, w = _bf(torch.randn(256, 512, generator=g)).cuda(), torch.randn(512, 512, generator=g).cuda()
+    wp = engine.pack_weight(w)
+    outs = []
+    for mt in (32, 64, 128):
+        y = torch.empty(256, 512, device="cuda")
+        lib.check(lib.load().syn_test_gemm(x.data_ptr(), wp.data_ptr(), None, 256, 512, 512, mt, y.data_ptr(),
+                                           lib.current_stream()), "syn_test_gemm")
+        outs.append(y.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
+@pytest.mark.parametrize("n_seq", [1, 5])
+def test_attention_matches_sdpa(lib, n_seq):
+    g = torch.Generator().manual_seed(n_seq)
+    q, k, v = (torch.randn(n_seq, 32, 4, 128, generator=g) for _ in range(3))
+    q = q * 2.0                                      # sharper softmax than unit-variance logits
+    qb, kb, vb = _bf(q).cuda(), _bf(k).cuda(), _bf(v).cuda()
+    vt = vb.permute(0, 2, 3, 1).contiguous()         # [seq][head][d][token]
+    o = torch.empty(n_seq, 32, 512, dtype=torch.bfloat16, device="cuda")
+    lib.check(lib.load().syn_test_attention(qb.reshape(n_seq, 32, 512).contiguous().data_ptr(),
+                                            kb.reshape(n_seq, 32, 512).contiguous().data_ptr(), vt.data_ptr(), n_seq,
+                                            o.data_ptr(), lib.current_stream()), "syn_test_attention")
+    torch.cuda.synchronize()
+    want = torch.nn.functional.scaled_dot_product_attention(
+        qb.float().permute(0, 2, 1, 3).cpu(), kb.float().permute(0, 2, 1, 3).cpu(), vb.float().permute(0, 2, 1, 3).cpu())
+    want = want.permute(0, 2, 1, 3).reshape(n_seq, 32, 512)
+    assert rel_l2(o.float().cpu(), want) < 8e-3      # P and O are rounded to bf16
+
+
+def test_layout_round_trip_and_bf16_shadow(lib):
+    x = torch.randn(3, 1536, 1, 32).cuda()
+    tm, tb = torch.empty(3 * 32, 1536, device="cuda"), torch.empty(3 * 32, 1536, dtype=torch.bfloat16, device="cuda")
+    lib.check(lib.load().syn_to_token_major(x.data_ptr(), 3, tm.data_ptr(), tb.data_ptr(), lib.current_stream()), "to")
+    assert torch.equal(tm.view(3, 32, 1536), x[:, :, 0, :].permute(0, 2, 1))
+    assert torch.equal(tb, tm.to(torch.bfloat16))
+    back = torch.empty_like(x)
+    lib.check(lib.load().syn_from_token_major(tm.data_ptr(), 3, back.data_ptr(), lib.current_stream()), "from")
+    assert torch.equal(back, x)
+
+
+def test_randn_is_standard_normal_and_shard_invariant(lib):
+    n = 1 << 20
+    a = torch.empty(n, device="cuda")
+    lib.check(lib.load().syn_randn(a.data_ptr(), n, 1234, 7, 0, lib.current_stream()), "randn")
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 1) < 5e-3
+    assert abs(float((a ** 4).mean()) - 3.0) < 0.05          # kurtosis of N(0,1)
+    b = torch.empty(n // 2, device="cuda")                   # second half drawn on "another rank"
+    lib.check(lib.load().syn_randn(b.data_ptr(), n // 2, 1234, 7, n // 2, lib.current_stream()), "randn")
+    assert torch.equal(b, a[n // 2:])
+    c = torch.empty(n, device="cuda")
+    lib.check(lib.load().syn_randn(c.data_ptr(), n, 1234, 8, 0, lib.current_stream()), "randn")
+    assert abs(float((a * c).mean())) < 5e-3                 # different step -> independent
