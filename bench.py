@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — denoising-steps/sec of the SynTalker hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B]
+
+One "step" = one DDPM denoising step (denoiser evaluation + posterior update, hipGraph replay) over a
+batch of B synthetic 128-frame clips per GPU (latent (B,1536,1,32)); metric = clip-steps/s over ALL
+GPUs (BASELINE.json: "denoising-steps/sec (128-frame clips)").  Workload = configs[1]
+(diffusion_rvqvae_128 sampling, p_sample_loop, bf16 operands / fp32 accumulate): random-init weights
+of the reference architecture, synthetic audio/word/seed conditioning, computed ONCE per clip before
+the timed region exactly as the fused p_sample_loop does (its cost is reported separately).
+Clips shard across GPUs with no collective (weak scaling: B per GPU is fixed).
+
+Extra objects on the JSON line:
+  roofline      dominant kernel: algorithmic FLOPs per launch / average launch duration (hipEvents around
+                every launch of eager steps run right after the timed region) vs the dense bf16 MFMA peak.
+  cpu_baseline  the as-written CPU restatement of the reference forward (oracle/) timed on the host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+F_STEP = 1_192_755_200            # algorithmic FLOPs per clip-step
+PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak, MI355X_MICROARCH.md
+STAGES = ["in_gemm", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm", "cfg_combine", "out_gemm"]
+# kernel symbol + algorithmic FLOPs per clip per launch for each stage class
+STAGE_INFO = {
+    "in_gemm": ("k_gemm<MT,EPI_IN>", 2 * 32 * 1536 * 512),
+    "qkv_gemm": ("k_gemm<MT,EPI_QKV>", 2 * 32 * 512 * 1536),
+    "attention": ("k_attn", 2 * 2 * 4 * 32 * 32 * 128),
+    "proj_gemm": ("k_gemm<MT,EPI_RESID>", 2 * 32 * 512 * 512),
+    "fc1_gemm": ("k_gemm<MT,EPI_GELU>", 2 * 32 * 512 * 1024),
+    "fc2_gemm": ("k_gemm<MT,EPI_RESID>", 2 * 32 * 1024 * 512),
+    "out_gemm": ("k_gemm<MT,EPI_OUT>", 2 * 32 * 512 * 1536),
+}
+
+
+def cpu_baseline(budget_s: float):
+    """Reference forward as written (no hoisting / folding), fp32, torch CPU, B=1 — SURVEY.md §8d protocol."""
+    from oracle import denoiser_ref as dr
+    from syntalker_amd import synth
+    from tests.refmodel import synth_state_dict
+    sd = synth_state_dict("beatx")
+    y, x = synth.synth_clip_inputs(1, seed=1), synth.synth_latent(1, seed=1)
+    n_threads = torch.get_num_threads()
+    with torch.no_grad():
+        for i in range(3):
+            dr.mdm_forward(sd, x, torch.tensor([999 - i]), y)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            dr.mdm_forward(sd, x, torch.tensor([996 - n % 900]), y)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s and n >= 20:
+                break
+    return {"value": round(n / dt, 2), "unit": "clip-steps/s", "cores": n_threads, "kind": "port",
+            "sample": f"{n} as-written MDM forwards at B=1 (fp32, torch {torch.__version__} CPU, "
+                      f"{n_threads} threads, conditioning recomputed every step like the reference), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1024, help="clips per GPU")
+    ap.add_argument("--m-tile", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from syntalker_amd import _lib, engine, synth
+    from syntalker_amd.denoiser import MDM
+    from syntalker_amd.process import create_gaussian_diffusion
+
+    B, K, W = args.batch, args.steps, args.warmup
+    model = synth.synth_fill_(MDM(synth.default_args()).eval(), seed=0).to(dev)
+    model.m_tile = args.m_tile
+    diff = create_gaussian_diffusion()
+    pm = model.packed()
+
+    # per-clip conditioning, once, in chunks (the audio encoder's activations are the only large temporaries)
+    sb = model.buffers(B, 1)
+    torch.cuda.synchronize()
+    tc0 = time.perf_counter()
+    chunk = 64
+    for b0 in range(0, B, chunk):
+        n = min(chunk, B - b0)
+        y = synth.to_device(synth.synth_clip_inputs(n, seed=1000 * rank + b0), dev)
+        sb.cond.view(B, 32, 512)[b0:b0 + n].copy_(pm.conditioner.cond(y))
+    torch.cuda.synchronize()
+    cond_ms_per_clip = (time.perf_counter() - tc0) * 1e3 / B
+
+    x_T = torch.randn(B, 1536, 1, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
+    sb.load_x(x_T)
+    coef = engine.posterior_coefs(diff.tables(), dev)
+    graph = engine.StepGraph(pm, sb, coef, True)
+
+    def step(i):                       # exactly the body of the fused p_sample_loop
+        sb.t_coef.fill_(i)
+        sb.t_model.fill_(i)
+        sb.draw_noise(1234, i, first_clip=rank * B)
+        graph.replay()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_idx = 999
+    for _ in range(W):
+        step(t_idx); t_idx = (t_idx - 1) % 1000
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step(t_idx); t_idx = (t_idx - 1) % 1000
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(sb.x).all(), "non-finite latent after the timed steps"
+
+    if rank == 0:
+        value = world * B * K / dt
+        # ---- per-kernel durations: hipEvents around every launch of 5 eager steps ----------------
+        ms = (C.c_float * 8)()
+        cnt = (C.c_int32 * 8)()
+        tot, launches = [0.0] * 8, [0] * 8
+        reps = 5
+        for r in range(reps):
+            sb.t_coef.fill_(500); sb.t_model.fill_(500)
+            sb.c.coef = coef.data_ptr(); sb.c.noise = sb.noise.data_ptr()
+            _lib.check(_lib.load().syn_denoise_step_profile(C.byref(pm.c), C.byref(sb.c), _lib.current_stream(), ms, cnt),
+                       "syn_denoise_step_profile")
+            for c in range(8):
+                tot[c] += ms[c]; launches[c] += cnt[c]
+        stage_ms = {STAGES[c]: tot[c] / reps for c in range(8) if launches[c]}
+        # group by kernel symbol (proj and fc2 share one)
+        by_kernel = {}
+        for name, t in stage_ms.items():
+            if name not in STAGE_INFO:
+                continue
+            sym, fl = STAGE_INFO[name]
+            n_l = launches[STAGES.index(name)] // reps
+            e = by_kernel.setdefault(sym, {"ms": 0.0, "launches": 0, "flops": 0.0})
+            e["ms"] += t; e["launches"] += n_l; e["flops"] += fl * B * n_l
+        dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
+        d = by_kernel[dom]
+        avg_s = d["ms"] * 1e-3 / d["launches"]
+        achieved = d["flops"] / d["launches"] / avg_s
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                pj = json.load(open(tpath))
+                if pj.get("batch") == B:
+                    traffic = pj.get("hbm_bytes_per_launch", {}).get(dom)
+            except Exception:
+                traffic = None
+        roofline = {"bound": "mfma", "kernel": dom.replace("MT", str(args.m_tile or "auto")),
+                    "achieved": round(achieved / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16, 4), "traffic": traffic,
+                    "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": d["launches"],
+                    "whole_step_frac": round(value / world * F_STEP / PEAK_BF16, 4),
+                    "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}}
+        out = {
+            "metric": "denoising-steps/sec (128-frame clips)", "value": round(value, 1), "unit": "clip-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "diffusion_rvqvae_128.yaml sampling: DDPM p_sample_loop steps (1000-step schedule), "
+                                   f"{B} clips/GPU x (1536,1,32) latents, MDM denoiser 8x512, random-init",
+                       "clips_per_gpu": B, "global_clips": world * B, "parallelism": f"clip-sharded x{world}, no collective",
+                       "m_tile": args.m_tile or "auto"},
+            "latency_note": "one step advances every clip of the batch; per-clip conditioning (audio/word/seed encoders, "
+                            f"PyTorch-ROCm) ran once before the timed region: {cond_ms_per_clip:.3f} ms/clip",
+            "roofline": roofline,
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,6 +98,11 @@ typedef struct syn_step {
 /* Enqueue one full step (42 kernels) on `stream`. */
 int syn_denoise_step(const syn_model* model, const syn_step* step, void* stream);
 
+/* Same step, eagerly, with a hipEvent after every launch: fills ms_out[8] / count_out[8] with the elapsed
+ * milliseconds and launch count per stage class {0 input GEMM, 1 qkv GEMM, 2 attention, 3 proj GEMM,
+ * 4 fc1 GEMM, 5 fc2 GEMM, 6 guidance combine, 7 output GEMM}.  Synchronises `stream`; not graph-capturable. */
+int syn_denoise_step_profile(const syn_model* model, const syn_step* step, void* stream, float* ms_out, int32_t* count_out);
+
 /* ---- load-time helpers -------------------------------------------------------------------- */
 /* fp32 row-major W[n][k] (nn.Linear.weight layout) -> packed bf16 fragments (n*k*2 bytes).
  * n % 16 == 0, k % 32 == 0. */

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Average per-dispatch counter values per kernel from a rocprofv3 counter_collection.csv (our kernels only)."""
+import csv
+import sys
+from collections import defaultdict
+
+acc = defaultdict(lambda: defaultdict(float))
+disp = defaultdict(set)
+with open(sys.argv[1]) as f:
+    for r in csv.DictReader(f):
+        k = r["Kernel_Name"]
+        if "k_gemm" not in k and "k_attn" not in k and "k_randn" not in k and "k_combine" not in k and "k_lay" not in k:
+            continue
+        k = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
+names = sorted({c for v in acc.values() for c in v})
+print("kernel,dispatches," + ",".join(names))
+for k in sorted(acc):
+    n = len(disp[k])
+    print(f"{k},{n}," + ",".join(f"{acc[k].get(c, 0.0) / n:.4g}" for c in names))

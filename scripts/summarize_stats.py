@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Trim a rocprofv3 kernel_stats.csv to a committed summary: our kernels in full + the top foreign kernels."""
+import csv
+import sys
+
+src, dst, note = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "")
+rows = list(csv.DictReader(open(src)))
+ours = [r for r in rows if "anonymous namespace" in r["Name"] or "syn_" in r["Name"]]
+other = [r for r in rows if r not in ours][:8]
+with open(dst, "w") as f:
+    f.write(f"# rocprofv3 --kernel-trace --stats summary ({note})\n")
+    f.write("# columns: calls, total_ms, avg_us, pct_of_all_gpu_time, min_us, max_us, kernel\n")
+    f.write("## syntalker_amd kernels\n")
+    for r in ours:
+        n = r["Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+        f.write(f"{int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:10.3f} {float(r['AverageNs'])/1e3:10.2f} "
+                f"{float(r['Percentage']):6.2f} {float(r['MinNs'])/1e3:9.2f} {float(r['MaxNs'])/1e3:9.2f}  {n[:90]}\n")
+    f.write("## largest other kernels (PyTorch-ROCm/MIOpen conditioning encoders, once per clip, outside the timed region)\n")
+    for r in other:
+        f.write(f"{int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:10.3f} {float(r['AverageNs'])/1e3:10.2f} "
+                f"{float(r['Percentage']):6.2f} {float(r['MinNs'])/1e3:9.2f} {float(r['MaxNs'])/1e3:9.2f}  {r['Name'][:90]}\n")

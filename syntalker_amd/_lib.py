@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsyn_hip.so")
 
 SYN_LAYERS = 8
-EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_pack_weight", "syn_to_token_major",
+EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_step_profile", "syn_pack_weight", "syn_to_token_major",
            "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_test_gemm", "syn_test_attention")
 
 vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
@@ -58,6 +58,7 @@ def load():
     lib.syn_version.restype = C.c_int
     lib.syn_last_error.restype = C.c_char_p
     lib.syn_denoise_step.argtypes = [C.POINTER(SynModel), C.POINTER(SynStep), vp]
+    lib.syn_denoise_step_profile.argtypes = [C.POINTER(SynModel), C.POINTER(SynStep), vp, vp, vp]
     lib.syn_pack_weight.argtypes = [vp, i32, i32, vp, vp]
     lib.syn_to_token_major.argtypes = [vp, i32, vp, vp, vp]
     lib.syn_from_token_major.argtypes = [vp, i32, vp, vp]

@@ -61,6 +61,7 @@ struct GArgs {
     float* Xn; __bf16* Xnb; float* X0;
     // plain fp32 output (unit tests)
     float* Yf; int ldyf;
+    int ablate;   // diagnostics (syn_test_gemm only): 1 = weights loaded once, 2 = activations staged once, 4 = no store
 };
 
 __device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
@@ -80,7 +81,7 @@ __device__ __forceinline__ float gelu_erf(float x) {   // nn.GELU() default: exa
 template <int MT, bool SWAP>
 __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[4][MT / 16], const __bf16* __restrict__ X, int ldx,
                                               int x_rows, int m0, int M, int K, const uint4* __restrict__ Wq,
-                                              char* smem) {
+                                              char* smem, const int ablate = 0) {
     constexpr int MF = MT / 16;
     constexpr int NLD = (MT * 8 + kThreads - 1) / kThreads;   // 16-byte staging loads per thread per K tile
     constexpr int BUF = MT * 128;
@@ -144,10 +145,10 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[4][MT / 16], const __
     for (int kt = 0; kt < NKT; ++kt) {
         const int buf = kt & 1;
         const bool more = kt + 1 < NKT;
-        if (more) stage_load(kt + 1);
-        w_load(wb, kt * 2 + 1);
+        if (more && !(ablate & 2)) stage_load(kt + 1);
+        if (!(ablate & 1) || kt == 0) w_load(wb, kt * 2 + 1);
         compute(wa, buf, 0);
-        if (more) w_load(wa, kt * 2 + 2);
+        if (more && !(ablate & 1)) w_load(wa, kt * 2 + 2);
         compute(wb, buf, 1);
         if (more) stage_store(buf ^ 1);
         __syncthreads();
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm(const GArgs a) {
     if (swap)
         gemm_mainloop<MT, true>(acc, X, a.ldx, a.x_rows, m0, a.M, a.K, Wq, smem);
     else
-        gemm_mainloop<MT, false>(acc, X, a.ldx, a.x_rows, m0, a.M, a.K, Wq, smem);
+        gemm_mainloop<MT, false>(acc, X, a.ldx, a.x_rows, m0, a.M, a.K, Wq, smem, EPI == EPI_PLAIN ? a.ablate : 0);
 
     const int ncol = chunk * kNT + wave * 64;   // first global output column of this wave
 
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(kThreads) void k_gemm(const GArgs a) {
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
                 const int m = m0 + mf * 16 + lr;
-                if (m < a.M) *reinterpret_cast<f32x4*>(a.Yf + (size_t)m * a.ldyf + n) = acc[nf][mf] + b;
+                if (m < a.M && (!(a.ablate & 4) || acc[nf][mf][0] == 12345.678f))
+                    *reinterpret_cast<f32x4*>(a.Yf + (size_t)m * a.ldyf + n) = acc[nf][mf] + b;
             }
         }
     } else if constexpr (EPI == EPI_IN) {
@@ -661,6 +663,8 @@ int syn_test_gemm(const void* x_bf16, const void* w_packed, const float* bias, i
     memset(&a, 0, sizeof(a));
     a.X = (const __bf16*)x_bf16; a.ldx = k; a.x_rows = m_rows; a.W = (const uint4*)w_packed; a.K = k; a.M = m_rows;
     a.bias = bias; a.Yf = y; a.ldyf = n;
+    a.ablate = m_tile >> 16;              // diagnostics: upper bits of m_tile
+    m_tile &= 0xffff;
     return launch_gemm<EPI_PLAIN>(a, m_tile ? m_tile : pick_tile(m_rows), n / kNT, (hipStream_t)stream);
 }
 
@@ -672,7 +676,23 @@ int syn_test_attention(const void* q, const void* k, const void* vt, int32_t n_s
     return e == hipSuccess ? 0 : fail("k_attn launch", e);
 }
 
-int syn_denoise_step(const syn_model* md, const syn_step* st, void* stream) {
+// Stage classes reported by syn_denoise_step_profile (index into ms[] / count[]).
+enum { ST_IN = 0, ST_QKV = 1, ST_ATTN = 2, ST_PROJ = 3, ST_FC1 = 4, ST_FC2 = 5, ST_COMBINE = 6, ST_OUT = 7, ST_N = 8 };
+
+struct StageTimer {          // optional hipEvent after every launch
+    bool on = false;
+    hipStream_t s = nullptr;
+    hipEvent_t ev[64];
+    int cls[64];
+    int n = 0;
+    void begin(hipStream_t st) { on = true; s = st; hipEventCreate(&ev[0]); hipEventRecord(ev[0], s); n = 1; }
+    void mark(int c) {
+        if (!on || n >= 64) return;
+        hipEventCreate(&ev[n]); hipEventRecord(ev[n], s); cls[n] = c; ++n;
+    }
+};
+
+static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, StageTimer* tm) {
     if (!md || !st) return fail_msg("syn_denoise_step: null model/step");
     const int B = st->n_clips, V = st->n_variants;
     if (B <= 0 || V <= 0) return fail_msg("syn_denoise_step: n_clips and n_variants must be positive");
@@ -680,11 +700,11 @@ int syn_denoise_step(const syn_model* md, const syn_step* st, void* stream) {
     if (!st->cond || !st->t_model || !st->x_t || !st->x_t_bf16 || !st->coef || !st->t_coef || !st->x_next ||
         !st->x_next_bf16 || !st->ws_h || !st->ws_xn || !st->ws_q || !st->ws_k || !st->ws_vt || !st->ws_o || !st->ws_hid)
         return fail_msg("syn_denoise_step: null state/workspace pointer");
-    hipStream_t s = (hipStream_t)stream;
     const int Mb = B * SYN_T, R = V * Mb;
     const int mt = st->m_tile ? st->m_tile : pick_tile(R);
     int rc;
     GArgs a;
+    auto mark = [&](int c) { if (tm) tm->mark(c); };
 
     // input stage: h = rotary(x_t A^T + cond + te[t]); xn = LN1_0(h)
     memset(&a, 0, sizeof(a));
@@ -692,6 +712,7 @@ int syn_denoise_step(const syn_model* md, const syn_step* st, void* stream) {
     a.cond = st->cond; a.te = md->te; a.t_model = st->t_model; a.rcos = md->rot_cos; a.rsin = md->rot_sin;
     a.H = st->ws_h; a.Y = (__bf16*)st->ws_xn; a.ldy = SYN_D; a.ln_g = md->layer[0].ln1_g; a.ln_b = md->layer[0].ln1_b;
     if ((rc = launch_gemm<EPI_IN>(a, mt, 1, s))) return rc;
+    mark(ST_IN);
 
     for (int l = 0; l < SYN_LAYERS; ++l) {
         const syn_layer& L = md->layer[l];
@@ -700,25 +721,30 @@ int syn_denoise_step(const syn_model* md, const syn_step* st, void* stream) {
         a.X = (const __bf16*)st->ws_xn; a.ldx = SYN_D; a.x_rows = R; a.W = (const uint4*)L.w_qkv; a.K = SYN_D; a.M = R;
         a.Q = (__bf16*)st->ws_q; a.Kb = (__bf16*)st->ws_k; a.Vt = (__bf16*)st->ws_vt;
         if ((rc = launch_gemm<EPI_QKV>(a, mt, 3, s))) return rc;
+        mark(ST_QKV);
         // attention
         hipLaunchKernelGGL(k_attn, dim3(R / SYN_T), dim3(256), 0, s, (const __bf16*)st->ws_q, (const __bf16*)st->ws_k,
                            (const __bf16*)st->ws_vt, (__bf16*)st->ws_o, R / SYN_T);
+        mark(ST_ATTN);
         // proj + residual, LN2 -> xn
         memset(&a, 0, sizeof(a));
         a.X = (const __bf16*)st->ws_o; a.ldx = SYN_D; a.x_rows = R; a.W = (const uint4*)L.w_proj; a.K = SYN_D; a.M = R;
         a.bias = L.b_proj; a.H = st->ws_h; a.Y = (__bf16*)st->ws_xn; a.ldy = SYN_D; a.ln_g = L.ln2_g; a.ln_b = L.ln2_b;
         if ((rc = launch_gemm<EPI_RESID>(a, mt, 1, s))) return rc;
+        mark(ST_PROJ);
         // fc1 + gelu
         memset(&a, 0, sizeof(a));
         a.X = (const __bf16*)st->ws_xn; a.ldx = SYN_D; a.x_rows = R; a.W = (const uint4*)L.w_fc1; a.K = SYN_D; a.M = R;
         a.bias = L.b_fc1; a.Y = (__bf16*)st->ws_hid; a.ldy = SYN_FF;
         if ((rc = launch_gemm<EPI_GELU>(a, mt, 2, s))) return rc;
+        mark(ST_FC1);
         // fc2 + residual, next block's LN1 -> xn (last block: plain bf16 copy, there is no final norm)
         memset(&a, 0, sizeof(a));
         a.X = (const __bf16*)st->ws_hid; a.ldx = SYN_FF; a.x_rows = R; a.W = (const uint4*)L.w_fc2; a.K = SYN_FF; a.M = R;
         a.bias = L.b_fc2; a.H = st->ws_h; a.Y = (__bf16*)st->ws_xn; a.ldy = SYN_D;
         if (l + 1 < SYN_LAYERS) { a.ln_g = md->layer[l + 1].ln1_g; a.ln_b = md->layer[l + 1].ln1_b; }
         if ((rc = launch_gemm<EPI_RESID>(a, mt, 1, s))) return rc;
+        mark(ST_FC2);
     }
 
     // output stage (+ guidance combination of the variants, linear so it commutes with the GEMM)
@@ -727,6 +753,7 @@ int syn_denoise_step(const syn_model* md, const syn_step* st, void* stream) {
         const size_t n4 = (size_t)3 * Mb * kNT / 4;
         hipLaunchKernelGGL(k_combine, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, st->ws_h, st->cfg_w, V, Mb,
                            (__bf16*)st->ws_hc);
+        mark(ST_COMBINE);
         a.X = (const __bf16*)st->ws_hc; a.x_chunk_stride = (long)Mb * kNT;
     } else {
         a.X = (const __bf16*)st->ws_xn;
@@ -735,8 +762,30 @@ int syn_denoise_step(const syn_model* md, const syn_step* st, void* stream) {
     a.Xt = st->x_t; a.noise = st->noise; a.coef = st->coef; a.t_coef = st->t_coef;
     a.Xn = st->x_next; a.Xnb = (__bf16*)st->x_next_bf16; a.X0 = st->pred_x0;
     if ((rc = launch_gemm<EPI_OUT>(a, st->m_tile ? st->m_tile : pick_tile(Mb), 3, s))) return rc;
+    mark(ST_OUT);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("syn_denoise_step", e);
+}
+
+int syn_denoise_step(const syn_model* md, const syn_step* st, void* stream) {
+    return step_impl(md, st, (hipStream_t)stream, nullptr);
+}
+
+int syn_denoise_step_profile(const syn_model* md, const syn_step* st, void* stream, float* ms_out, int32_t* count_out) {
+    if (!ms_out || !count_out) return fail_msg("syn_denoise_step_profile: null output");
+    StageTimer tm;
+    tm.begin((hipStream_t)stream);
+    const int rc = step_impl(md, st, (hipStream_t)stream, &tm);
+    for (int c = 0; c < ST_N; ++c) { ms_out[c] = 0.f; count_out[c] = 0; }
+    if (tm.n > 1) hipEventSynchronize(tm.ev[tm.n - 1]);
+    for (int i = 1; i < tm.n; ++i) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, tm.ev[i - 1], tm.ev[i]);
+        ms_out[tm.cls[i]] += ms;
+        count_out[tm.cls[i]] += 1;
+    }
+    for (int i = 0; i < tm.n; ++i) hipEventDestroy(tm.ev[i]);
+    return rc;
 }
 
 }  // extern "C"
