@@ -32,13 +32,27 @@ F_STEP = 1_192_755_200            # algorithmic FLOPs per clip-step (SURVEY.md Â
 PEAK_BF16 = 2.5e15                # dense bf16 MFMA peak, MI355X_MICROARCH.md
 STAGES = ["in_gemm", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm", "cfg_combine", "out_gemm"]
 # kernel symbol + algorithmic FLOPs per clip per launch for each stage class
-STAGE_INFO = {
+_ATT = 2 * 2 * 4 * 32 * 32 * 128
+STAGE_INFO_LEGACY = {
     "in_gemm": ("k_gemm<MT,EPI_IN>", 2 * 32 * 1536 * 512),
     "qkv_gemm": ("k_gemm<MT,EPI_QKV>", 2 * 32 * 512 * 1536),
-    "attention": ("k_attn", 2 * 2 * 4 * 32 * 32 * 128),
+    "attention": ("k_attn", _ATT),
     "proj_gemm": ("k_gemm<MT,EPI_RESID>", 2 * 32 * 512 * 512),
     "fc1_gemm": ("k_gemm<MT,EPI_GELU>", 2 * 32 * 512 * 1024),
     "fc2_gemm": ("k_gemm<MT,EPI_RESID>", 2 * 32 * 1024 * 512),
+    "out_gemm": ("k_gemm<MT,EPI_OUT>", 2 * 32 * 512 * 1536),
+}
+_BLOCK = 2 * 32 * 512 * 1536 + _ATT + 2 * 32 * 512 * 512 + 2 * 2 * 32 * 512 * 1024
+STAGE_INFO_STACK = {
+    "in_gemm": ("k_gemm<MT,EPI_IN>", 2 * 32 * 1536 * 512),
+    "fc2_gemm": ("k_stack<MT>", 8 * _BLOCK),
+    "out_gemm": ("k_gemm<MT,EPI_OUT>", 2 * 32 * 512 * 1536),
+}
+# fused layer kernels report under the qkv / fc2 stage slots of syn_denoise_step_profile
+STAGE_INFO_FUSED = {
+    "in_gemm": ("k_gemm<MT,EPI_IN>", 2 * 32 * 1536 * 512),
+    "qkv_gemm": ("k_attn_block<MT>", 2 * 32 * 512 * 1536 + _ATT),
+    "fc2_gemm": ("k_mlp_block<MT>", 2 * 32 * 512 * 512 + 2 * 2 * 32 * 512 * 1024),
     "out_gemm": ("k_gemm<MT,EPI_OUT>", 2 * 32 * 512 * 1536),
 }
 
@@ -75,6 +89,7 @@ def main():
     ap.add_argument("--m-tile", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--layer-mode", type=int, default=0, help="0 whole-stack kernel, 2 two kernels/block, 1 five kernels/block (A/B)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -94,6 +109,8 @@ def main():
     B, K, W = args.batch, args.steps, args.warmup
     model = synth.synth_fill_(MDM(synth.default_args()).eval(), seed=0).to(dev)
     model.m_tile = args.m_tile
+    model.layer_mode = args.layer_mode
+    STAGE_INFO = {0: STAGE_INFO_STACK, 1: STAGE_INFO_LEGACY, 2: STAGE_INFO_FUSED}[args.layer_mode]
     diff = create_gaussian_diffusion()
     pm = model.packed()
 
@@ -155,6 +172,7 @@ def main():
                        "syn_denoise_step_profile")
             for c in range(8):
                 tot[c] += ms[c]; launches[c] += cnt[c]
+        rename = {0: {"fc2_gemm": "stack"}, 1: {}, 2: {"qkv_gemm": "attn_block", "fc2_gemm": "mlp_block"}}[args.layer_mode]
         stage_ms = {STAGES[c]: tot[c] / reps for c in range(8) if launches[c]}
         # group by kernel symbol (proj and fc2 share one)
         by_kernel = {}
@@ -183,7 +201,7 @@ def main():
                     "frac": round(achieved / PEAK_BF16, 4), "traffic": traffic,
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": d["launches"],
                     "whole_step_frac": round(value / world * F_STEP / PEAK_BF16, 4),
-                    "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}}
+                    "stage_ms_per_step": {rename.get(k, k): round(v, 4) for k, v in stage_ms.items()}}
         out = {
             "metric": "denoising-steps/sec (128-frame clips)", "value": round(value, 1), "unit": "clip-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),

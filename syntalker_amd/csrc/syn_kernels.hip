@@ -70,16 +70,35 @@ __device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
     return r;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) {   // nn.GELU() default: exact erf form
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+// nn.GELU() default = exact erf form 0.5 x (1 + erf(x / sqrt2)).  erf by Abramowitz & Stegun 7.1.26
+// (|abs err| <= 1.5e-7, i.e. fp32-roundoff class) with v_rcp_f32 / v_exp_f32: ~16 VALU ops per element.
+// The ocml erff() call it replaces measured ~300 cycles per element-wave: 28 % of the fused MLP kernel.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erf_abs = fmaf(-p * t, e, 1.0f);                 // erf(|x|/sqrt2)
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
 // ------------------------------------------------------------------------------------------------
-// Main loop: acc[nf][mf] += W-frag(nf) x X-frag(mf) over K.
-//   SWAP=false: acc[nf][mf][r] = out[m = 16mf + (l&15)][n = 16nf + 4(l>>4) + r]
-//   SWAP=true : acc[nf][mf][r] = out[m = 16mf + 4(l>>4) + r][n = 16nf + (l&15)]
-template <int MT, bool SWAP>
-__device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[4][MT / 16], const __bf16* __restrict__ X, int ldx,
+// Main loop: acc[nf][mf] += W-frag(nf) x X-frag(mf) over K (K a multiple of 128).
+//   slot nf not in SWAPMASK: acc[nf][mf][r] = out[m = 16mf + (l&15)][n = 16nf' + 4(l>>4) + r]
+//   slot nf in SWAPMASK    : acc[nf][mf][r] = out[m = 16mf + 4(l>>4) + r][n = 16nf' + (l&15)]
+// Software pipeline (vmcnt retires loads IN ORDER, so every load is issued >= 3 k-steps before its
+// consumer and nothing urgent ever queues behind a younger long-latency load):
+//   * weight fragments: ring of 4 register slots, loaded 3 k-steps ahead straight from L2/MALL;
+//   * activation K-tiles: two register sets in flight (2 tiles ahead of the LDS store), LDS double buffer,
+//     one workgroup barrier per K-tile;
+//   * __builtin_amdgcn_sched_barrier(0) after each issue block: hipcc otherwise SINKS the prefetch loads
+//     down to their consumers (observed: at most 2-3 loads in flight, 76 % of wave cycles parked).
+// Wq: this lane's pointer to fragment (slot 0, k-step 0); fragment (nf, ks) is at Wq[((nf*FS)*KS + ks)*64].
+template <int MT, int NF, int FS, int SWAPMASK>
+__device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[NF][MT / 16], const __bf16* __restrict__ X, int ldx,
                                               int x_rows, int m0, int M, int K, const uint4* __restrict__ Wq,
                                               char* smem, const int ablate = 0) {
     constexpr int MF = MT / 16;
@@ -88,7 +107,6 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[4][MT / 16], const __
     const int tid = threadIdx.x, lane = tid & 63;
     const int KS = K / 32, NKT = K / kKT;
 
-    // staging assignment: 16-byte slot `slot` of tile row `row`
     const __bf16* src[NLD];
     int dst[NLD];
     bool live[NLD];
@@ -101,13 +119,14 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[4][MT / 16], const __
         src[i] = X + (size_t)(live[i] ? (m % x_rows) : 0) * ldx + slot * 8;
         dst[i] = row * 128 + ((slot ^ (row & 7)) << 4);
     }
-    uint4 st[NLD];
-    auto stage_load = [&](int kt) {
+    auto stage_load = [&](uint4 (&st)[NLD], int kt) {
+        if (kt < NKT && !((ablate & 2) && kt > 1)) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            st[i] = live[i] ? *reinterpret_cast<const uint4*>(src[i] + kt * kKT) : make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < NLD; ++i)
+                st[i] = live[i] ? *reinterpret_cast<const uint4*>(src[i] + kt * kKT) : make_uint4(0, 0, 0, 0);
+        }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](const uint4 (&st)[NLD], int buf) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
             if (NLD * kThreads == MT * 8 || tid + i * kThreads < MT * 8)
@@ -118,39 +137,65 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[4][MT / 16], const __
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) xoff[ks] = (lane & 15) * 128 + ((((4 * ks) + (lane >> 4)) ^ (lane & 7)) << 4);
 
-    // Weight fragments: two register sets, each prefetched one k-step (32 MFMAs ~ 500 cycles) ahead.
-    uint4 wa[4], wb[4];
-    auto w_load = [&](uint4 (&w)[4], int kstep) {
+    uint4 w0[NF], w1[NF], w2[NF], w3[NF];
+    auto w_load = [&](uint4 (&w)[NF], int kstep) {
+        if (kstep < KS && !((ablate & 1) && kstep > 3)) {
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) w[nf] = Wq[((size_t)nf * KS + kstep) * 64];
+            for (int nf = 0; nf < NF; ++nf) w[nf] = Wq[((size_t)(nf * FS) * KS + kstep) * 64];
+        }
     };
-    auto compute = [&](const uint4 (&w)[4], int buf, int ks) {
-        bf16x8 xf[MF];
+    auto compute = [&](const uint4 (&w)[NF], int buf, int ks) {
+        // activation fragments in groups of <= 4 (16 VGPRs) to stay inside the 256-register budget at MT = 128
+        constexpr int G = MF > 4 ? 4 : MF;
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf)
-            xf[mf] = *reinterpret_cast<const bf16x8*>(smem + buf * BUF + mf * 2048 + xoff[ks]);
+        for (int h = 0; h < MF / G; ++h) {
+            bf16x8 xf[G];
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const bf16x8 wf = __builtin_bit_cast(bf16x8, w[nf]);
+            for (int i = 0; i < G; ++i)
+                xf[i] = *reinterpret_cast<const bf16x8*>(smem + buf * BUF + (h * G + i) * 2048 + xoff[ks]);
 #pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-                acc[nf][mf] = SWAP ? MFMA16(xf[mf], wf, acc[nf][mf]) : MFMA16(wf, xf[mf], acc[nf][mf]);
+            for (int nf = 0; nf < NF; ++nf) {
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, w[nf]);
+#pragma unroll
+                for (int i = 0; i < G; ++i)
+                    acc[nf][h * G + i] = ((SWAPMASK >> nf) & 1) ? MFMA16(xf[i], wf, acc[nf][h * G + i])
+                                                                 : MFMA16(wf, xf[i], acc[nf][h * G + i]);
+            }
+            if (MF > G) __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    stage_load(0);
-    w_load(wa, 0);
-    stage_store(0);
+    uint4 sa[NLD], sb[NLD];
+    w_load(w0, 0);
+    w_load(w1, 1);
+    w_load(w2, 2);
+    stage_load(sa, 0);
+    stage_load(sb, 1);
+    stage_store(sa, 0);
+    stage_load(sa, 2);
     __syncthreads();
-    for (int kt = 0; kt < NKT; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < NKT;
-        if (more && !(ablate & 2)) stage_load(kt + 1);
-        if (!(ablate & 1) || kt == 0) w_load(wb, kt * 2 + 1);
-        compute(wa, buf, 0);
-        if (more && !(ablate & 1)) w_load(wa, kt * 2 + 2);
-        compute(wb, buf, 1);
-        if (more) stage_store(buf ^ 1);
+    for (int j = 0; 2 * j < NKT; ++j) {
+        const int s4 = 4 * j;
+        w_load(w3, s4 + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(w0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        w_load(w0, s4 + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(w1, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_store(sb, 1);                 // tile 2j+1 (loaded two tiles ago)
+        stage_load(sb, 2 * j + 3);
+        w_load(w1, s4 + 5);
+        __syncthreads();
+        compute(w2, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        w_load(w2, s4 + 6);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(w3, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (2 * j + 2 < NKT) stage_store(sa, 0);   // tile 2j+2
+        stage_load(sa, 2 * j + 4);
         __syncthreads();
     }
 }
@@ -220,6 +265,7 @@ __device__ __forceinline__ void store_h_and_norm(const GArgs& a, f32x4 (&v)[4][M
             for (int nf = 0; nf < 4; ++nf)
                 *reinterpret_cast<f32x4*>(a.H + (size_t)m * kNT + wave * 64 + nf * 16 + g * 4) = v[nf][mf];
     }
+    if (a.Y == nullptr) return;             // residual stream only (the fused stack normalises on chip)
     float mean[MF], rstd[MF];
     if (a.ln_g != nullptr) {
         float* red = reinterpret_cast<float*>(smem);
@@ -293,9 +339,9 @@ __global__ __launch_bounds__(kThreads) void k_gemm(const GArgs a) {
     const __bf16* X = a.X + (size_t)chunk * a.x_chunk_stride;
     const bool swap = (EPI == EPI_QKV) && (chunk == 2);
     if (swap)
-        gemm_mainloop<MT, true>(acc, X, a.ldx, a.x_rows, m0, a.M, a.K, Wq, smem);
+        gemm_mainloop<MT, 4, 1, 0xF>(acc, X, a.ldx, a.x_rows, m0, a.M, a.K, Wq, smem);
     else
-        gemm_mainloop<MT, false>(acc, X, a.ldx, a.x_rows, m0, a.M, a.K, Wq, smem, EPI == EPI_PLAIN ? a.ablate : 0);
+        gemm_mainloop<MT, 4, 1, 0>(acc, X, a.ldx, a.x_rows, m0, a.M, a.K, Wq, smem, EPI == EPI_PLAIN ? a.ablate : 0);
 
     const int ncol = chunk * kNT + wave * 64;   // first global output column of this wave
 
@@ -441,7 +487,7 @@ __global__ __launch_bounds__(256) void k_attn(const __bf16* __restrict__ Q, cons
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const __bf16 p = (__bf16)exp2f((s[i][j][r] - mx) * sc);
+                const __bf16 p = (__bf16)__builtin_amdgcn_exp2f((s[i][j][r] - mx) * sc);
                 pf[j][i * 4 + r] = p;
                 sum += (float)p;
             }
@@ -466,6 +512,560 @@ __global__ __launch_bounds__(256) void k_attn(const __bf16* __restrict__ Q, cons
             *reinterpret_cast<bf16x4*>(o + (size_t)(16 * j + lr) * 512 + 16 * df + 4 * g) = to_bf16x4(acc * inv[j]);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused attention half of a block:  O = softmax(q k^T / sqrt(128)) v,  [q|k|v] = xn . Wqkv^T.
+// One workgroup owns MT rows (MT/32 whole sequences) and walks the 4 heads; q, k, v of one head live
+// only in LDS (bf16) and the attention itself only in registers, so nothing but xn (read) and O
+// (write) touches HBM.  Per head every wave computes one 16-column fragment of q, one of k and one of
+// v for all MT rows (so the three accumulator slots have compile-time roles); v uses the swapped MFMA
+// orientation so it lands transposed ([d][token]) as the PV product wants it.
+//   LDS: [0, 2*MT*128)  activation K-tiles (double buffer)
+//        Qs  MT x 256 B   row = token, 16-B slots XOR-swizzled by (row & 15)
+//        Ks  MT x 256 B   same
+//        Vts MT/32 x 128 x 72 B   [sequence][d][token], rows padded 64 -> 72 B
+struct AArgs {
+    long long* dbg;       // diagnostics: per-workgroup phase timestamps (null in production)
+    const __bf16* X;      // [M][512] LN1 output
+    const uint4* W;       // packed qkv weight (1536 x 512)
+    __bf16* O;            // [M][512]
+    int M;
+};
+
+__device__ __forceinline__ void stamp(long long* dbg, int slot) {
+    if (dbg != nullptr && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 32 + slot] = (long long)__builtin_readcyclecounter();
+}
+
+template <int MT>
+__global__ __launch_bounds__(kThreads) void k_attn_block(const AArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MF = MT / 16;
+    constexpr int BUF = MT * 128;
+    constexpr int KS = SYN_D / 32;
+    char* const Qs = smem + 2 * BUF;
+    char* const Ks = Qs + MT * 256;
+    char* const Vts = Ks + MT * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lr = lane & 15;
+    const int m0 = blockIdx.x * MT;
+
+    stamp(a.dbg, 0);
+    for (int head = 0; head < SYN_HEADS; ++head) {
+        // ---- qkv GEMM for this head: 3 fragments per wave (q, k, v), K = 512 -------------------------
+        f32x4 acc[3][MF];
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) acc[sl][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // fragment of slot sl: n-frag sl*32 + head*8 + wave; slot 2 (v) uses the swapped orientation
+        gemm_mainloop<MT, 3, 32, 0x4>(acc, a.X, SYN_D, a.M, m0, a.M, SYN_D,
+                                      a.W + ((size_t)(head * 8 + wave) * KS) * 64 + lane, smem);
+        stamp(a.dbg, 1 + head * 3);
+        // ---- q, k -> LDS row-major (swizzled); v -> LDS transposed -----------------------------------
+        // q/k: acc[sl][mf][r] = [token 16mf + lr][d = 16*wave + 4g + r]
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int row = mf * 16 + lr;
+            const int off = row * 256 + ((((2 * wave) + (g >> 1)) ^ lr) << 4) + (g & 1) * 8;
+            *reinterpret_cast<bf16x4*>(Qs + off) = to_bf16x4(acc[0][mf]);
+            *reinterpret_cast<bf16x4*>(Ks + off) = to_bf16x4(acc[1][mf]);
+            // v: acc[2][mf][r] = [token 16mf + 4g + r][d = 16*wave + lr]
+            *reinterpret_cast<bf16x4*>(Vts + (mf >> 1) * (128 * 72) + (wave * 16 + lr) * 72 + ((mf & 1) * 16 + g * 4) * 2) =
+                to_bf16x4(acc[2][mf]);
+        }
+        __syncthreads();
+        stamp(a.dbg, 2 + head * 3);
+        // ---- attention: wave -> (sequence c, 16-query half qh) -----------------------------------------
+        if (wave < MT / 16) {
+            const int c = wave >> 1, qh = wave & 1;
+            const int qrow = c * 32 + qh * 16 + lr;
+            f32x4 sc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int so = (((4 * ks) + g) ^ lr) << 4;
+                const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + qrow * 256 + so);
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (c * 32 + f * 16 + lr) * 256 + so);
+                    sc[f] = MFMA16(kf, qf, sc[f]);
+                }
+            }
+            // sc[f][r] = S[q = lr][key = 16f + 4g + r]
+            const float scale = 0.08838834764831845f * 1.4426950408889634f;
+            float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
+                             fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            bf16x8 pf;
+            float sum = 0.f;
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const __bf16 pv = (__bf16)__builtin_amdgcn_exp2f((sc[f][r] - mx) * scale);
+                    pf[f * 4 + r] = pv;
+                    sum += (float)pv;
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            const char* vt = Vts + c * (128 * 72);
+            char* own = Qs + (c * 32 + qh * 16) * 256;      // this wave's 16 q rows: private, reused for O
+#pragma unroll
+            for (int df = 0; df < 8; ++df) {
+                const char* vr = vt + (16 * df + lr) * 72 + 8 * g;
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + 32);
+                bf16x8 vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                const f32x4 o = MFMA16(vf, pf, (f32x4{0.f, 0.f, 0.f, 0.f}));
+                // o[r] = O[q = lr][d = 16df + 4g + r]
+                *reinterpret_cast<bf16x4*>(own + lr * 256 + (16 * df + 4 * g) * 2) = to_bf16x4(o * inv);
+            }
+            // read the 16 x 256 B tile back row-major: 4 rows per instruction, 256 B contiguous per row
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 4 * i + g;
+                const uint4 v = *reinterpret_cast<const uint4*>(own + row * 256 + lr * 16);
+                const int m = m0 + c * 32 + qh * 16 + row;
+                if (m < a.M) *reinterpret_cast<uint4*>(a.O + (size_t)m * SYN_D + head * 128 + lr * 8) = v;
+            }
+        }
+        __syncthreads();
+        stamp(a.dbg, 3 + head * 3);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused MLP half of a block (plus the attention output projection in front of it):
+//   h  += o . Wproj^T + bproj ;  x2 = LN2(h)
+//   h  += gelu(x2 . W1^T + b1) . W2^T + b2 ;  y = LN1_next(h)  (or bf16(h) after the last block)
+// One workgroup owns MT = 64 (or 32) rows; the residual rows live in the fc2/proj accumulators
+// (wave w = columns [64w, 64w+64)), x2 (MT x 512 bf16) and one 256-wide slice of the hidden layer live
+// in LDS, so per layer only o (read), h (read+write) and y (write) touch HBM.  The fc1 K-loop reads the
+// resident x2 and needs no barrier; the hidden slices are double-buffered: one barrier per slice.
+//   LDS: [0, 2*MT*128) o K-tiles / LayerNorm scratch | X2 MT x 1024 B | HID 2 x MT x 512 B
+struct BArgs {
+    long long* dbg;       // diagnostics: per-workgroup phase timestamps (null in production)
+    const __bf16* O;  const uint4* Wp; const float* bp;
+    float* H;
+    const float* ln2_g; const float* ln2_b;
+    const uint4* W1; const float* b1; const uint4* W2; const float* b2;
+    const float* lnn_g; const float* lnn_b;     // next LayerNorm (null: y = bf16(h))
+    __bf16* Y;
+    int M;
+};
+
+template <int MT>
+__global__ __launch_bounds__(kThreads) void k_mlp_block(const BArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MF = MT / 16;
+    constexpr int HC = 256;                       // hidden columns per slice
+#ifndef SYN_D1
+#define SYN_D1 6
+#endif
+#ifndef SYN_D2
+#define SYN_D2 3
+#endif
+    constexpr int D1 = SYN_D1, D2 = SYN_D2;      // weight k-steps in flight in the fc1 / fc2 loops
+    char* const X2 = smem + 2 * MT * 128;
+    char* const HID = X2 + MT * 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lr = lane & 15;
+    const int m0 = blockIdx.x * MT;
+
+    stamp(a.dbg, 0);
+    // residual + proj bias -> accumulators
+    f32x4 acc[4][MF];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+        const int n = wave * 64 + nf * 16 + g * 4;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int m = m0 + mf * 16 + lr;
+            f32x4 h = {0.f, 0.f, 0.f, 0.f};
+            if (m < a.M) h = *reinterpret_cast<const f32x4*>(a.H + (size_t)m * kNT + n);
+            acc[nf][mf] = h + b;
+        }
+    }
+    gemm_mainloop<MT, 4, 1, 0>(acc, a.O, SYN_D, a.M, m0, a.M, SYN_D, a.Wp + ((size_t)(wave * 4) * (SYN_D / 32)) * 64 + lane, smem);
+
+    stamp(a.dbg, 1);
+    // x2 = LN2(h) -> LDS (bf16, 16-B slots swizzled by row & 15); accumulators keep h + b2
+    {
+        float mean[MF], rstd[MF];
+        float* red = reinterpret_cast<float*>(smem);
+        row_stats<MT>(acc, red, red + MT * 8, mean, rstd);
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int n = wave * 64 + nf * 16 + g * 4;
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(a.ln2_g + n), bb = *reinterpret_cast<const f32x4*>(a.ln2_b + n);
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.b2 + n);
+            const int slot = 8 * wave + 2 * nf + (g >> 1);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const f32x4 y = (acc[nf][mf] - mean[mf]) * rstd[mf] * gg + bb;
+                *reinterpret_cast<bf16x4*>(X2 + (mf * 16 + lr) * 1024 + ((slot ^ lr) << 4) + (g & 1) * 8) = to_bf16x4(y);
+                acc[nf][mf] = acc[nf][mf] + b2;
+            }
+        }
+    }
+    __syncthreads();
+
+    stamp(a.dbg, 2);
+    constexpr int KS1 = SYN_D / 32, KS2 = SYN_FF / 32;
+    const uint4* W2q = a.W2 + ((size_t)(wave * 4) * KS2) * 64 + lane;
+    for (int c = 0; c < SYN_FF / HC; ++c) {
+        // ---- fc1 slice: hidden[:, 256c + 32*wave + (0..31)] = x2 . W1^T, K = 512, no barriers --------------
+        f32x4 a1[2][MF];
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) a1[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint4* W1q = a.W1 + ((size_t)(c * 16 + wave * 2) * KS1) * 64 + lane;
+        uint4 wq[D1][2];                                  // ring of D1 k-steps in flight (latency of L2/MALL)
+#pragma unroll
+        for (int p = 0; p < D1 - 1; ++p)
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) wq[p][nf] = W1q[((size_t)nf * KS1 + p) * 64];
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) {
+            if (s + D1 - 1 < KS1)
+#pragma unroll
+                for (int nf = 0; nf < 2; ++nf) wq[(s + D1 - 1) % D1][nf] = W1q[((size_t)nf * KS1 + s + D1 - 1) * 64];
+            __builtin_amdgcn_sched_barrier(0);        // keep the prefetch D1-1 k-steps ahead (hipcc would sink it)
+            bf16x8 xf[MF];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+                xf[mf] = *reinterpret_cast<const bf16x8*>(X2 + (mf * 16 + lr) * 1024 + (((4 * s + g) ^ lr) << 4));
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, wq[s % D1][nf]);
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) a1[nf][mf] = MFMA16(wf, xf[mf], a1[nf][mf]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (c == 1) stamp(a.dbg, 16 + s);
+        }
+        stamp(a.dbg, 3 + c * 3);
+        // ---- gelu -> hidden slice in LDS (buffer c & 1) ---------------------------------------------------
+        char* const hb = HID + (c & 1) * (MT * 512);
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(a.b1 + c * HC + wave * 32 + nf * 16 + g * 4);
+            const int slot = 4 * wave + 2 * nf + (g >> 1);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                f32x4 v = a1[nf][mf] + b;
+                v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+                *reinterpret_cast<bf16x4*>(hb + (mf * 16 + lr) * 512 + ((slot ^ lr) << 4) + (g & 1) * 8) = to_bf16x4(v);
+            }
+        }
+        __syncthreads();
+        stamp(a.dbg, 4 + c * 3);
+        // ---- fc2 partial: h[:, 64*wave + ..] += hidden_slice . W2[:, 256c + ..]^T, K = 256 -------------------
+        uint4 w2[D2][4];
+#pragma unroll
+        for (int p = 0; p < D2 - 1; ++p)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) w2[p][nf] = W2q[((size_t)nf * KS2 + c * 8 + p) * 64];
+#pragma unroll
+        for (int s = 0; s < HC / 32; ++s) {
+            if (s + D2 - 1 < HC / 32)
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) w2[(s + D2 - 1) % D2][nf] = W2q[((size_t)nf * KS2 + c * 8 + s + D2 - 1) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 xf[MF];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+                xf[mf] = *reinterpret_cast<const bf16x8*>(hb + (mf * 16 + lr) * 512 + (((4 * s + g) ^ lr) << 4));
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, w2[s % D2][nf]);
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = MFMA16(wf, xf[mf], acc[nf][mf]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp(a.dbg, 5 + c * 3);
+    }
+    // ---- h out, next LayerNorm (or plain copy) -> y ---------------------------------------------------------
+    GArgs e;
+    e.H = a.H; e.Y = a.Y; e.ldy = SYN_D; e.ln_g = a.lnn_g; e.ln_b = a.lnn_b; e.M = a.M;
+    __syncthreads();                   // LayerNorm scratch aliases the o K-tile buffers; all waves are past them
+    store_h_and_norm<MT>(e, acc, m0, smem);
+    stamp(a.dbg, 15);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_stack: the WHOLE 8-block transformer stack for one 64-row tile (2 sequences) in one kernel.
+// Rows of different sequences never interact (attention is per sequence), so a workgroup can carry its
+// tile through all 8 blocks with no grid-level synchronisation: the fp32 residual rows live in the
+// accumulator registers for the entire stack (wave w = columns [64w, 64w+64), 64 VGPRs), every
+// intermediate (LayerNorm outputs, q/k/v of one head, attention output, MLP hidden slices) lives in LDS
+// as bf16, and the only HBM traffic of the stack is h in (fp32), y out (bf16) and the weight stream,
+// which all workgroups walk in the same order so it is served by L2 / the 256 MB Infinity Cache.
+// Every GEMM piece is the same barrier-free loop: B operand = activation rows resident in LDS,
+// A operand = weight fragments streamed straight from L2 into a register ring D k-steps deep.
+//   LDS (130 KB): XN 64x1024 B (LayerNorm output, slots swizzled by row&15)
+//                 region B 64 KB: { QS 64x256 | KS 64x256 | VTS 2x128x72 } during attention,
+//                                 { HID 2 x 64x512 } during the MLP
+//                 RED 2.5 KB LayerNorm scratch
+struct SArgs {
+    float* H;             // [M][512] fp32 residual stream: read at entry, final value written back
+    __bf16* Y;            // [M][512] bf16(h_final): operand of the output GEMM
+    syn_layer layer[SYN_LAYERS];
+    int M;
+    int write_h;          // also write the final fp32 h (needed only by the guidance combine)
+    long long* dbg;
+};
+
+// Weight ring of a barrier-free GEMM piece: D k-steps x NF fragments.  kloop_prime issues the first D-1
+// k-steps (call it EARLY - before the barrier / LayerNorm / softmax that precedes the loop - so the ~1 us
+// L2-miss latency of the first fragments is hidden behind that work); kloop_run consumes it.
+template <int NF, int FS, int KSTEPS, int D>
+__device__ __forceinline__ void kloop_prime(uint4 (&ring)[D][NF], const uint4* __restrict__ Wq, int KS, int kbase) {
+#pragma unroll
+    for (int p = 0; p < D - 1; ++p)
+        if (p < KSTEPS)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) ring[p][nf] = Wq[((size_t)(nf * FS) * KS + kbase + p) * 64];
+}
+
+// acc[nf][mf] += W(nf, kbase + s) x LDS-rows, s = 0..KSTEPS-1.  Row r of the operand is at base + r*ROWB,
+// 16-byte slot (4s + g) of the row holds k = 32s + 8g .. +7, stored at slot ^ (r & 15).
+template <int MF, int NF, int FS, int SWAPMASK, int KSTEPS, int ROWB, int D>
+__device__ __forceinline__ void kloop_run(f32x4 (&acc)[NF][MF], uint4 (&ring)[D][NF], const char* base,
+                                          const uint4* __restrict__ Wq, int KS, int kbase) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, lr = lane & 15;
+    const int lane_off = lr * ROWB + (((g ^ lr) & 3) << 4), hi = (lr & 12) << 4;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        if (s + D - 1 < KSTEPS)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) ring[(s + D - 1) % D][nf] = Wq[((size_t)(nf * FS) * KS + kbase + s + D - 1) * 64];
+        __builtin_amdgcn_sched_barrier(0);        // keep the prefetch D-1 k-steps ahead (hipcc would sink it)
+        // slot (4s+g) ^ lr = ((4s) ^ (lr & 12)) | ((g ^ lr) & 3): one xor + add per k-step; the asm keeps hipcc from
+        // hoisting all KSTEPS offsets out of the enclosing loops (16 live VGPRs per call site otherwise)
+        int hv = hi;
+        asm volatile("" : "+v"(hv));
+        const char* xrow = base + lane_off + ((64 * s) ^ hv);
+        bf16x8 xf[MF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) xf[mf] = *reinterpret_cast<const bf16x8*>(xrow + mf * 16 * ROWB);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, ring[s % D][nf]);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+                acc[nf][mf] = ((SWAPMASK >> nf) & 1) ? MFMA16(xf[mf], wf, acc[nf][mf]) : MFMA16(wf, xf[mf], acc[nf][mf]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// y = LayerNorm(h) * g + b -> bf16 rows in LDS (ROWB = 1024, slots swizzled by row & 15); then h += add[n].
+template <int MT>
+__device__ __forceinline__ void ln_to_lds(f32x4 (&h)[4][MT / 16], const float* __restrict__ lg, const float* __restrict__ lb,
+                                          const float* __restrict__ add, char* XN, float* red) {
+    constexpr int MF = MT / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
+    float mean[MF], rstd[MF];
+    row_stats<MT>(h, red, red + MT * 8, mean, rstd);
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+        const int n = wave * 64 + nf * 16 + g * 4;
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(lg + n), bb = *reinterpret_cast<const f32x4*>(lb + n);
+        const f32x4 ad = *reinterpret_cast<const f32x4*>(add + n);
+        const int slot = 8 * wave + 2 * nf + (g >> 1);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const f32x4 y = (h[nf][mf] - mean[mf]) * rstd[mf] * gg + bb;
+            *reinterpret_cast<bf16x4*>(XN + (mf * 16 + lr) * 1024 + ((slot ^ lr) << 4) + (g & 1) * 8) = to_bf16x4(y);
+            h[nf][mf] = h[nf][mf] + ad;
+        }
+    }
+}
+
+template <int MT>
+__global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MF = MT / 16;
+    constexpr int HC = 256;
+    char* const XN = smem;
+    char* const RB = smem + MT * 1024;              // region B
+    char* const Qs = RB;
+    char* const Ks = RB + MT * 256;
+    char* const Vts = RB + MT * 512;
+    float* const red = reinterpret_cast<float*>(RB + MT * 1024);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lr = lane & 15;
+    const int m0 = blockIdx.x * MT;
+    constexpr int KS1 = SYN_D / 32, KS2 = SYN_FF / 32;
+    stamp(a.dbg, 0);
+
+    f32x4 h[4][MF];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int m = m0 + mf * 16 + lr;
+            h[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < a.M) h[nf][mf] = *reinterpret_cast<const f32x4*>(a.H + (size_t)m * kNT + wave * 64 + nf * 16 + g * 4);
+        }
+
+#ifndef SYN_DQ
+#define SYN_DQ 4
+#endif
+#ifndef SYN_DP
+#define SYN_DP 3
+#endif
+#ifndef SYN_D1
+#define SYN_D1 6
+#endif
+#ifndef SYN_D2
+#define SYN_D2 3
+#endif
+    constexpr int DQ = SYN_DQ, DP = SYN_DP, D1 = SYN_D1, D2 = SYN_D2;   // weight-ring depths (k-steps in flight)
+    auto wqkv = [&](int l, int head) { return (const uint4*)a.layer[l].w_qkv + ((size_t)(head * 8 + wave) * KS1) * 64 + lane; };
+    for (int l = 0; l < SYN_LAYERS; ++l) {
+        const syn_layer& L = a.layer[l];
+        // Rings are declared per block so they are dead (not loop-carried registers) outside their phase.
+        uint4 rq[DQ][3];                           // qkv ring: primed one phase ahead of its loop
+        kloop_prime<3, 32, KS1, DQ>(rq, wqkv(l, 0), KS1, 0);      // in flight during LayerNorm 1
+        const uint4* const wproj = (const uint4*)L.w_proj + ((size_t)(wave * 4) * KS1) * 64 + lane;
+        const uint4* const wfc2 = (const uint4*)L.w_fc2 + ((size_t)(wave * 4) * KS2) * 64 + lane;
+        // ---- x1 = LN1(h) -> XN;  h += b_proj ------------------------------------------------------------
+        ln_to_lds<MT>(h, L.ln1_g, L.ln1_b, L.b_proj, XN, red);
+        __syncthreads();
+        if (l == 3) stamp(a.dbg, 1);
+        for (int head = 0; head < SYN_HEADS; ++head) {
+            // ---- q, k, v fragments of this head for all MT rows ------------------------------------------
+            f32x4 acc[3][MF];
+#pragma unroll
+            for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) acc[sl][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            kloop_run<MF, 3, 32, 0x4, KS1, 1024, DQ>(acc, rq, XN, wqkv(l, head), KS1, 0);
+            uint4 rp[DP][4];                        // proj ring: in flight during the attention
+            kloop_prime<4, 1, 4, DP>(rp, wproj, KS1, head * 4);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int row = mf * 16 + lr;
+                const int off = row * 256 + ((((2 * wave) + (g >> 1)) ^ lr) << 4) + (g & 1) * 8;
+                *reinterpret_cast<bf16x4*>(Qs + off) = to_bf16x4(acc[0][mf]);
+                *reinterpret_cast<bf16x4*>(Ks + off) = to_bf16x4(acc[1][mf]);
+                *reinterpret_cast<bf16x4*>(Vts + (mf >> 1) * (128 * 72) + (wave * 16 + lr) * 72 + ((mf & 1) * 16 + g * 4) * 2) =
+                    to_bf16x4(acc[2][mf]);
+            }
+            __syncthreads();
+            if (l == 3 && head == 0) stamp(a.dbg, 2);
+            // ---- attention: wave -> (sequence c, 16-query half qh); o overwrites the wave's own q rows ------
+            if (wave < MT / 16) {
+                const int c = wave >> 1, qh = wave & 1;
+                const int qrow = c * 32 + qh * 16 + lr;
+                f32x4 sc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int so = (((4 * ks) + g) ^ lr) << 4;
+                    const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + qrow * 256 + so);
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (c * 32 + f * 16 + lr) * 256 + so);
+                        sc[f] = MFMA16(kf, qf, sc[f]);
+                    }
+                }
+                const float scale = 0.08838834764831845f * 1.4426950408889634f;
+                float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
+                                 fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                bf16x8 pf;
+                float sum = 0.f;
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const __bf16 pv = (__bf16)__builtin_amdgcn_exp2f((sc[f][r] - mx) * scale);
+                        pf[f * 4 + r] = pv;
+                        sum += (float)pv;
+                    }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                const float inv = 1.0f / sum;
+                const char* vt = Vts + c * (128 * 72);
+#pragma unroll
+                for (int df = 0; df < 8; ++df) {
+                    const char* vr = vt + (16 * df + lr) * 72 + 8 * g;
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr);
+                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + 32);
+                    bf16x8 vf;
+                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+                    const f32x4 o = MFMA16(vf, pf, (f32x4{0.f, 0.f, 0.f, 0.f}));
+                    // o[r] = O[q = lr][d = 16df + 4g + r] -> row qrow, 16-B slot 2df + (g>>1), swizzled like q/k
+                    *reinterpret_cast<bf16x4*>(Qs + qrow * 256 + ((((2 * df) + (g >> 1)) ^ lr) << 4) + (g & 1) * 8) =
+                        to_bf16x4(o * inv);
+                }
+            }
+            // next qkv ring (next head, or head 0 of the next block) goes in flight before the proj piece
+            if (head + 1 < SYN_HEADS) kloop_prime<3, 32, KS1, DQ>(rq, wqkv(l, head + 1), KS1, 0);
+            __syncthreads();
+            if (l == 3 && head == 0) stamp(a.dbg, 3);
+            // ---- h += o_head . Wproj[:, 128 head .. +128]^T  (K = 128) ---------------------------------------
+            kloop_run<MF, 4, 1, 0, 4, 256, DP>(h, rp, Qs, wproj, KS1, head * 4);
+            __syncthreads();
+            if (l == 3 && head == 0) stamp(a.dbg, 4);
+        }
+        if (l == 3) stamp(a.dbg, 5);
+        // ---- x2 = LN2(h) -> XN;  h += b_fc2 ------------------------------------------------------------------
+        uint4 r1[D1][2];
+        auto wfc1 = [&](int c) { return (const uint4*)L.w_fc1 + ((size_t)(c * 16 + wave * 2) * KS1) * 64 + lane; };
+        kloop_prime<2, 1, KS1, D1>(r1, wfc1(0), KS1, 0);          // in flight during LayerNorm 2
+        ln_to_lds<MT>(h, L.ln2_g, L.ln2_b, L.b_fc2, XN, red);
+        __syncthreads();
+        if (l == 3) stamp(a.dbg, 6);
+        for (int c = 0; c < SYN_FF / HC; ++c) {
+            f32x4 a1[2][MF];
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) a1[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            kloop_run<MF, 2, 1, 0, KS1, 1024, D1>(a1, r1, XN, wfc1(c), KS1, 0);
+            uint4 r2[D2][4];
+            kloop_prime<4, 1, HC / 32, D2>(r2, wfc2, KS2, c * 8);   // in flight during the GELU
+            char* const hb = RB + (c & 1) * (MT * 512);
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(L.b_fc1 + c * HC + wave * 32 + nf * 16 + g * 4);
+                const int slot = 4 * wave + 2 * nf + (g >> 1);
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) {
+                    f32x4 v = a1[nf][mf] + b;
+                    v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+                    *reinterpret_cast<bf16x4*>(hb + (mf * 16 + lr) * 512 + ((slot ^ lr) << 4) + (g & 1) * 8) = to_bf16x4(v);
+                }
+            }
+            if (c + 1 < SYN_FF / HC) kloop_prime<2, 1, KS1, D1>(r1, wfc1(c + 1), KS1, 0);
+            __syncthreads();
+            kloop_run<MF, 4, 1, 0, HC / 32, 512, D2>(h, r2, hb, wfc2, KS2, c * 8);
+        }
+        __syncthreads();        // region B (hidden slices) becomes q/k/v + LayerNorm scratch of the next block
+        if (l == 3) stamp(a.dbg, 7);
+    }
+    // ---- out: y = bf16(h) (there is no final LayerNorm, models/denoiser.py:188-195), optionally fp32 h ------
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int m = m0 + mf * 16 + lr;
+        if (m < a.M)
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const size_t off = (size_t)m * kNT + wave * 64 + nf * 16 + g * 4;
+                if (a.write_h) *reinterpret_cast<f32x4*>(a.H + off) = h[nf][mf];
+                *reinterpret_cast<bf16x4*>(a.Y + off) = to_bf16x4(h[nf][mf]);
+            }
+    }
+    stamp(a.dbg, 8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -576,6 +1176,8 @@ __global__ void k_randn(float* __restrict__ out, long n4, uint64_t seed, uint64_
 
 // ------------------------------------------------------------------------------------------------
 thread_local char g_err[256] = "";
+long long* g_dbg_attn = nullptr;   // diagnostics only (syn_debug_timing)
+long long* g_dbg_mlp = nullptr;
 
 int fail(const char* what, hipError_t e) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
@@ -588,7 +1190,7 @@ int fail_msg(const char* what) {
 
 template <int EPI>
 int launch_gemm(const GArgs& a, int mt, int chunks, hipStream_t s) {
-    if (a.K % kKT != 0 || a.M <= 0) return fail_msg("gemm: K must be a multiple of 64 and M > 0");
+    if (a.K % 128 != 0 || a.M <= 0) return fail_msg("gemm: K must be a multiple of 128 and M > 0");
     dim3 grid((a.M + mt - 1) / mt, chunks), block(kThreads);
     switch (mt) {
         case 128: hipLaunchKernelGGL((k_gemm<128, EPI>), grid, block, 2 * 128 * 128, s, a); break;
@@ -600,9 +1202,66 @@ int launch_gemm(const GArgs& a, int mt, int chunks, hipStream_t s) {
     return e == hipSuccess ? 0 : fail("k_gemm launch", e);
 }
 
+template <typename K>
+void allow_lds(K kernel, int bytes) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+int launch_attn_block(const AArgs& a, int mt, hipStream_t s) {
+    static bool once = false;
+    if (!once) {
+        allow_lds(k_attn_block<128>, 2 * 128 * 128 + 2 * 128 * 256 + 4 * 128 * 72);
+        allow_lds(k_attn_block<64>, 2 * 64 * 128 + 2 * 64 * 256 + 2 * 128 * 72);
+        once = true;
+    }
+    dim3 grid((a.M + mt - 1) / mt), block(kThreads);
+    switch (mt) {
+        case 128: hipLaunchKernelGGL(k_attn_block<128>, grid, block, 2 * 128 * 128 + 2 * 128 * 256 + 4 * 128 * 72, s, a); break;
+        case 64:  hipLaunchKernelGGL(k_attn_block<64>, grid, block, 2 * 64 * 128 + 2 * 64 * 256 + 2 * 128 * 72, s, a); break;
+        case 32:  hipLaunchKernelGGL(k_attn_block<32>, grid, block, 2 * 32 * 128 + 2 * 32 * 256 + 1 * 128 * 72, s, a); break;
+        default:  return fail_msg("attn_block: m_tile must be 32, 64 or 128");
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_attn_block launch", e);
+}
+
+int launch_mlp_block(const BArgs& a, int mt, hipStream_t s) {
+    static bool once = false;
+    if (!once) {
+        allow_lds(k_mlp_block<64>, 64 * 2304);
+        allow_lds(k_mlp_block<32>, 32 * 2304);
+        once = true;
+    }
+    dim3 grid((a.M + mt - 1) / mt), block(kThreads);
+    switch (mt) {
+        case 64: hipLaunchKernelGGL(k_mlp_block<64>, grid, block, 64 * 2304, s, a); break;
+        case 32: hipLaunchKernelGGL(k_mlp_block<32>, grid, block, 32 * 2304, s, a); break;
+        default: return fail_msg("mlp_block: m_tile must be 32 or 64");
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_mlp_block launch", e);
+}
+
+int launch_stack(const SArgs& a, int mt, hipStream_t s) {
+    static bool once = false;
+    if (!once) {
+        allow_lds(k_stack<64>, 64 * 2048 + 4096);
+        allow_lds(k_stack<32>, 32 * 2048 + 4096);
+        once = true;
+    }
+    dim3 grid((a.M + mt - 1) / mt), block(kThreads);
+    switch (mt) {
+        case 64: hipLaunchKernelGGL(k_stack<64>, grid, block, 64 * 2048 + 4096, s, a); break;
+        case 32: hipLaunchKernelGGL(k_stack<32>, grid, block, 32 * 2048 + 4096, s, a); break;
+        default: return fail_msg("stack: m_tile must be 32 or 64");
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_stack launch", e);
+}
+
 int pick_tile(int rows) {
-    // enough workgroups to cover the 256 CUs first, then the largest tile (weight reuse per L2 byte)
-    if (rows / 128 >= 192) return 128;
+    // enough workgroups to cover the 256 CUs first, then the larger tile (weight reuse per L2 byte).
+    // 128-row tiles exist for the A/B paths only: with the 4-slot weight ring they exceed 256 VGPRs.
     if (rows / 64 >= 192) return 64;
     return 32;
 }
@@ -612,6 +1271,10 @@ int pick_tile(int rows) {
 extern "C" {
 
 int syn_version(void) { return SYN_ABI_VERSION; }
+
+/* diagnostics (not part of the public header): per-workgroup cycle stamps of layer 3's fused kernels,
+ * 32 slots per workgroup; pass NULL to switch off. */
+void syn_debug_timing(long long* attn_buf, long long* mlp_buf) { g_dbg_attn = attn_buf; g_dbg_mlp = mlp_buf; }
 const char* syn_last_error(void) { return g_err; }
 
 int syn_pack_weight(const float* w, int32_t n, int32_t k, void* out_packed, void* stream) {
@@ -710,10 +1373,43 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     memset(&a, 0, sizeof(a));
     a.X = (const __bf16*)st->x_t_bf16; a.ldx = SYN_C; a.x_rows = Mb; a.W = (const uint4*)md->w_in; a.K = SYN_C; a.M = R;
     a.cond = st->cond; a.te = md->te; a.t_model = st->t_model; a.rcos = md->rot_cos; a.rsin = md->rot_sin;
-    a.H = st->ws_h; a.Y = (__bf16*)st->ws_xn; a.ldy = SYN_D; a.ln_g = md->layer[0].ln1_g; a.ln_b = md->layer[0].ln1_b;
+    a.H = st->ws_h; a.ldy = SYN_D;
+    if ((st->reserved & 3) != 0) { a.Y = (__bf16*)st->ws_xn; a.ln_g = md->layer[0].ln1_g; a.ln_b = md->layer[0].ln1_b; }
     if ((rc = launch_gemm<EPI_IN>(a, mt, 1, s))) return rc;
     mark(ST_IN);
 
+    // layer implementation: 0 = whole stack in one kernel (production), 2 = two fused kernels per block,
+    // 1 = five kernels per block.  1 and 2 are kept for A/B measurements and bitwise cross-checks.
+    const int mode = st->reserved & 3;
+    const bool fused = mode == 2;
+    if (mode == 0) {
+        SArgs sa;
+        sa.H = st->ws_h; sa.Y = (__bf16*)st->ws_xn; sa.M = R; sa.write_h = V > 1; sa.dbg = g_dbg_mlp;
+        for (int l = 0; l < SYN_LAYERS; ++l) sa.layer[l] = md->layer[l];
+        if ((rc = launch_stack(sa, mt > 64 ? 64 : mt, s))) return rc;
+        mark(ST_FC2);
+    } else
+    if (fused) {
+        const int mtb = mt > 64 ? 64 : mt;
+        for (int l = 0; l < SYN_LAYERS; ++l) {
+            const syn_layer& L = md->layer[l];
+            AArgs aa;
+            aa.dbg = l == 3 ? g_dbg_attn : nullptr;
+            aa.X = (const __bf16*)st->ws_xn; aa.W = (const uint4*)L.w_qkv; aa.O = (__bf16*)st->ws_o; aa.M = R;
+            if ((rc = launch_attn_block(aa, mt, s))) return rc;
+            mark(ST_QKV);
+            BArgs bb;
+            bb.dbg = l == 3 ? g_dbg_mlp : nullptr;
+            bb.O = (const __bf16*)st->ws_o; bb.Wp = (const uint4*)L.w_proj; bb.bp = L.b_proj; bb.H = st->ws_h;
+            bb.ln2_g = L.ln2_g; bb.ln2_b = L.ln2_b; bb.W1 = (const uint4*)L.w_fc1; bb.b1 = L.b_fc1;
+            bb.W2 = (const uint4*)L.w_fc2; bb.b2 = L.b_fc2;
+            bb.lnn_g = l + 1 < SYN_LAYERS ? md->layer[l + 1].ln1_g : nullptr;
+            bb.lnn_b = l + 1 < SYN_LAYERS ? md->layer[l + 1].ln1_b : nullptr;
+            bb.Y = (__bf16*)st->ws_xn; bb.M = R;
+            if ((rc = launch_mlp_block(bb, mtb, s))) return rc;
+            mark(ST_FC2);
+        }
+    } else
     for (int l = 0; l < SYN_LAYERS; ++l) {
         const syn_layer& L = md->layer[l];
         // qkv

@@ -152,6 +152,7 @@ class MDM(nn.Module):
         self._packed, self._packed_key = None, None
         self._bufs, self._cond_entry = {}, None
         self.m_tile = 0
+        self.layer_mode = 0            # 0 whole-stack kernel (production); 2 / 1: two / five kernels per block (A/B)
 
     # ---- engine plumbing ----------------------------------------------------------------------
     @property
@@ -171,11 +172,11 @@ class MDM(nn.Module):
         return self._packed
 
     def buffers(self, B, V=1, want_x0=False) -> engine.StepBuffers:
-        k = (B, V, want_x0, self.m_tile)
+        k = (B, V, want_x0, self.m_tile, self.layer_mode)
         if k not in self._bufs:
             if len(self._bufs) > 4:
                 self._bufs.clear()
-            self._bufs[k] = engine.StepBuffers(B, V, next(self.parameters()).device, want_x0, self.m_tile)
+            self._bufs[k] = engine.StepBuffers(B, V, next(self.parameters()).device, want_x0, self.m_tile, self.layer_mode)
         return self._bufs[k]
 
     def variant_conds(self, y: dict, variants) -> torch.Tensor:

@@ -5,7 +5,8 @@ Layout in HBM (one GPU, everything resident for the whole loop):
     x                token-major fp32 [B*32][1536] + bf16 shadow copy (GEMM operand), updated in place
     cond             fp32 [V*B*32][512], computed once per clip (conditioning.py)
     workspace        h fp32 [R][512]; xn/q/k/o bf16 [R][512]; vt bf16 [R*512]; hid bf16 [R][1024]   (R = V*B*32)
-One step = one ``syn_denoise_step`` call = 42 kernel launches, hipGraph-captured and replayed; the
+One step = one ``syn_denoise_step`` call = 3 kernel launches (input GEMM, the 8-block stack, output GEMM +
+posterior), hipGraph-captured and replayed; the
 timestep enters through two device int32 vectors so the same graph serves every step.
 """
 from __future__ import annotations
@@ -79,7 +80,7 @@ class PackedModel:
 class StepBuffers:
     """State + workspace for B clips x V conditioning variants; owns the syn_step struct."""
 
-    def __init__(self, B: int, V: int, device, want_x0: bool = False, m_tile: int = 0):
+    def __init__(self, B: int, V: int, device, want_x0: bool = False, m_tile: int = 0, layer_mode: int = 0):
         self.B, self.V = B, V
         R, Mb = V * B * T, B * T
         e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=device)
@@ -97,6 +98,7 @@ class StepBuffers:
         self.hc = e(3, Mb, D, dt=bf) if V > 1 else None
         s = _lib.SynStep()
         s.n_clips, s.n_variants, s.m_tile = B, V, m_tile
+        s.reserved = layer_mode                # 0 whole-stack kernel; 2 / 1 = two / five kernels per block (A/B, bisecting)
         s.cond, s.t_model, s.cfg_w = self.cond.data_ptr(), self.t_model.data_ptr(), _lib.ptr(self.cfg_w)
         s.x_t, s.x_t_bf16, s.noise = self.x.data_ptr(), self.xb.data_ptr(), self.noise.data_ptr()
         s.t_coef = self.t_coef.data_ptr()

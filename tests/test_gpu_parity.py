@@ -47,11 +47,11 @@ def test_forward_vs_golden(beatx, golden):
 
 
 def test_forward_residual_stream_vs_golden(beatx, golden):
-    """After a forward the workspace holds the last residual stream h8 (fp32)."""
+    """After a forward the workspace holds bf16(h8), the last residual stream (operand of the output GEMM)."""
     y, x = synth.to_device(synth.synth_clip_inputs(2, seed=1), DEV), synth.synth_latent(2, seed=1).to(DEV)
     with torch.no_grad():
         beatx(x, torch.tensor([500, 999], device=DEV), y)
-    h8 = beatx.buffers(2, 1).h.view(2, 32, 512).cpu()
+    h8 = beatx.buffers(2, 1).xn.float().view(2, 32, 512).cpu()
     assert rel_l2(h8, golden["beatx.tap.h8"]) < FWD_TOL
 
 
@@ -95,6 +95,27 @@ def test_batch_rows_are_independent(beatx):
     assert torch.equal(run(1, x[1:2], cond[1:2], t[1:2]), full[1:2])
     for mt in (32, 64, 128):
         assert torch.equal(run(3, x, cond, t, mt), full)
+
+
+def test_fused_layer_kernels_equal_unfused_bitwise(beatx):
+    """The whole-stack kernel (mode 0), the two-kernels-per-block path (mode 2) and the five-kernel path
+    (mode 1) round at exactly the same points (LayerNorm outputs, q/k/v, P, o, hidden in bf16; fp32
+    accumulation in the same k order) -> identical bits, for every tile size."""
+    y, x = synth.to_device(synth.synth_clip_inputs(5, seed=41), DEV), synth.synth_latent(5, seed=41).to(DEV)
+    t = torch.tensor([3, 100, 450, 800, 999], device=DEV)
+    outs = {}
+    with torch.no_grad():
+        for mode in (0, 1, 2):
+            for mt in (32, 64, 128):
+                beatx.layer_mode, beatx.m_tile = mode, mt
+                try:
+                    outs[(mode, mt)] = beatx(x, t, y).cpu()
+                finally:
+                    beatx.layer_mode, beatx.m_tile = 0, 0
+    ref = outs[(1, 32)]
+    assert torch.isfinite(ref).all()
+    for k, v in outs.items():
+        assert torch.equal(v, ref), k
 
 
 def test_ddpm10_and_ddim50_vs_golden(beatx, golden):
