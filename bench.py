@@ -129,13 +129,13 @@ def main():
     x_T = torch.randn(B, 1536, 1, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(rank))
     sb.load_x(x_T)
     coef = engine.posterior_coefs(diff.tables(), dev)
-    graph = engine.StepGraph(pm, sb, coef, True)
+    sb.set_rng(1234, first_clip=rank * B)
+    graph = engine.StepGraph(pm, sb, coef, True, fused_rng=True)
 
     def step(i):                       # exactly the body of the fused p_sample_loop
         sb.t_coef.fill_(i)
         sb.t_model.fill_(i)
-        sb.draw_noise(1234, i, first_clip=rank * B)
-        graph.replay()
+        graph.replay()                 # noise ~ Philox(seed, step = t, global element index), drawn in the epilogue
 
     def barrier():
         torch.cuda.synchronize()
@@ -167,7 +167,7 @@ def main():
         reps = 5
         for r in range(reps):
             sb.t_coef.fill_(500); sb.t_model.fill_(500)
-            sb.c.coef = coef.data_ptr(); sb.c.noise = sb.noise.data_ptr()
+            sb.c.coef = coef.data_ptr(); sb.c.noise = None; sb.c.rng = sb.rng.data_ptr()
             _lib.check(_lib.load().syn_denoise_step_profile(C.byref(pm.c), C.byref(sb.c), _lib.current_stream(), ms, cnt),
                        "syn_denoise_step_profile")
             for c in range(8):

@@ -78,7 +78,10 @@ typedef struct syn_step {
     /* state, token-major */
     const float*   x_t;       /* [B*32][1536] fp32                                               */
     const void*    x_t_bf16;  /* [B*32][1536] bf16 copy of x_t (GEMM operand)                    */
-    const float*   noise;     /* [B*32][1536] fp32 N(0,1), or NULL for no noise term             */
+    const float*   noise;     /* [B*32][1536] fp32 N(0,1) to inject, or NULL                     */
+    const uint64_t* rng;      /* used when noise == NULL: device {seed, first_clip} -> the output GEMM's epilogue
+                                 draws N(0,1) itself, identical to syn_randn(seed, stream_id = t_coef[clip],
+                                 first_index = first_clip*32*1536); NULL = no noise term            */
     const float*   coef;      /* [n][4] rows (c_x0, c_xt, sigma, unused)                         */
     const int32_t* t_coef;    /* [B] row of coef used by each clip                               */
     float*         x_next;      /* [B*32][1536] = c_x0*x0_hat + c_xt*x_t + sigma*noise; may alias x_t */

@@ -32,7 +32,7 @@ class SynModel(C.Structure):
 class SynStep(C.Structure):
     _fields_ = [("n_clips", i32), ("n_variants", i32), ("m_tile", i32), ("reserved", i32),
                 ("cond", vp), ("t_model", vp), ("cfg_w", vp),
-                ("x_t", vp), ("x_t_bf16", vp), ("noise", vp), ("coef", vp), ("t_coef", vp),
+                ("x_t", vp), ("x_t_bf16", vp), ("noise", vp), ("rng", vp), ("coef", vp), ("t_coef", vp),
                 ("x_next", vp), ("x_next_bf16", vp), ("pred_x0", vp),
                 ("ws_h", vp), ("ws_xn", vp), ("ws_q", vp), ("ws_k", vp), ("ws_vt", vp), ("ws_o", vp),
                 ("ws_hid", vp), ("ws_hc", vp)]

@@ -59,6 +59,7 @@ struct GArgs {
     // posterior epilogue
     const float* Xt; const float* noise; const float* coef; const int* t_coef;
     float* Xn; __bf16* Xnb; float* X0;
+    const unsigned long long* rng;   // {seed, first_clip}: draw the noise in the epilogue, stream id = the clip's t_coef
     // plain fp32 output (unit tests)
     float* Yf; int ldyf;
     int ablate;   // diagnostics (syn_test_gemm only): 1 = weights loaded once, 2 = activations staged once, 4 = no store
@@ -200,56 +201,41 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[NF][MT / 16], const _
     }
 }
 
-// Row mean / rstd over the 512 columns a workgroup owns (8 waves x 64), two-pass for accuracy.
-// v[nf][mf][r] in the SWAP=false layout.  red: MT*8 floats, stat: 2*MT floats (LDS).
+// Row mean / rstd over the 512 columns a workgroup owns (8 waves x 64).  One pass (sum and sum of squares,
+// fp32), ONE workgroup barrier: every lane then adds the 8 per-wave partials of its own rows (broadcast LDS
+// reads).  The cancellation in E[x^2] - mean^2 costs ~6e-8 * (1 + mean^2/var) relative, far below the bf16
+// rounding of the normalised output.  v[nf][mf][r] in the non-swapped layout.  red: MT*16 floats of LDS;
+// `stat` is unused (kept for the call signature).
 template <int MT>
-__device__ __forceinline__ void row_stats(const f32x4 (&v)[4][MT / 16], float* red, float* stat,
+__device__ __forceinline__ void row_stats(const f32x4 (&v)[4][MT / 16], float* red, float* /*stat*/,
                                           float (&mean)[MT / 16], float (&rstd)[MT / 16]) {
     constexpr int MF = MT / 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lr = lane & 15;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, lr = lane & 15;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
-        float s = 0.f;
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) s += (v[nf][mf][0] + v[nf][mf][1]) + (v[nf][mf][2] + v[nf][mf][3]);
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (g == 0) red[(mf * 16 + lr) * 8 + wave] = s;
-    }
-    __syncthreads();
-    if (tid < MT) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) s += red[tid * 8 + w];
-        stat[tid] = s * (1.0f / 512.0f);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) mean[mf] = stat[mf * 16 + lr];
-#pragma unroll
-    for (int mf = 0; mf < MF; ++mf) {
-        float s = 0.f;
+        float s = 0.f, q = 0.f;
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float d = v[nf][mf][r] - mean[mf];
-                s += d * d;
+                s += v[nf][mf][r];
+                q = fmaf(v[nf][mf][r], v[nf][mf][r], q);
             }
-        s += __shfl_xor(s, 16);
-        s += __shfl_xor(s, 32);
-        if (g == 0) red[(mf * 16 + lr) * 8 + wave] = s;
-    }
-    __syncthreads();
-    if (tid < MT) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) s += red[tid * 8 + w];
-        stat[MT + tid] = rsqrtf(s * (1.0f / 512.0f) + 1e-5f);   // nn.LayerNorm: biased variance, eps 1e-5
+        s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+        s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+        if (g == 0) *reinterpret_cast<float2*>(red + (mf * 16 + lr) * 16 + wave * 2) = make_float2(s, q);
     }
     __syncthreads();
 #pragma unroll
-    for (int mf = 0; mf < MF; ++mf) rstd[mf] = stat[MT + mf * 16 + lr];
+    for (int mf = 0; mf < MF; ++mf) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(red + (mf * 16 + lr) * 16);
+        const f32x4 a = p[0], b = p[1], c = p[2], d = p[3];           // (s0,q0,s1,q1) ...
+        const float S = ((a[0] + a[2]) + (b[0] + b[2])) + ((c[0] + c[2]) + (d[0] + d[2]));
+        const float Q = ((a[1] + a[3]) + (b[1] + b[3])) + ((c[1] + c[3]) + (d[1] + d[3]));
+        mean[mf] = S * (1.0f / 512.0f);
+        const float var = fmaxf(Q * (1.0f / 512.0f) - mean[mf] * mean[mf], 0.f);
+        rstd[mf] = rsqrtf(var + 1e-5f);                                // nn.LayerNorm: biased variance, eps 1e-5
+    }
 }
 
 // h (fp32) is final in v; write H, then Y = LN(v)*g + b (or plain bf16(v) when ln_g == nullptr).
@@ -287,6 +273,35 @@ __device__ __forceinline__ void store_h_and_norm(const GArgs& a, f32x4 (&v)[4][M
             if (m < a.M) *reinterpret_cast<bf16x4*>(a.Y + (size_t)m * a.ldy + n) = to_bf16x4(y);
         }
     }
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter = (index/4, stream_id), key = seed; Box-Muller pairs.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+
+// Four N(0,1) values for elements [4*idx4, 4*idx4+3] of the flat noise tensor of step `stream_id`.
+__device__ __forceinline__ f32x4 randn4(uint64_t seed, uint64_t stream_id, uint64_t idx4) {
+    uint32_t c[4] = {(uint32_t)idx4, (uint32_t)(idx4 >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) philox_round(c, k);
+    const float inv32 = 2.3283064365386963e-10f;   // 2^-32
+    f32x4 z;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const float u1 = ((float)c[2 * p] + 0.5f) * inv32;           // (0,1)
+        const float u2 = ((float)c[2 * p + 1] + 0.5f) * inv32;
+        const float rad = sqrtf(-2.0f * __logf(u1));
+        float sn, cs;
+        __sincosf(6.283185307179586f * u2, &sn, &cs);
+        z[2 * p] = rad * cs;
+        z[2 * p + 1] = rad * sn;
+    }
+    return z;
 }
 
 template <int MT, int EPI>
@@ -423,7 +438,8 @@ __global__ __launch_bounds__(kThreads) void k_gemm(const GArgs a) {
         for (int mf = 0; mf < MF; ++mf) {
             const int m = m0 + mf * 16 + lr;
             if (m >= a.M) continue;
-            const f32x4 cf = *reinterpret_cast<const f32x4*>(a.coef + (size_t)a.t_coef[m >> 5] * 4);
+            const int tc = a.t_coef[m >> 5];
+            const f32x4 cf = *reinterpret_cast<const f32x4*>(a.coef + (size_t)tc * 4);
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
                 const int n = ncol + nf * 16 + g * 4;
@@ -432,6 +448,7 @@ __global__ __launch_bounds__(kThreads) void k_gemm(const GArgs a) {
                 const f32x4 xt = *reinterpret_cast<const f32x4*>(a.Xt + off);
                 f32x4 xn = x0 * cf[0] + xt * cf[1];
                 if (a.noise) xn = xn + *reinterpret_cast<const f32x4*>(a.noise + off) * cf[2];
+                else if (a.rng) xn = xn + randn4(a.rng[0], (uint64_t)tc, (a.rng[1] * (uint64_t)(SYN_T * SYN_C) + off) >> 2) * cf[2];
                 *reinterpret_cast<f32x4*>(a.Xn + off) = xn;
                 *reinterpret_cast<bf16x4*>(a.Xnb + off) = to_bf16x4(xn);
                 if (a.X0) *reinterpret_cast<f32x4*>(a.X0 + off) = x0;
@@ -927,9 +944,14 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
 #define SYN_D2 3
 #endif
     constexpr int DQ = SYN_DQ, DP = SYN_DP, D1 = SYN_D1, D2 = SYN_D2;   // weight-ring depths (k-steps in flight)
-    auto wqkv = [&](int l, int head) { return (const uint4*)a.layer[l].w_qkv + ((size_t)(head * 8 + wave) * KS1) * 64 + lane; };
+#ifdef SYN_HOTW   /* diagnostic build only: every weight stream aliases block 0 / head 0 / slice 0 (L2-hot) */
+#define HOT(x) 0
+#else
+#define HOT(x) (x)
+#endif
+    auto wqkv = [&](int l, int head) { return (const uint4*)a.layer[HOT(l)].w_qkv + ((size_t)(HOT(head) * 8 + wave) * KS1) * 64 + lane; };
     for (int l = 0; l < SYN_LAYERS; ++l) {
-        const syn_layer& L = a.layer[l];
+        const syn_layer& L = a.layer[HOT(l)];
         // Rings are declared per block so they are dead (not loop-carried registers) outside their phase.
         uint4 rq[DQ][3];                           // qkv ring: primed one phase ahead of its loop
         kloop_prime<3, 32, KS1, DQ>(rq, wqkv(l, 0), KS1, 0);      // in flight during LayerNorm 1
@@ -948,7 +970,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
                 for (int mf = 0; mf < MF; ++mf) acc[sl][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
             kloop_run<MF, 3, 32, 0x4, KS1, 1024, DQ>(acc, rq, XN, wqkv(l, head), KS1, 0);
             uint4 rp[DP][4];                        // proj ring: in flight during the attention
-            kloop_prime<4, 1, 4, DP>(rp, wproj, KS1, head * 4);
+            kloop_prime<4, 1, 4, DP>(rp, wproj, KS1, HOT(head) * 4);
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
                 const int row = mf * 16 + lr;
@@ -1013,14 +1035,14 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
             __syncthreads();
             if (l == 3 && head == 0) stamp(a.dbg, 3);
             // ---- h += o_head . Wproj[:, 128 head .. +128]^T  (K = 128) ---------------------------------------
-            kloop_run<MF, 4, 1, 0, 4, 256, DP>(h, rp, Qs, wproj, KS1, head * 4);
+            kloop_run<MF, 4, 1, 0, 4, 256, DP>(h, rp, Qs, wproj, KS1, HOT(head) * 4);
             __syncthreads();
             if (l == 3 && head == 0) stamp(a.dbg, 4);
         }
         if (l == 3) stamp(a.dbg, 5);
         // ---- x2 = LN2(h) -> XN;  h += b_fc2 ------------------------------------------------------------------
         uint4 r1[D1][2];
-        auto wfc1 = [&](int c) { return (const uint4*)L.w_fc1 + ((size_t)(c * 16 + wave * 2) * KS1) * 64 + lane; };
+        auto wfc1 = [&](int c) { return (const uint4*)L.w_fc1 + ((size_t)(HOT(c) * 16 + wave * 2) * KS1) * 64 + lane; };
         kloop_prime<2, 1, KS1, D1>(r1, wfc1(0), KS1, 0);          // in flight during LayerNorm 2
         ln_to_lds<MT>(h, L.ln2_g, L.ln2_b, L.b_fc2, XN, red);
         __syncthreads();
@@ -1033,7 +1055,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
                 for (int mf = 0; mf < MF; ++mf) a1[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
             kloop_run<MF, 2, 1, 0, KS1, 1024, D1>(a1, r1, XN, wfc1(c), KS1, 0);
             uint4 r2[D2][4];
-            kloop_prime<4, 1, HC / 32, D2>(r2, wfc2, KS2, c * 8);   // in flight during the GELU
+            kloop_prime<4, 1, HC / 32, D2>(r2, wfc2, KS2, HOT(c) * 8);   // in flight during the GELU
             char* const hb = RB + (c & 1) * (MT * 512);
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) {
@@ -1048,7 +1070,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
             }
             if (c + 1 < SYN_FF / HC) kloop_prime<2, 1, KS1, D1>(r1, wfc1(c + 1), KS1, 0);
             __syncthreads();
-            kloop_run<MF, 4, 1, 0, HC / 32, 512, D2>(h, r2, hb, wfc2, KS2, c * 8);
+            kloop_run<MF, 4, 1, 0, HC / 32, 512, D2>(h, r2, hb, wfc2, KS2, HOT(c) * 8);
         }
         __syncthreads();        // region B (hidden slices) becomes q/k/v + LayerNorm scratch of the next block
         if (l == 3) stamp(a.dbg, 7);
@@ -1143,35 +1165,10 @@ __global__ void k_axpby_rows(const float* __restrict__ x, const float* __restric
     reinterpret_cast<f32x4*>(out)[i] = xv * a + yv * b;
 }
 
-// Philox4x32-10 (Salmon et al. 2011), counter = (index/4, stream_id), key = seed; Box-Muller pairs.
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0], n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
-    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
-    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
-}
-
 __global__ void k_randn(float* __restrict__ out, long n4, uint64_t seed, uint64_t stream_id, long first4) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
-    const uint64_t ctr = (uint64_t)(first4 + i);
-    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)stream_id, (uint32_t)(stream_id >> 32)};
-    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-#pragma unroll
-    for (int r = 0; r < 10; ++r) philox_round(c, k);
-    const float inv32 = 2.3283064365386963e-10f;   // 2^-32
-    f32x4 z;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const float u1 = ((float)c[2 * p] + 0.5f) * inv32;           // (0,1)
-        const float u2 = ((float)c[2 * p + 1] + 0.5f) * inv32;
-        const float rad = sqrtf(-2.0f * __logf(u1));
-        float sn, cs;
-        __sincosf(6.283185307179586f * u2, &sn, &cs);
-        z[2 * p] = rad * cs;
-        z[2 * p + 1] = rad * sn;
-    }
-    reinterpret_cast<f32x4*>(out)[i] = z;
+    reinterpret_cast<f32x4*>(out)[i] = randn4(seed, stream_id, (uint64_t)(first4 + i));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1455,7 +1452,7 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
         a.X = (const __bf16*)st->ws_xn;
     }
     a.ldx = SYN_D; a.x_rows = Mb; a.W = (const uint4*)md->w_out; a.K = SYN_D; a.M = Mb; a.bias = md->b_out;
-    a.Xt = st->x_t; a.noise = st->noise; a.coef = st->coef; a.t_coef = st->t_coef;
+    a.Xt = st->x_t; a.noise = st->noise; a.rng = (const unsigned long long*)st->rng; a.coef = st->coef; a.t_coef = st->t_coef;
     a.Xn = st->x_next; a.Xnb = (__bf16*)st->x_next_bf16; a.X0 = st->pred_x0;
     if ((rc = launch_gemm<EPI_OUT>(a, st->m_tile ? st->m_tile : pick_tile(Mb), 3, s))) return rc;
     mark(ST_OUT);

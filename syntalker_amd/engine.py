@@ -87,6 +87,7 @@ class StepBuffers:
         bf = torch.bfloat16
         self.x, self.xb = e(Mb, CH), e(Mb, CH, dt=bf)
         self.noise = e(Mb, CH)
+        self.rng = torch.zeros(2, dtype=torch.int64, device=device)     # {seed, first_clip} of the in-epilogue generator
         self.x0 = e(Mb, CH) if want_x0 else None
         self.cond = e(R, D)
         self.t_model = torch.zeros(V * B, dtype=torch.int32, device=device)
@@ -102,6 +103,7 @@ class StepBuffers:
         s.cond, s.t_model, s.cfg_w = self.cond.data_ptr(), self.t_model.data_ptr(), _lib.ptr(self.cfg_w)
         s.x_t, s.x_t_bf16, s.noise = self.x.data_ptr(), self.xb.data_ptr(), self.noise.data_ptr()
         s.t_coef = self.t_coef.data_ptr()
+        s.rng = None
         s.x_next, s.x_next_bf16, s.pred_x0 = self.x.data_ptr(), self.xb.data_ptr(), _lib.ptr(self.x0)
         s.ws_h, s.ws_xn, s.ws_q, s.ws_k = self.h.data_ptr(), self.xn.data_ptr(), self.q.data_ptr(), self.k.data_ptr()
         s.ws_vt, s.ws_o, s.ws_hid, s.ws_hc = self.vt.data_ptr(), self.o.data_ptr(), self.hid.data_ptr(), _lib.ptr(self.hc)
@@ -119,6 +121,10 @@ class StepBuffers:
         _lib.check(_lib.load().syn_to_token_major(eps_bct.data_ptr(), self.B, self.noise.data_ptr(), None,
                                                   _lib.current_stream()), "syn_to_token_major")
 
+    def set_rng(self, seed: int, first_clip: int = 0):
+        """Key of the in-epilogue generator for the whole loop; the per-step stream id is the clip's t_coef."""
+        self.rng.copy_(torch.tensor([seed, first_clip], dtype=torch.int64))
+
     def draw_noise(self, seed: int, step: int, first_clip: int = 0):
         """N(0,1) keyed by (seed, step, global element index): identical for any sharding of the batch."""
         n = self.B * T * CH
@@ -132,27 +138,30 @@ class StepBuffers:
         return out
 
 
-def run_step(pm: PackedModel, sb: StepBuffers, coef: torch.Tensor, use_noise: bool = True):
+def run_step(pm: PackedModel, sb: StepBuffers, coef: torch.Tensor, use_noise: bool = True, fused_rng: bool = False):
+    """use_noise + fused_rng: the output GEMM's epilogue draws the noise, keyed by sb.rng = {seed, first_clip} and t_coef;
+    use_noise only: the noise is read from sb.noise (injected or drawn by draw_noise)."""
     sb.c.coef = coef.data_ptr()
-    sb.c.noise = sb.noise.data_ptr() if use_noise else None
+    sb.c.noise = sb.noise.data_ptr() if (use_noise and not fused_rng) else None
+    sb.c.rng = sb.rng.data_ptr() if (use_noise and fused_rng) else None
     _lib.check(_lib.load().syn_denoise_step(C.byref(pm.c), C.byref(sb.c), _lib.current_stream()), "syn_denoise_step")
 
 
 class StepGraph:
     """hipGraph of one step; replays read the timestep from sb.t_model / sb.t_coef (device memory)."""
 
-    def __init__(self, pm: PackedModel, sb: StepBuffers, coef: torch.Tensor, use_noise: bool = True):
+    def __init__(self, pm: PackedModel, sb: StepBuffers, coef: torch.Tensor, use_noise: bool = True, fused_rng: bool = False):
         self.pm, self.sb, self.coef = pm, sb, coef
         side = torch.cuda.Stream(device=pm.device)
         side.wait_stream(torch.cuda.current_stream(pm.device))
         with torch.cuda.stream(side):          # warm-up launch outside capture (module load, etc.)
             x_save, xb_save = sb.x.clone(), sb.xb.clone()
-            run_step(pm, sb, coef, use_noise)
+            run_step(pm, sb, coef, use_noise, fused_rng)
             sb.x.copy_(x_save); sb.xb.copy_(xb_save)
         torch.cuda.current_stream(pm.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            run_step(pm, sb, coef, use_noise)
+            run_step(pm, sb, coef, use_noise, fused_rng)
 
     def replay(self):
         self.graph.replay()

@@ -238,7 +238,7 @@ class GaussianDiffusion:
         return mdm, plan_fn
 
     def _fused(self, kind, mdm, plan_fn, shape, noise, model_kwargs, eta, skip_timesteps, init_image, step_noise,
-               seed, progress, each=None):
+               seed, progress, each=None, first_clip=0):
         """x stays on the device in token-major layout for the whole loop; one graph replay per step."""
         dev = next(mdm.parameters()).device
         y = model_kwargs["y"]
@@ -261,12 +261,15 @@ class GaussianDiffusion:
             _, tmap = self._model_timesteps(dev)
             if seed is None and noisy and step_noise is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # follows torch.manual_seed
-            gkey = ("graph", id(pm), id(sb), coef.data_ptr(), noisy)
+            fused_rng = noisy and step_noise is None     # noise drawn inside the output GEMM's epilogue
+            if fused_rng:
+                sb.set_rng(seed, first_clip)
+            gkey = ("graph", id(pm), id(sb), coef.data_ptr(), noisy, fused_rng)
             graphs = mdm.__dict__.setdefault("_graphs", {})
             if gkey not in graphs:
                 if len(graphs) > 8:
                     graphs.clear()
-                graphs[gkey] = engine.StepGraph(pm, sb, coef, noisy)
+                graphs[gkey] = engine.StepGraph(pm, sb, coef, noisy, fused_rng)
             graph = graphs[gkey]
             if progress:
                 try:
@@ -277,11 +280,8 @@ class GaussianDiffusion:
             for k, i in enumerate(indices):
                 sb.t_coef.fill_(i)
                 sb.t_model.fill_(tmap[i])
-                if noisy:
-                    if step_noise is not None:
-                        sb.load_noise(step_noise[k].to(dev))
-                    else:
-                        sb.draw_noise(seed, i)
+                if noisy and step_noise is not None:
+                    sb.load_noise(step_noise[k].to(dev))
                 graph.replay()
                 if each is not None:
                     each(k, sb)

@@ -248,9 +248,10 @@ def test_full_size_properties(beatx):
     sb.load_x(xT)
     x_before = sb.x.clone()
     sb.t_model.fill_(500); sb.t_coef.fill_(500)
-    sb.draw_noise(9, 500)
+    sb.draw_noise(9, 500)                     # the separate generator kernel ...
+    sb.set_rng(9, 0)                          # ... and the in-epilogue generator must agree bit for bit
     coef = engine.posterior_coefs(d.tables(), DEV)
-    engine.run_step(pm, sb, coef, True)
+    engine.run_step(pm, sb, coef, True, fused_rng=True)
     torch.cuda.synchronize()
     c = coef[500].double()
     want = c[0] * sb.x0.double() + c[1] * x_before.double() + c[2] * sb.noise.double()
