@@ -43,10 +43,9 @@ STAGE_INFO_LEGACY = {
     "out_gemm": ("k_gemm<MT,EPI_OUT>", 2 * 32 * 512 * 1536),
 }
 _BLOCK = 2 * 32 * 512 * 1536 + _ATT + 2 * 32 * 512 * 512 + 2 * 2 * 32 * 512 * 1024
+# production: input GEMM + 8 blocks + output GEMM + posterior update are ONE kernel
 STAGE_INFO_STACK = {
-    "in_gemm": ("k_gemm<MT,EPI_IN>", 2 * 32 * 1536 * 512),
-    "fc2_gemm": ("k_stack<MT>", 8 * _BLOCK),
-    "out_gemm": ("k_gemm<MT,EPI_OUT>", 2 * 32 * 512 * 1536),
+    "fc2_gemm": ("k_stack<MT>", 2 * 32 * 1536 * 512 + 8 * _BLOCK + 2 * 32 * 512 * 1536),
 }
 # fused layer kernels report under the qkv / fc2 stage slots of syn_denoise_step_profile
 STAGE_INFO_FUSED = {
@@ -172,7 +171,7 @@ def main():
                        "syn_denoise_step_profile")
             for c in range(8):
                 tot[c] += ms[c]; launches[c] += cnt[c]
-        rename = {0: {"fc2_gemm": "stack"}, 1: {}, 2: {"qkv_gemm": "attn_block", "fc2_gemm": "mlp_block"}}[args.layer_mode]
+        rename = {0: {"fc2_gemm": "step_kernel"}, 1: {}, 2: {"qkv_gemm": "attn_block", "fc2_gemm": "mlp_block"}}[args.layer_mode]
         stage_ms = {STAGES[c]: tot[c] / reps for c in range(8) if launches[c]}
         # group by kernel symbol (proj and fc2 share one)
         by_kernel = {}

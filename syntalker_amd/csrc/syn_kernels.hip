@@ -836,6 +836,11 @@ struct SArgs {
     int M;
     int write_h;          // also write the final fp32 h (needed only by the guidance combine)
     long long* dbg;
+    // fused input stage (in.X != nullptr): h = rotary(x_t . A^T + cond + te[t]) instead of reading H
+    GArgs in;
+    // fused output stage (out.Xn != nullptr; single conditioning variant only): x0 = h . Wout^T + b and the
+    // posterior / DDIM update, instead of writing Y
+    GArgs out;
 };
 
 // Weight ring of a barrier-free GEMM piece: D k-steps x NF fragments.  kloop_prime issues the first D-1
@@ -922,14 +927,47 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
     stamp(a.dbg, 0);
 
     f32x4 h[4][MF];
-#pragma unroll
-    for (int nf = 0; nf < 4; ++nf)
+    if (a.in.X != nullptr) {
+        // ---- input stage: h = rotary(x_t . A^T + cond + te[t]); K = 1536 streamed through region B ----------
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
             const int m = m0 + mf * 16 + lr;
-            h[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (m < a.M) h[nf][mf] = *reinterpret_cast<const f32x4*>(a.H + (size_t)m * kNT + wave * 64 + nf * 16 + g * 4);
+            const bool ok = m < a.M;
+            const int ts = ok ? a.in.t_model[m >> 5] : 0;
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                const int n = wave * 64 + nf * 16 + g * 4;
+                f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                if (ok) c = *reinterpret_cast<const f32x4*>(a.in.cond + (size_t)m * kNT + n);
+                h[nf][mf] = c + *reinterpret_cast<const f32x4*>(a.in.te + (size_t)ts * kNT + n);
+            }
         }
+        gemm_mainloop<MT, 4, 1, 0>(h, a.in.X, a.in.ldx, a.in.x_rows, m0, a.M, a.in.K,
+                                   a.in.W + ((size_t)(wave * 4) * (a.in.K / 32)) * 64 + lane, RB);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int pos = (m0 + mf * 16 + lr) & 31;
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                const int j = nf * 16 + g * 4;
+                const f32x4 cs = *reinterpret_cast<const f32x4*>(a.in.rcos + pos * 32 + j);
+                const f32x4 sn = *reinterpret_cast<const f32x4*>(a.in.rsin + pos * 32 + j);
+                const f32x4 u = h[nf][mf], w = h[nf + 2][mf];
+                h[nf][mf] = u * cs - w * sn;
+                h[nf + 2][mf] = w * cs + u * sn;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int m = m0 + mf * 16 + lr;
+                h[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m < a.M) h[nf][mf] = *reinterpret_cast<const f32x4*>(a.H + (size_t)m * kNT + wave * 64 + nf * 16 + g * 4);
+            }
+    }
+    if (a.dbg) stamp(a.dbg, 9);
 
 #ifndef SYN_DQ
 #define SYN_DQ 4
@@ -1075,6 +1113,50 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
         __syncthreads();        // region B (hidden slices) becomes q/k/v + LayerNorm scratch of the next block
         if (l == 3) stamp(a.dbg, 7);
     }
+    if (a.out.Xn != nullptr) {
+        // ---- output stage: x0 = h . Wout^T + b (there is no final LayerNorm, models/denoiser.py:188-195), then
+        //      x_next = c0*x0 + c1*x_t + sigma*eps.  bf16(h) goes to XN with the usual swizzle.
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int slot = 8 * wave + 2 * nf + (g >> 1);
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+                *reinterpret_cast<bf16x4*>(XN + (mf * 16 + lr) * 1024 + ((slot ^ lr) << 4) + (g & 1) * 8) = to_bf16x4(h[nf][mf]);
+        }
+        __syncthreads();
+        for (int c = 0; c < SYN_C / kNT; ++c) {
+            f32x4 acc[4][MF];
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const uint4* wo = a.out.W + ((size_t)(c * 32 + wave * 4) * KS1) * 64 + lane;
+            uint4 ro[4][4];
+            kloop_prime<4, 1, KS1, 4>(ro, wo, KS1, 0);
+            kloop_run<MF, 4, 1, 0, KS1, 1024, 4>(acc, ro, XN, wo, KS1, 0);
+            const int ncol = c * kNT + wave * 64;
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) {
+                const int m = m0 + mf * 16 + lr;
+                if (m >= a.M) continue;
+                const int tc = a.out.t_coef[m >> 5];
+                const f32x4 cf = *reinterpret_cast<const f32x4*>(a.out.coef + (size_t)tc * 4);
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) {
+                    const int n = ncol + nf * 16 + g * 4;
+                    const size_t off = (size_t)m * SYN_C + n;
+                    const f32x4 x0 = acc[nf][mf] + *reinterpret_cast<const f32x4*>(a.out.bias + n);
+                    const f32x4 xt = *reinterpret_cast<const f32x4*>(a.out.Xt + off);
+                    f32x4 xn = x0 * cf[0] + xt * cf[1];
+                    if (a.out.noise) xn = xn + *reinterpret_cast<const f32x4*>(a.out.noise + off) * cf[2];
+                    else if (a.out.rng) xn = xn + randn4(a.out.rng[0], (uint64_t)tc, (a.out.rng[1] * (uint64_t)(SYN_T * SYN_C) + off) >> 2) * cf[2];
+                    *reinterpret_cast<f32x4*>(a.out.Xn + off) = xn;
+                    *reinterpret_cast<bf16x4*>(a.out.Xnb + off) = to_bf16x4(xn);
+                    if (a.out.X0) *reinterpret_cast<f32x4*>(a.out.X0 + off) = x0;
+                }
+            }
+        }
+    } else {
     // ---- out: y = bf16(h) (there is no final LayerNorm, models/denoiser.py:188-195), optionally fp32 h ------
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
@@ -1086,6 +1168,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
                 if (a.write_h) *reinterpret_cast<f32x4*>(a.H + off) = h[nf][mf];
                 *reinterpret_cast<bf16x4*>(a.Y + off) = to_bf16x4(h[nf][mf]);
             }
+    }
     }
     stamp(a.dbg, 8);
 }
@@ -1366,23 +1449,36 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     GArgs a;
     auto mark = [&](int c) { if (tm) tm->mark(c); };
 
-    // input stage: h = rotary(x_t A^T + cond + te[t]); xn = LN1_0(h)
-    memset(&a, 0, sizeof(a));
-    a.X = (const __bf16*)st->x_t_bf16; a.ldx = SYN_C; a.x_rows = Mb; a.W = (const uint4*)md->w_in; a.K = SYN_C; a.M = R;
-    a.cond = st->cond; a.te = md->te; a.t_model = st->t_model; a.rcos = md->rot_cos; a.rsin = md->rot_sin;
-    a.H = st->ws_h; a.ldy = SYN_D;
-    if ((st->reserved & 3) != 0) { a.Y = (__bf16*)st->ws_xn; a.ln_g = md->layer[0].ln1_g; a.ln_b = md->layer[0].ln1_b; }
-    if ((rc = launch_gemm<EPI_IN>(a, mt, 1, s))) return rc;
-    mark(ST_IN);
+    const int mode = st->reserved & 3;
+    // input stage: h = rotary(x_t A^T + cond + te[t]) [; xn = LN1_0(h) for the unfused A/B paths]
+    GArgs ain;
+    memset(&ain, 0, sizeof(ain));
+    ain.X = (const __bf16*)st->x_t_bf16; ain.ldx = SYN_C; ain.x_rows = Mb; ain.W = (const uint4*)md->w_in; ain.K = SYN_C; ain.M = R;
+    ain.cond = st->cond; ain.te = md->te; ain.t_model = st->t_model; ain.rcos = md->rot_cos; ain.rsin = md->rot_sin;
+    ain.H = st->ws_h; ain.ldy = SYN_D;
+    if (mode != 0) {
+        ain.Y = (__bf16*)st->ws_xn; ain.ln_g = md->layer[0].ln1_g; ain.ln_b = md->layer[0].ln1_b;
+        if ((rc = launch_gemm<EPI_IN>(ain, mt, 1, s))) return rc;
+        mark(ST_IN);
+    }
+    // output stage arguments (fused into the step kernel when there is a single conditioning variant)
+    GArgs aout;
+    memset(&aout, 0, sizeof(aout));
+    aout.ldx = SYN_D; aout.x_rows = Mb; aout.W = (const uint4*)md->w_out; aout.K = SYN_D; aout.M = Mb; aout.bias = md->b_out;
+    aout.Xt = st->x_t; aout.noise = st->noise; aout.rng = (const unsigned long long*)st->rng; aout.coef = st->coef;
+    aout.t_coef = st->t_coef; aout.Xn = st->x_next; aout.Xnb = (__bf16*)st->x_next_bf16; aout.X0 = st->pred_x0;
+    const bool fuse_out = mode == 0 && V == 1;
 
     // layer implementation: 0 = whole stack in one kernel (production), 2 = two fused kernels per block,
     // 1 = five kernels per block.  1 and 2 are kept for A/B measurements and bitwise cross-checks.
-    const int mode = st->reserved & 3;
     const bool fused = mode == 2;
     if (mode == 0) {
         SArgs sa;
+        memset(&sa, 0, sizeof(sa));
         sa.H = st->ws_h; sa.Y = (__bf16*)st->ws_xn; sa.M = R; sa.write_h = V > 1; sa.dbg = g_dbg_mlp;
         for (int l = 0; l < SYN_LAYERS; ++l) sa.layer[l] = md->layer[l];
+        sa.in = ain;
+        if (fuse_out) sa.out = aout;
         if ((rc = launch_stack(sa, mt > 64 ? 64 : mt, s))) return rc;
         mark(ST_FC2);
     } else
@@ -1441,21 +1537,19 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     }
 
     // output stage (+ guidance combination of the variants, linear so it commutes with the GEMM)
-    memset(&a, 0, sizeof(a));
-    if (V > 1) {
-        const size_t n4 = (size_t)3 * Mb * kNT / 4;
-        hipLaunchKernelGGL(k_combine, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, st->ws_h, st->cfg_w, V, Mb,
-                           (__bf16*)st->ws_hc);
-        mark(ST_COMBINE);
-        a.X = (const __bf16*)st->ws_hc; a.x_chunk_stride = (long)Mb * kNT;
-    } else {
-        a.X = (const __bf16*)st->ws_xn;
+    if (!fuse_out) {
+        if (V > 1) {
+            const size_t n4 = (size_t)3 * Mb * kNT / 4;
+            hipLaunchKernelGGL(k_combine, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, st->ws_h, st->cfg_w, V, Mb,
+                               (__bf16*)st->ws_hc);
+            mark(ST_COMBINE);
+            aout.X = (const __bf16*)st->ws_hc; aout.x_chunk_stride = (long)Mb * kNT;
+        } else {
+            aout.X = (const __bf16*)st->ws_xn;
+        }
+        if ((rc = launch_gemm<EPI_OUT>(aout, st->m_tile ? st->m_tile : pick_tile(Mb), 3, s))) return rc;
+        mark(ST_OUT);
     }
-    a.ldx = SYN_D; a.x_rows = Mb; a.W = (const uint4*)md->w_out; a.K = SYN_D; a.M = Mb; a.bias = md->b_out;
-    a.Xt = st->x_t; a.noise = st->noise; a.rng = (const unsigned long long*)st->rng; a.coef = st->coef; a.t_coef = st->t_coef;
-    a.Xn = st->x_next; a.Xnb = (__bf16*)st->x_next_bf16; a.X0 = st->pred_x0;
-    if ((rc = launch_gemm<EPI_OUT>(a, st->m_tile ? st->m_tile : pick_tile(Mb), 3, s))) return rc;
-    mark(ST_OUT);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("syn_denoise_step", e);
 }

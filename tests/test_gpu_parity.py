@@ -47,11 +47,16 @@ def test_forward_vs_golden(beatx, golden):
 
 
 def test_forward_residual_stream_vs_golden(beatx, golden):
-    """After a forward the workspace holds bf16(h8), the last residual stream (operand of the output GEMM)."""
+    """The un-fused A/B path leaves bf16(h8), the last residual stream, in the workspace (in production the
+    whole step is one kernel and h never leaves the chip): layer-level bisecting tap against the reference."""
     y, x = synth.to_device(synth.synth_clip_inputs(2, seed=1), DEV), synth.synth_latent(2, seed=1).to(DEV)
-    with torch.no_grad():
-        beatx(x, torch.tensor([500, 999], device=DEV), y)
-    h8 = beatx.buffers(2, 1).xn.float().view(2, 32, 512).cpu()
+    beatx.layer_mode = 2
+    try:
+        with torch.no_grad():
+            beatx(x, torch.tensor([500, 999], device=DEV), y)
+        h8 = beatx.buffers(2, 1).xn.float().view(2, 32, 512).cpu()
+    finally:
+        beatx.layer_mode = 0
     assert rel_l2(h8, golden["beatx.tap.h8"]) < FWD_TOL
 
 
