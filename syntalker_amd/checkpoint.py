@@ -1,0 +1,26 @@
+"""Checkpoint I/O in the reference's format (utils/other_tools.py:757-790): a torch file holding
+``{'model_state': state_dict}`` whose keys may carry nn.DataParallel's ``module.`` prefix."""
+from __future__ import annotations
+
+import torch
+
+
+def strip_module_prefix(sd: dict) -> dict:
+    return {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+
+
+def load_checkpoints(model, save_path, load_name="model"):
+    """Same call signature as the reference's loader.  Accepts prefixed and unprefixed keys."""
+    states = torch.load(save_path, map_location="cpu")
+    sd = states["model_state"] if isinstance(states, dict) and "model_state" in states else states
+    target = model.module if hasattr(model, "module") and not any(k.startswith("module.") for k in model.state_dict()) else model
+    missing, unexpected = target.load_state_dict(strip_module_prefix(sd), strict=False)
+    missing = [k for k in missing if not k.endswith("num_batches_tracked")]
+    if missing or unexpected:
+        raise KeyError(f"checkpoint/model key mismatch: missing {missing[:5]}..., unexpected {unexpected[:5]}...")
+    return model
+
+
+def save_checkpoints(save_path, model, opt=None, epoch=None, lrs=None):
+    """Writes only the model state, like the reference (no optimizer / epoch)."""
+    torch.save({"model_state": model.state_dict()}, save_path)

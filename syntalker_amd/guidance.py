@@ -32,17 +32,20 @@ def _scalar(v, what):
 class _Plan:
     """variants: list of (uncond, uncond_audio, style_override|None); weights: (3, V) python lists."""
 
-    def __init__(self):
+    def __init__(self, null_style_on_uncond: bool = True):
+        # MDM replaces the style vector by its null row when `uncond` is set (denoiser_h3d.py:116-124), so a
+        # style override is irrelevant there and such variants merge; for arbitrary wrapped modules they do not.
         self.variants, self._index, self.weights = [], {}, [[], [], []]
+        self.merge = null_style_on_uncond
 
     def add(self, uncond, uncond_audio, style, w3):
         if not any(w3):            # a zero-weight evaluation cannot change the result: skip it
             return
-        # uncond replaces the style vector by the learned null row, so the override is irrelevant then
-        key = (bool(uncond), bool(uncond_audio), None if (style is None or uncond) else id(style))
+        drop = uncond and self.merge
+        key = (bool(uncond), bool(uncond_audio), None if (style is None or drop) else id(style))
         if key not in self._index:
             self._index[key] = len(self.variants)
-            self.variants.append((bool(uncond), bool(uncond_audio), None if uncond else style))
+            self.variants.append((bool(uncond), bool(uncond_audio), None if drop else style))
             for r in self.weights:
                 r.append(0.0)
         v = self._index[key]
@@ -81,8 +84,8 @@ class ClassifierFreeSampleModel(nn.Module):
         self.model = model
         self.eval_metric = eval
 
-    def plan(self, y):
-        p = _Plan()
+    def plan(self, y, mdm=True):
+        p = _Plan(mdm)
         if self.eval_metric:
             p.add(True, True, None, [1.0] * 3)
         else:
@@ -93,7 +96,7 @@ class ClassifierFreeSampleModel(nn.Module):
 
     def forward(self, x, timesteps, y=None):
         y["uncond_audio"] = True
-        return _run(self.model, x, timesteps, y, self.plan(y))
+        return _run(self.model, x, timesteps, y, self.plan(y, isinstance(unwrap(self.model), MDM)))
 
 
 def _two_cfg_into(p: _Plan, y, style, sa, sp, blocks):
@@ -112,14 +115,14 @@ class TwoClassifierFreeSampleModel(nn.Module):
         self.model = model
         self.eval_metric = eval
 
-    def plan(self, y):
-        p = _Plan()
+    def plan(self, y, mdm=True):
+        p = _Plan(mdm)
         _two_cfg_into(p, y, None, _scalar(y["scale_audio"], "scale_audio"), _scalar(y["scale_prompt"], "scale_prompt"),
                       (0, 1, 2))
         return p
 
     def forward(self, x, timesteps, y=None):
-        return _run(self.model, x, timesteps, y, self.plan(y))
+        return _run(self.model, x, timesteps, y, self.plan(y, isinstance(unwrap(self.model), MDM)))
 
 
 class TwoClassifierFreeSampleModel_Bodypart(nn.Module):
@@ -134,8 +137,8 @@ class TwoClassifierFreeSampleModel_Bodypart(nn.Module):
         self.audio_scale = 1
         self.prompt_scale = 4
 
-    def plan(self, y):
-        p = _Plan()
+    def plan(self, y, mdm=True):
+        p = _Plan(mdm)
         if self.eval_metric:       # y_uncond: uncond=True, style <- lower prompt (irrelevant once uncond), scales (audio, 0)
             _two_cfg_into(p, dict(y, uncond=True), None, float(self.audio_scale), 0.0, (0, 1, 2))
             return p
@@ -152,7 +155,7 @@ class TwoClassifierFreeSampleModel_Bodypart(nn.Module):
         return p
 
     def forward(self, x, timesteps, y=None):
-        return _run(self.model.model, x, timesteps, y, self.plan(y))
+        return _run(self.model.model, x, timesteps, y, self.plan(y, isinstance(unwrap(self.model.model), MDM)))
 
 
 class ClassifierFreeSampleModel_Bodypart(nn.Module):
@@ -165,8 +168,8 @@ class ClassifierFreeSampleModel_Bodypart(nn.Module):
         self.latent_dim = 1536
         self.eval_metric = eval
 
-    def plan(self, y):
-        p = _Plan()
+    def plan(self, y, mdm=True):
+        p = _Plan(mdm)
         ua0 = bool(y.get("uncond_audio", False))
         if self.eval_metric:
             p.add(True, ua0, None, [1.0] * 3)
@@ -184,7 +187,7 @@ class ClassifierFreeSampleModel_Bodypart(nn.Module):
         return p
 
     def forward(self, x, timesteps, y=None):
-        return _run(self.model, x, timesteps, y, self.plan(y))
+        return _run(self.model, x, timesteps, y, self.plan(y, isinstance(unwrap(self.model), MDM)))
 
 
 def resolve(model):

@@ -313,8 +313,10 @@ class GaussianDiffusion:
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                       model_kwargs=None, device=None, progress=False, skip_timesteps=0, init_image=None,
                       randomize_class=False, cond_fn_with_grad=False, dump_steps=None, const_noise=False, *,
-                      step_noise=None, seed=None):
-        """gaussian_diffusion.py:607-670.  Returns the final sample, or the list of dumped samples."""
+                      step_noise=None, seed=None, first_clip=0):
+        """gaussian_diffusion.py:607-670.  Returns the final sample, or the list of dumped samples.
+        ``first_clip``: global index of this batch's first clip when a larger batch is sharded over ranks
+        (keys the counter-based noise so results do not depend on the sharding)."""
         mdm, plan_fn = self._fusable(model, model_kwargs, denoised_fn, cond_fn, clip_denoised, const_noise,
                                      randomize_class, cond_fn_with_grad, shape)
         if mdm is not None:
@@ -323,7 +325,7 @@ class GaussianDiffusion:
             if dump_steps is not None:
                 each = lambda k, sb: dump.append(sb.read(sb.x)) if k in dump_steps else None
             final = self._fused("ddpm", mdm, plan_fn, shape, noise, model_kwargs, 0.0, skip_timesteps, init_image,
-                                step_noise, seed, progress, each)
+                                step_noise, seed, progress, each, first_clip)
             return dump if dump_steps is not None else final
         final, dump = None, []
         for i, out in enumerate(self.p_sample_loop_progressive(
@@ -346,7 +348,7 @@ class GaussianDiffusion:
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                          model_kwargs=None, device=None, progress=False, eta=0.0, skip_timesteps=0, init_image=None,
                          randomize_class=False, cond_fn_with_grad=False, dump_steps=None, const_noise=False, *,
-                         step_noise=None, seed=None):
+                         step_noise=None, seed=None, first_clip=0):
         """gaussian_diffusion.py:888-935."""
         if dump_steps is not None or const_noise:
             raise NotImplementedError()          # same as the reference (:912-915)
@@ -354,7 +356,7 @@ class GaussianDiffusion:
                                      randomize_class, cond_fn_with_grad, shape)
         if mdm is not None:
             return self._fused("ddim", mdm, plan_fn, shape, noise, model_kwargs, eta, skip_timesteps, init_image,
-                               step_noise, seed, progress)
+                               step_noise, seed, progress, None, first_clip)
         final = None
         for out in self.ddim_sample_loop_progressive(model, shape, noise, clip_denoised, denoised_fn, cond_fn,
                                                      model_kwargs, device, progress, eta, skip_timesteps, init_image,

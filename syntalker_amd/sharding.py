@@ -1,0 +1,68 @@
+"""Clip-sharded sampling across the GPUs of one node.
+
+Inference shards with NO data-path collective: clips are independent, every rank holds the full
+(38 MB) weight set and runs its own hipGraph loop over a contiguous slice of the clip batch; the only
+communication is the optional gather of the finished latents.  Noise is keyed by (seed, step, GLOBAL
+clip index) (syn_randn / the in-epilogue Philox), so the result does not depend on the number of ranks.
+One process per GPU, ``torch.distributed`` (backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).
+
+Windows of ONE long sequence are sequential (each window's seed is the tail of the previous one,
+diffusion_rvqvae_trainer.py:428-431): shard across sequences, never across windows.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_clips: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous, balanced slice [lo, hi) of the clip batch owned by `rank` (first ranks get the remainder)."""
+    per, extra = divmod(n_clips, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
+
+
+def shard_kwargs(y: dict, lo: int, hi: int, n_clips: int) -> dict:
+    """Slice every per-clip tensor of model_kwargs['y'] (leading dim == n_clips); leave the rest alone."""
+    out = {}
+    for k, v in y.items():
+        if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n_clips:
+            out[k] = v[lo:hi]
+        elif isinstance(v, dict):
+            out[k] = shard_kwargs(v, lo, hi, n_clips)
+        else:
+            out[k] = v
+    return out
+
+
+def gather_clips(local: torch.Tensor, n_clips: int, group=None) -> torch.Tensor:
+    """all_gather of ragged per-rank slices -> the full (n_clips, ...) tensor on every rank."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    sizes = [shard_range(n_clips, r, world) for r in range(world)]
+    longest = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+
+
+def sample_sharded(diffusion, model, shape, model_kwargs, *, ddim=False, noise=None, seed=0, gather=True, **loop_kw):
+    """p_sample_loop / ddim_sample_loop over this rank's slice of a global batch of shape[0] clips.
+
+    `noise` (x_T) and per-clip entries of model_kwargs['y'] are GLOBAL tensors; each rank slices its part.
+    Returns the full batch on every rank when `gather`, else the local slice."""
+    n = shape[0]
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    lo, hi = shard_range(n, rank, world)
+    kw = dict(model_kwargs)
+    kw["y"] = shard_kwargs(model_kwargs["y"], lo, hi, n)
+    loop = diffusion.ddim_sample_loop if ddim else diffusion.p_sample_loop
+    if "step_noise" in loop_kw and loop_kw["step_noise"] is not None:
+        loop_kw = dict(loop_kw, step_noise=loop_kw["step_noise"][:, lo:hi])
+    local = loop(model, (hi - lo,) + tuple(shape[1:]), noise=None if noise is None else noise[lo:hi],
+                 model_kwargs=kw, seed=seed, first_clip=lo, **loop_kw)
+    return gather_clips(local, n) if gather else local

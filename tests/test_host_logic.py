@@ -1,0 +1,216 @@
+"""CPU tests of the host-side logic (no GPU, no HIP compute): diffusion process arithmetic, step
+coefficient tables, guidance plans, weight folding + per-clip conditioning, state_dict surface,
+checkpoint format, schedule sampler, and the C-ABI export list."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser_ref as dr
+from oracle import guidance_ref as gr
+from oracle.process_ref import RefProcess
+from syntalker_amd import checkpoint, conditioning, engine, guidance, process, resample, synth
+from tests.conftest import REPO, rel_l2
+from tests.refmodel import state_spec, synth_state_dict
+
+
+class ToyModel(torch.nn.Module):
+    """A stand-in denoiser with the MDM calling convention whose output depends on every flag."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor(0.7))
+
+    def forward(self, x, t, y=None):
+        s = y["style_feature"].mean() if torch.is_tensor(y.get("style_feature")) else 0.0
+        out = self.w * x + 0.01 * t.view(-1, 1, 1, 1).float() + s
+        if y.get("uncond", False):
+            out = out - 0.3 * x
+        if y.get("uncond_audio", False):
+            out = out + 0.2 * x.flip(1)
+        return out
+
+
+def test_tables_and_factory_match_reference(golden_tables):
+    for tag, ddim in (("ddpm", False), ("ddim", True)):
+        d = process.create_gaussian_diffusion(use_ddim=ddim)
+        assert isinstance(d, process.SpacedDiffusion) and d.num_timesteps == (50 if ddim else 1000)
+        assert list(d.timestep_map) == list(golden_tables[f"{tag}.timestep_map"])
+        for k, v in d.tables().items():
+            assert np.array_equal(v, golden_tables[f"{tag}.{k}"]), k
+    with pytest.raises(NotImplementedError):
+        process.GaussianDiffusion(betas=[0.1], model_mean_type=process.ModelMeanType.EPSILON,
+                                  model_var_type=process.ModelVarType.FIXED_SMALL, loss_type=process.LossType.MSE)
+
+
+@pytest.mark.parametrize("ddim", [False, True])
+def test_generic_loops_equal_oracle(ddim):
+    """The per-step generic path (any nn.Module) reproduces the oracle's loop on the same injected noise."""
+    toy = ToyModel()
+    d = process.create_gaussian_diffusion(use_ddim=ddim)
+    ref = RefProcess(ddim)
+    y = {"style_feature": torch.randn(3, 4), "mask": torch.ones(3, 1, 1, 8, dtype=torch.bool)}
+    shape = (3, 6, 1, 8)
+    xT = torch.randn(*shape)
+    steps = 50 if ddim else 12
+    sn = torch.randn(steps, *shape)
+    fn = lambda a, b, c: toy(a, b, c)
+    if ddim:
+        got = d.ddim_sample_loop(toy, shape, noise=xT.clone(), clip_denoised=False, model_kwargs={"y": y}, step_noise=sn)
+        want = ref.ddim_sample_loop(fn, shape, y, noise=xT.clone(), step_noise=sn)
+    else:
+        got = d.p_sample_loop(toy, shape, noise=xT.clone(), clip_denoised=False, model_kwargs={"y": y},
+                              skip_timesteps=988, step_noise=sn)
+        want = ref.p_sample_loop(fn, shape, y, noise=xT.clone(), step_noise=sn, skip_timesteps=988)
+    assert rel_l2(got, want) < 1e-6
+    x0, t, eps = torch.randn(*shape), torch.tensor([0, 25, 49] if ddim else [0, 500, 999]), torch.randn(*shape)
+    a = d.training_losses(toy, x0, t, model_kwargs={"y": y}, noise=eps)
+    b = ref.training_losses(fn, x0, t, y, eps)
+    assert torch.allclose(a["loss"], b["loss"], rtol=1e-6) and torch.equal(a["loss"], a["rot_mse"])
+
+
+def test_step_coefficients_are_the_reference_updates():
+    """engine.posterior_coefs / ddim_coefs: x_next = c0*x0 + c1*x_t + sigma*eps must equal p_sample / ddim_sample.
+    Checked (a) against the fp32 oracle step (the DDIM eps-recovery (sqrt(1/ab) x - x0)/sqrt(1/ab - 1) cancels
+    badly in fp32 at small t, so the reference itself carries ~1e-4 there), and (b) against the same formulas
+    evaluated in fp64, where the linear form must be exact."""
+    x0, xt, eps = (torch.randn(1, 5, 1, 7, dtype=torch.float64) for _ in range(3))
+    for ddim in (False, True):
+        ref = RefProcess(ddim)
+        tab = ref.tab
+        coef64 = engine.ddim_coefs(tab, 0.0, "cpu") if ddim else engine.posterior_coefs(tab, "cpu")
+        for i in (0, 1, ref.num_timesteps // 2, ref.num_timesteps - 1):
+            t = torch.tensor([i])
+            step = ref.ddim_sample if ddim else ref.p_sample
+            want, _ = step(lambda a, b, c: x0.float(), xt.float(), t, {}, eps.float())
+            c = coef64[i].double()
+            got = c[0] * x0 + c[1] * xt + c[2] * eps
+            assert rel_l2(got, want) < (2e-4 if ddim else 2e-6), (ddim, i)
+            if ddim:    # fp64 evaluation of gaussian_diffusion.py:771-791
+                e_hat = (tab["sqrt_recip_alphas_cumprod"][i] * xt - x0) / tab["sqrt_recipm1_alphas_cumprod"][i]
+                exact = x0 * np.sqrt(tab["alphas_cumprod_prev"][i]) + np.sqrt(1 - tab["alphas_cumprod_prev"][i]) * e_hat
+            else:       # :255-277, :546-556
+                nz = 0.0 if i == 0 else 1.0
+                exact = tab["posterior_mean_coef1"][i] * x0 + tab["posterior_mean_coef2"][i] * xt + \
+                    nz * np.exp(0.5 * tab["posterior_log_variance_clipped"][i]) * eps
+            assert rel_l2(got, exact) < 1e-6, (ddim, i)           # fp32 rounding of the coefficient table only
+    assert float(engine.posterior_coefs(RefProcess(False).tab, "cpu")[0, 2]) == 0.0     # no noise at t == 0
+    e = engine.ddim_coefs(RefProcess(True).tab, 0.7, "cpu")                              # eta > 0 draws noise
+    assert float(e[10, 2]) > 0 and float(e[0, 2]) == 0.0
+
+
+def test_guidance_plans_and_generic_path_equal_oracle():
+    toy = ToyModel()
+    fn = lambda a, b, c: toy(a, b, c)
+    x, t = torch.randn(1, 1536, 1, 4), torch.tensor([17])
+    y = {"style_feature": torch.randn(1, 256), "seed": torch.zeros(1, 4, 1536)}
+    got = guidance.ClassifierFreeSampleModel(toy)(x, t, dict(y, scale=torch.ones(1) * 2.5))
+    assert rel_l2(got, gr.cfg(fn, x, t, dict(y, scale=torch.ones(1) * 2.5))) < 1e-6
+    yy = dict(y, scale_audio=torch.ones(1) * 1.0, scale_prompt=torch.ones(1) * 4.0)
+    assert rel_l2(guidance.TwoClassifierFreeSampleModel(toy)(x, t, dict(yy)), gr.two_cfg(fn, x, t, dict(yy))) < 1e-6
+    parts = {"upper_mask": torch.randn(1, 256), "hands_mask": None, "lower_mask": torch.randn(1, 256)}
+    w = guidance.TwoClassifierFreeSampleModel_Bodypart(toy)
+    assert rel_l2(w(x, t, dict(y, style_feature=parts)), gr.two_cfg_bodypart(fn, x, t, dict(y, style_feature=parts))) < 1e-6
+    plan = w.plan(dict(y, style_feature=parts))
+    assert len(plan.variants) == 4                               # 9 reference evaluations, de-duplicated (MDM semantics)
+    assert np.allclose(np.array(plan.weights).sum(1), 1.0)       # per channel block the weights sum to one
+    w2 = guidance.ClassifierFreeSampleModel_Bodypart(toy)
+    yb = dict(y, style_feature=parts, scale=torch.ones(1) * 2.5)
+    assert rel_l2(w2(x, t, dict(yb)), gr.cfg_bodypart(fn, x, t, dict(yb))) < 1e-6
+    assert np.allclose(np.array(w2.plan(yb).weights).sum(1), 1.0)
+    with pytest.raises(NotImplementedError):                      # per-sample scales are not fused
+        guidance.ClassifierFreeSampleModel(toy).plan(dict(y, scale=torch.tensor([1.0, 2.0])))
+    assert guidance.resolve(toy) == (None, None)
+
+
+@pytest.mark.parametrize("variant", ["beatx", "h3d"])
+def test_folding_and_conditioning_equal_oracle(variant):
+    sd = synth_state_dict(variant)
+    style = variant == "h3d"
+    fw = conditioning.fold_input_stage(sd, style)
+    fo = dr.fold_weights(dr.cast_sd(sd, torch.float64), variant)
+    for k in ("A", "cbias", "W2a", "W2c"):
+        assert rel_l2(fw[k], fo[k]) < 1e-12, k
+    y = synth.synth_clip_inputs(2, seed=3, style_dim=256 if style else 512, style_zero=not style)
+    cc = conditioning.ClipConditioner(sd, fw, variant, style)
+    for flags in ((False, False), (True, True)):
+        yy = dict(y, uncond=flags[0], uncond_audio=flags[1])
+        want = dr.clip_conditioning(sd, yy, {k: (v.float() if v is not None else None) for k, v in fo.items()}, variant)
+        assert rel_l2(cc.cond(y, *flags), want) < 5e-6, flags
+    te = conditioning.time_table(sd, fw["W2a"], 1000)
+    assert rel_l2(te, dr.time_table(sd, {k: (v.float() if v is not None else None) for k, v in fo.items()})) < 5e-6
+    rc, rs = conditioning.rotary_tables(sd["rel_pos.inv_freq"])
+    assert rc.shape == (32, 32) and torch.allclose(rc ** 2 + rs ** 2, torch.ones(32, 32), atol=1e-6)
+
+
+@pytest.mark.parametrize("variant", ["beatx", "h3d"])
+def test_state_dict_surface_and_checkpoint_format(variant, tmp_path):
+    from syntalker_amd.denoiser import MDM, MDM_RVQ
+    from syntalker_amd.denoiser_h3d import MDM as MDMH
+    m = (MDMH if variant == "h3d" else MDM)(synth.default_args())
+    assert MDM_RVQ is MDM
+    sd = m.state_dict()
+    for k, shp in state_spec(variant).items():
+        assert k in sd and tuple(sd[k].shape) == tuple(shp), k
+    assert sum(p.numel() for p in m.parameters()) == (30001252 if variant == "h3d" else 29607012)
+    synth.synth_fill_(m, seed=1)
+    path = tmp_path / "last_1.bin"
+    torch.save({"model_state": {"module." + k: v for k, v in m.state_dict().items()}}, path)       # DataParallel keys
+    m2 = (MDMH if variant == "h3d" else MDM)(synth.default_args())
+    checkpoint.load_checkpoints(m2, str(path))
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    checkpoint.save_checkpoints(str(path), m2)
+    assert set(torch.load(str(path))) == {"model_state"}
+
+
+def test_cpu_tensors_fail_loudly_and_train_mode_is_refused():
+    from syntalker_amd._lib import SynHipError
+    from syntalker_amd.denoiser import MDM
+    m = MDM(synth.default_args()).eval()
+    with pytest.raises(SynHipError):
+        m(synth.synth_latent(1), torch.tensor([3]), synth.synth_clip_inputs(1))
+
+
+def test_uniform_sampler_follows_numpy_global_rng():
+    d = process.create_gaussian_diffusion()
+    s = resample.create_named_schedule_sampler("uniform", d)
+    np.random.seed(2021)
+    t, w = s.sample(40, "cpu")
+    np.random.seed(2021)
+    want = np.random.choice(1000, size=(40,), p=np.ones(1000) / 1000)
+    assert np.array_equal(t.numpy(), want) and torch.all(w == 1) and t.dtype == torch.int64
+    with pytest.raises(NotImplementedError):
+        resample.create_named_schedule_sampler("loss-second-moment", d)
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """Every function declared in include/syn_hip.h is exported by the built shared object (no compute calls)."""
+    from syntalker_amd import _lib
+    header = open(os.path.join(REPO, "include", "syn_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(syn_[a-z_0-9]+)\s*\(", header, flags=re.M))
+    assert declared and declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.fail(f"{_lib.LIB_PATH} missing: run __graft_entry__.build()")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.syn_version() == 1
+    # struct sizes as the C compiler lays them out (include/syn_hip.h): 4 int32 + 20 pointers; 11 pointers; 760 B
+    assert ctypes.sizeof(_lib.SynStep) == 16 + 8 * 20 and ctypes.sizeof(_lib.SynLayer) == 88
+    assert ctypes.sizeof(_lib.SynModel) == 8 * 5 + 88 * 8 + 16
+
+
+def test_dropin_aliases_resolve():
+    from syntalker_amd import dropin
+    dropin.install()
+    from diffusion.model_util import create_gaussian_diffusion
+    from diffusion.cfg_sampler import TwoClassifierFreeSampleModel_Bodypart
+    from diffusion.resample import create_named_schedule_sampler
+    import importlib
+    MDM = getattr(importlib.import_module("models.denoiser"), "MDM")
+    assert create_gaussian_diffusion is process.create_gaussian_diffusion
+    assert TwoClassifierFreeSampleModel_Bodypart is guidance.TwoClassifierFreeSampleModel_Bodypart
+    assert create_named_schedule_sampler is resample.create_named_schedule_sampler and MDM.__name__ == "MDM"

@@ -1,0 +1,67 @@
+"""world_size-2 gloo test (CPU) of the clip-sharded sampling path: slices, first_clip bookkeeping, ragged
+gather.  The denoiser is a stand-in module (the HIP MDM needs a GPU); the sharding code is the product's."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from syntalker_amd import process
+from syntalker_amd.sharding import gather_clips, sample_sharded, shard_range
+
+
+class Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor(0.6))
+
+    def forward(self, x, t, y=None):
+        return self.w * x + y["seed"].mean(dim=(1, 2)).view(-1, 1, 1, 1) + 0.001 * t.view(-1, 1, 1, 1).float()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _case(n=5):
+    g = torch.Generator().manual_seed(0)
+    shape = (n, 6, 1, 4)
+    y = {"seed": torch.randn(n, 4, 6, generator=g), "mask": torch.ones(n, 1, 1, 4, dtype=torch.bool), "scalar": 3}
+    return shape, y, torch.randn(*shape, generator=g), torch.randn(8, *shape, generator=g)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shape, y, xT, sn = _case()
+        d = process.create_gaussian_diffusion()
+        full = sample_sharded(d, Toy(), shape, {"y": y}, noise=xT, clip_denoised=False, skip_timesteps=992, step_noise=sn)
+        lo, hi = shard_range(shape[0], rank, world)
+        ragged = gather_clips(torch.full((hi - lo, 2), float(rank)), shape[0])
+        if rank == 0:
+            torch.save({"full": full, "ragged": ragged}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly():
+    for n in (1, 5, 8, 1023):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+
+
+def test_two_rank_sharded_sampling_equals_single_process(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    shape, y, xT, sn = _case()
+    d = process.create_gaussian_diffusion()
+    want = d.p_sample_loop(Toy(), shape, noise=xT, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=992, step_noise=sn)
+    assert torch.equal(got["full"], want)
+    assert got["ragged"].shape == (5, 2) and got["ragged"][:3].eq(0).all() and got["ragged"][3:].eq(1).all()
