@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o $TAG -- python $ROOT/bench.py "$@" > $OUT/bench.log 2>&1
-tail -1 $OUT/bench.log > $OUT/bench.json
+grep "^{\"metric\"" $OUT/bench.log | tail -1 > $OUT/bench.json
 find $OUT -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 rm -f $(find $OUT -name "*kernel_trace.csv")   # large; the stats table is what gets committed
 head -20 $OUT/kernel_stats.csv
