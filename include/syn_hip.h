@@ -126,6 +126,16 @@ int syn_axpby_rows(const float* x, const float* y, const float* coef_ab /*[n][2]
  * for any batch sharding across GPUs.  n % 4 == 0. */
 int syn_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t first_index, void* stream);
 
+/* ---- training building block ------------------------------------------------------------------------
+ * y[m][n] = sum_k x[m][k] * W[n][k] (+ bias[n]): nn.Linear forward on the MFMA GEMM (bf16 operands, fp32 accumulate
+ * and output).  The same entry point serves the backward passes with re-packed operands:
+ *   dgrad  dx = dy . W      -> x := dy (m x n_out),   w_packed := pack(W^T)   (n_in x n_out)
+ *   wgrad  dW = dy^T . x    -> x := dy^T (n_out x m), w_packed := pack(x^T)   (n_in x m)
+ * n % 512 == 0, k % 128 == 0 (callers zero-pad).  Replaces torch.nn.functional.linear for
+ * models/timm_transformer/transformer.py:85,102,146,149 and models/denoiser.py:148,162,170,195 in training. */
+int syn_linear(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k, float* y,
+               void* stream);
+
 /* ---- single stages, exported for unit tests and bisecting ----------------------------------- */
 /* Y[m][n] = sum_k X[m][k] * W[n][k] (+ bias[n]); X bf16 [m_rows][k], W packed, Y fp32 [m_rows][n]. n % 512 == 0. */
 int syn_test_gemm(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k,

@@ -1,0 +1,20 @@
+"""Training-step timing (not the contract bench): B clips per GPU, fwd+bwd+Adam, 1 GPU."""
+import sys, time, torch, numpy as np
+sys.path.insert(0, '.')
+from syntalker_amd import synth, training
+from syntalker_amd.denoiser import MDM
+from syntalker_amd.process import create_gaussian_diffusion
+from syntalker_amd.resample import create_named_schedule_sampler
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+m = synth.synth_fill_(MDM(synth.default_args()).train(), 0).cuda()
+d = create_gaussian_diffusion(); s = create_named_schedule_sampler("uniform", d)
+opt = torch.optim.Adam(m.parameters(), lr=5e-5, betas=(0.5, 0.999))
+y = synth.to_device(synth.synth_clip_inputs(B, seed=1, mask_batch=B), 'cuda')
+y["audio"] = torch.randn(B, 68266, 2, device='cuda')          # training clip length (beat_sep_lower.py:678)
+x0 = synth.synth_latent(B, seed=1, name="x0").cuda()
+for _ in range(3): training.train_step(m, d, s, opt, x0, {"y": y})
+torch.cuda.synchronize(); t0 = time.perf_counter()
+n = 10
+for _ in range(n): training.train_step(m, d, s, opt, x0, {"y": y})
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+print(f"train step B={B}: {dt*1e3:.1f} ms  ({B/dt:.0f} samples/s on 1 GPU)")

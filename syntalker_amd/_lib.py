@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SYN_HIP_LIB") or os.path.join(_HERE, "csrc", "libsyn_
 
 SYN_LAYERS = 8
 EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_step_profile", "syn_pack_weight", "syn_to_token_major",
-           "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_test_gemm", "syn_test_attention")
+           "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_test_gemm", "syn_test_attention")
 
 vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
 
@@ -64,6 +64,7 @@ def load():
     lib.syn_from_token_major.argtypes = [vp, i32, vp, vp]
     lib.syn_axpby_rows.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     lib.syn_randn.argtypes = [vp, i64, u64, u64, i64, vp]
+    lib.syn_linear.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     lib.syn_test_gemm.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.syn_test_attention.argtypes = [vp, vp, vp, i32, vp, vp]
     for name in EXPORTS:

@@ -1411,6 +1411,17 @@ int syn_test_gemm(const void* x_bf16, const void* w_packed, const float* bias, i
     return launch_gemm<EPI_PLAIN>(a, m_tile ? m_tile : pick_tile(m_rows), n / kNT, (hipStream_t)stream);
 }
 
+int syn_linear(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k, float* y,
+               void* stream) {
+    if (!x_bf16 || !w_packed || !y || n % kNT || k % 128 || m_rows <= 0)
+        return fail_msg("syn_linear: need n % 512 == 0, k % 128 == 0, m_rows > 0 and non-null pointers");
+    GArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = (const __bf16*)x_bf16; a.ldx = k; a.x_rows = m_rows; a.W = (const uint4*)w_packed; a.K = k; a.M = m_rows;
+    a.bias = bias; a.Yf = y; a.ldyf = n;
+    return launch_gemm<EPI_PLAIN>(a, pick_tile(m_rows), n / kNT, (hipStream_t)stream);
+}
+
 int syn_test_attention(const void* q, const void* k, const void* vt, int32_t n_seq, void* o, void* stream) {
     if (!q || !k || !vt || !o || n_seq <= 0) return fail_msg("syn_test_attention: bad arguments");
     hipLaunchKernelGGL(k_attn, dim3(n_seq), dim3(256), 0, (hipStream_t)stream, (const __bf16*)q, (const __bf16*)k,

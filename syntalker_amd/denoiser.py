@@ -153,6 +153,7 @@ class MDM(nn.Module):
         self._bufs, self._cond_entry = {}, None
         self.m_tile = 0
         self.layer_mode = 0            # 0 whole-stack kernel (production); 2 / 1: two / five kernels per block (A/B)
+        self.differentiable_eval = False   # eval() + autograd on: take the differentiable path (gradient tests)
 
     # ---- engine plumbing ----------------------------------------------------------------------
     @property
@@ -204,6 +205,9 @@ class MDM(nn.Module):
     # ---- reference-compatible call --------------------------------------------------------------
     def forward(self, x, timesteps, y=None, uncond_info=False):
         """x (B, 1536, 1, T=32), timesteps (B,) -> predicted x_0, same shape (models/denoiser.py:132-196)."""
+        if torch.is_grad_enabled() and (self.training or self.differentiable_eval):
+            from . import training                      # differentiable path: HIP GEMMs fwd/dgrad/wgrad (training.py)
+            return training.train_forward(self, x, timesteps, y)
         return self.forward_variants(x, timesteps, y, [self.own_variant(y)], None)
 
     def forward_variants(self, x, timesteps, y, variants, weights):
@@ -211,9 +215,7 @@ class MDM(nn.Module):
         (weights (3, V): one row per 512-channel body-part block; None for V == 1)."""
         engine._require_cuda(x, "x")
         if self.training and torch.is_grad_enabled():
-            raise NotImplementedError(
-                "MDM is in train() mode with autograd on: the HIP backward kernels are not part of this round "
-                "(DESIGN.md, scope). Call .eval() / torch.no_grad() for sampling.")
+            raise NotImplementedError("guidance / fused sampling is inference-only: call .eval() and torch.no_grad()")
         B, Cc, _, Tt = x.shape
         if Cc != engine.CH or Tt != engine.T:
             raise SynHipError(f"step kernels are specialised for (B,1536,1,32) latents, got {tuple(x.shape)}")

@@ -1,0 +1,187 @@
+"""Training path of the denoiser (e): `training_losses` forward + backward.
+
+Structure this round
+  * every nn.Linear of the denoiser (qkv, proj, fc1, fc2, poseEmbedding, input_process2/3, poseFinal, embed_text,
+    time MLP, word/mix projections) runs forward, dgrad and wgrad on the hand-written MFMA GEMM through the C ABI
+    entry `syn_linear` (bf16 operands, fp32 accumulate/output) — `HipLinearFn`;
+  * LayerNorm, softmax attention, GELU, rotary, DropPath and the SmoothL1 loss are fp32 PyTorch-ROCm ops here
+    (fused HIP backward kernels for them are the next step), and the WavEncoder convolutions (78 % of the
+    training FLOPs) run on MIOpen, as SURVEY.md §7 stage 6 prescribes for the first cut;
+  * data parallelism: one process per GPU, torch DDP over RCCL (`make_ddp`), gradients averaged by bucketed
+    all-reduce overlapped with backward; optional SyncBatchNorm for the WavEncoder (the reference's DDP branch,
+    train.py:90).
+Train-mode semantics follow the reference: BatchNorm batch statistics, DropPath(0.1) per sample with
+scale-by-keep (timm_transformer/transformer.py:21-38), h3d Bernoulli(0.3) style dropout
+(denoiser_h3d.py:116-124).  There is no CPU fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib, engine
+
+
+def _ceil_to(a: int, m: int) -> int:
+    return (a + m - 1) // m * m
+
+
+def hip_matmul_nt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """fp32 y[M, N] = x[M, K] @ w[N, K]^T (+ bias) on the MFMA GEMM (operands rounded to bf16).
+    Shapes are zero-padded to the kernel's granularity (N % 512, K % 128)."""
+    engine._require_cuda(x, "training input")
+    M, K = x.shape
+    N = w.shape[0]
+    Kp, Np = _ceil_to(K, 128), _ceil_to(N, 512)
+    xb = x.to(torch.bfloat16)
+    wf = w.float()
+    if Kp != K:
+        xb = F.pad(xb, (0, Kp - K))
+        wf = F.pad(wf, (0, Kp - K))
+    if Np != N:
+        wf = F.pad(wf, (0, 0, 0, Np - N))
+    xb = xb.contiguous()
+    wp = engine.pack_weight(wf.contiguous())
+    b = None
+    if bias is not None:
+        b = bias.float()
+        if Np != N:
+            b = F.pad(b, (0, Np - N))
+        b = b.contiguous()
+    y = torch.empty(M, Np, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().syn_linear(xb.data_ptr(), wp.data_ptr(), _lib.ptr(b), M, Np, Kp, y.data_ptr(),
+                                      _lib.current_stream()), "syn_linear")
+    return y if Np == N else y[:, :N]
+
+
+class HipLinearFn(torch.autograd.Function):
+    """y = x W^T + b with forward, dgrad and wgrad on syn_linear."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        K = x.shape[-1]
+        xb = x.reshape(-1, K).to(torch.bfloat16)
+        y = hip_matmul_nt(xb, w, b)
+        ctx.save_for_backward(xb, w)
+        ctx.has_bias = b is not None
+        ctx.in_shape = x.shape
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, w = ctx.saved_tensors
+        N = w.shape[0]
+        dy2 = dy.reshape(-1, N)
+        dyb = dy2.to(torch.bfloat16)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = hip_matmul_nt(dyb, w.t()).reshape(ctx.in_shape)              # dy . W
+        if ctx.needs_input_grad[1]:
+            dw = hip_matmul_nt(dyb.t(), xb.t()).to(w.dtype)                   # dy^T . x  (contraction over tokens)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dw, db
+
+
+def lin(x, module: nn.Linear):
+    return HipLinearFn.apply(x, module.weight, module.bias)
+
+
+def _drop_path(x, p: float, training: bool):
+    if p == 0. or not training:
+        return x
+    keep = 1 - p
+    mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep).div_(keep)
+    return x * mask
+
+
+def _rotary(m, h):
+    """models/denoiser.py:178-186,324-343 on (B, T, 512)."""
+    B, T, _ = h.shape
+    g = h.view(B, T, 8, -1).permute(0, 2, 1, 3).reshape(B * 8, T, -1)
+    pos = torch.arange(T, device=h.device).type_as(m.rel_pos.inv_freq)
+    fr = torch.einsum("i,j->ij", pos, m.rel_pos.inv_freq)
+    fr = torch.cat((fr, fr), dim=-1)
+    half = g.shape[-1] // 2
+    g = g * fr.cos() + torch.cat((-g[..., half:], g[..., :half]), dim=-1) * fr.sin()
+    return g.reshape(B, 8, T, -1).permute(0, 2, 1, 3).reshape(B, T, -1)
+
+
+def _wav_block(blk, x):
+    """models/utils/layer.py:171-184 with the module's own Conv1d / BatchNorm1d (train or eval statistics)."""
+    short = x
+    z = F.leaky_relu(blk.bn1(blk.conv1(x)), 0.01)
+    z = blk.bn2(blk.conv2(z))
+    if blk.downsample is not None:
+        short = blk.downsample(short)
+    return F.leaky_relu(z + short, 0.01)
+
+
+def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
+    """Differentiable MDM.forward, op-for-op with models/denoiser.py:132-196 (denoiser_h3d.py:148-221), with the
+    module's current train()/eval() semantics.  x (B,1536,1,T) -> (B,1536,1,T)."""
+    engine._require_cuda(x, "x")
+    bs, C, _, T = x.shape
+    training = m.training
+    h3d = m.variant == "h3d"
+    te = m.embed_timestep
+    e = te.sequence_pos_encoder.pe[timesteps]                                   # (B,1,512)
+    emb_t = lin(F.silu(lin(e, te.time_embed[0])), te.time_embed[2]).permute(1, 0, 2)
+    emb_seed = lin(y["seed"].reshape(bs, -1), m.embed_text)
+    audio, word = y["audio"], y["word"]
+    if h3d and y.get("uncond_audio", False):
+        audio, word = torch.zeros_like(audio), torch.zeros_like(word)
+    a = audio.unsqueeze(1) if audio.dim() == 2 else audio.transpose(1, 2)
+    for blk in m.WavEncoder.feat_extractor:
+        a = _wav_block(blk, a)
+    a_feat = a.transpose(1, 2).permute(1, 0, 2)                                  # (128, B, 256)
+    w_feat = lin(m.text_pre_encoder_body(word), m.text_encoder_body).permute(1, 0, 2)
+    at = lin(torch.cat([a_feat, w_feat], dim=2), m.mix_audio_text)
+    at = F.avg_pool1d(at.permute(1, 2, 0), getattr(m.args, "vqvae_squeeze_scale", 4) if not h3d else 4).permute(2, 0, 1)
+    xt = x.reshape(bs, C, 1, T).permute(3, 0, 1, 2).reshape(T, bs, C)
+    x_ = lin(xt, m.input_process.poseEmbedding)
+    seq = lin(torch.cat(((emb_seed + emb_t).repeat(T, 1, 1), x_, at), dim=2), m.input_process2)
+    if m.uses_style:
+        st = y["style_feature"]
+        force = bool(y.get("uncond", False))
+        null = m.uncon_text_embeddings.repeat(bs, 1) if h3d else torch.zeros_like(st)
+        if force:
+            st = null
+        elif training and m.cond_mask_prob > 0.:
+            mask = torch.bernoulli(torch.ones(bs, device=st.device) * m.cond_mask_prob).view(bs, 1)
+            st = st * (1. - mask) + null * mask
+        seq = lin(torch.cat((seq, st.unsqueeze(0).repeat(T, 1, 1)), dim=2), m.input_process3)
+    h = _rotary(m, seq.permute(1, 0, 2))
+    for blk in m.mytimmblocks:
+        z = F.layer_norm(h, (512,), blk.norm1.weight, blk.norm1.bias, 1e-5)
+        qkv = lin(z, blk.attn.qkv).reshape(bs, T, 3, 4, 128).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], dropout_p=0.0).transpose(1, 2).reshape(bs, T, 512)
+        h = h + _drop_path(lin(o, blk.attn.proj), drop_path, training)
+        z = F.layer_norm(h, (512,), blk.norm2.weight, blk.norm2.bias, 1e-5)
+        h = h + _drop_path(lin(F.gelu(lin(z, blk.mlp.fc1)), blk.mlp.fc2), drop_path, training)
+    out = lin(h.permute(1, 0, 2), m.output_process.poseFinal)
+    return out.reshape(T, bs, C, 1).permute(1, 2, 3, 0)
+
+
+def make_ddp(model, local_rank: int | None = None, sync_bn: bool = False):
+    """One process per GPU, gradients all-reduced over RCCL (backend "nccl"); `embed_style` and the h3d
+    `uncon_audio_embeddings` never receive gradients (unused in forward), hence find_unused_parameters."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    if sync_bn:
+        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    dev_ids = None if local_rank is None else [local_rank]
+    return DDP(model, device_ids=dev_ids, broadcast_buffers=False, find_unused_parameters=True,
+               gradient_as_bucket_view=True, bucket_cap_mb=64)
+
+
+def train_step(model, diffusion, sampler, optimizer, x0, model_kwargs, grad_norm: float = 0.99):
+    """The body of the reference's hot training loop (diffusion_rvqvae_trainer.py:339-356, 555-560)."""
+    t, _ = sampler.sample(x0.shape[0], x0.device)
+    optimizer.zero_grad(set_to_none=True)
+    loss = diffusion.training_losses(model, x0, t, model_kwargs=model_kwargs)["loss"].mean()
+    loss.backward()
+    if grad_norm:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm)
+    optimizer.step()
+    return loss.detach()

@@ -264,3 +264,64 @@ def test_full_size_properties(beatx):
     # identical clips (the batch tiles 4 distinct clips) produce identical rows of x0_hat
     x0 = sb.read(sb.x0)
     assert rel_l2(x0[0:4].cpu(), x0[4:8].cpu()) > 1e-3              # different x_T rows -> different outputs
+
+
+# ---------------------------------------------------------------------------------------------------------
+# training path: loss value, gradient norms vs the reference goldens, full gradients vs the oracle
+def test_training_loss_and_gradients(golden):
+    from oracle import denoiser_ref as dr
+    from oracle.process_ref import RefProcess
+    from syntalker_amd.process import create_gaussian_diffusion
+    m = _model("beatx")
+    m.differentiable_eval = True                      # the goldens were taken with an eval()-mode model (deterministic)
+    y = synth.synth_clip_inputs(4, seed=5)
+    x0, eps = synth.synth_latent(4, seed=5, name="x0"), synth.synth_latent(4, seed=6, name="eps")
+    t4 = torch.tensor([0, 17, 500, 999])
+    d = create_gaussian_diffusion()
+    terms = d.training_losses(m, x0.to(DEV), t4.to(DEV), model_kwargs={"y": synth.to_device(y, DEV)}, noise=eps.to(DEV))
+    loss = terms["loss"]
+    assert np.allclose(loss.detach().cpu().numpy(), golden["beatx.train.loss"], rtol=2e-2)
+    loss.mean().backward()
+    params = dict(m.named_parameters())
+    names = [str(n) for n in golden["beatx.train.gradnorm_names"]]
+    got = np.array([params[n].grad.norm().item() for n in names])
+    print("grad norms got/want:", got / golden["beatx.train.gradnorm"])
+    assert np.allclose(got, golden["beatx.train.gradnorm"], rtol=3e-2)
+    # full gradients of every parameter against autograd through the CPU oracle
+    buffers = ("running_mean", "running_var", ".pe", "inv_freq")
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(buffers)) for k, v in synth_state_dict("beatx").items()}
+    ref = RefProcess(False).training_losses(lambda a, b, c: dr.mdm_forward(sd, a, b, c), x0, t4, y, eps)["loss"].mean()
+    ref.backward()
+    worst = 0.0
+    for n, p in params.items():
+        if p.grad is None or n not in sd or sd[n].grad is None or float(sd[n].grad.norm()) == 0.0:
+            continue
+        e = rel_l2(p.grad.cpu(), sd[n].grad)
+        worst = max(worst, e)
+        assert e < 3e-2, (n, e)                      # bf16 GEMM operands in forward, dgrad and wgrad
+    print(f"worst per-tensor gradient rel-L2 vs oracle: {worst:.3e}")
+    assert params["embed_style.weight"].grad is None     # never used in forward
+
+
+def test_train_mode_step_runs_and_updates(beatx):
+    """train(): BatchNorm batch statistics + DropPath; one Adam step (lr, betas of optimizers/optim_factory.py:122)."""
+    from syntalker_amd import training
+    from syntalker_amd.process import create_gaussian_diffusion
+    from syntalker_amd.resample import create_named_schedule_sampler
+    m = _model("h3d").train()
+    d = create_gaussian_diffusion()
+    opt = torch.optim.Adam(m.parameters(), lr=5e-5, betas=(0.5, 0.999))
+    y = synth.to_device(synth.synth_clip_inputs(4, seed=51, style_dim=256, style_zero=False), DEV)
+    x0 = synth.synth_latent(4, seed=51, name="x0").to(DEV)
+    before = m.mytimmblocks[0].attn.qkv.weight.detach().clone()
+    rm = m.WavEncoder.feat_extractor[0].bn1.running_mean.clone()
+    np.random.seed(0); torch.manual_seed(0)
+    l1 = training.train_step(m, d, create_named_schedule_sampler("uniform", d), opt, x0, {"y": y})
+    l2 = training.train_step(m, d, create_named_schedule_sampler("uniform", d), opt, x0, {"y": y})
+    assert torch.isfinite(l1) and torch.isfinite(l2)
+    assert not torch.equal(before, m.mytimmblocks[0].attn.qkv.weight)            # parameters moved
+    assert not torch.equal(rm, m.WavEncoder.feat_extractor[0].bn1.running_mean)  # BatchNorm used batch statistics
+    m.eval()
+    with torch.no_grad():                                                         # packed weights follow the update
+        out = m(x0, torch.tensor([5, 6, 7, 8], device=DEV), y)
+    assert torch.isfinite(out).all()

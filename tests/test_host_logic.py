@@ -166,12 +166,14 @@ def test_state_dict_surface_and_checkpoint_format(variant, tmp_path):
     assert set(torch.load(str(path))) == {"model_state"}
 
 
-def test_cpu_tensors_fail_loudly_and_train_mode_is_refused():
+def test_cpu_tensors_fail_loudly():
     from syntalker_amd._lib import SynHipError
     from syntalker_amd.denoiser import MDM
     m = MDM(synth.default_args()).eval()
     with pytest.raises(SynHipError):
         m(synth.synth_latent(1), torch.tensor([3]), synth.synth_clip_inputs(1))
+    with pytest.raises(SynHipError):                     # the training path has no CPU fallback either
+        m.train()(synth.synth_latent(1), torch.tensor([3]), synth.synth_clip_inputs(1))
 
 
 def test_uniform_sampler_follows_numpy_global_rng():

@@ -65,3 +65,46 @@ def test_two_rank_sharded_sampling_equals_single_process(tmp_path):
     want = d.p_sample_loop(Toy(), shape, noise=xT, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=992, step_noise=sn)
     assert torch.equal(got["full"], want)
     assert got["ragged"].shape == (5, 2) and got["ragged"][:3].eq(0).all() and got["ragged"][3:].eq(1).all()
+
+
+# ---- data-parallel training wiring: torch DDP as configured by training.make_ddp, gloo on CPU ----
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from syntalker_amd.training import make_ddp
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+        net.add_module("unused", torch.nn.Linear(2, 2))          # like embed_style: never reached in forward
+        fwd = lambda m, x: m[2](m[1](m[0](x)))
+        g = torch.Generator().manual_seed(7)
+        data = torch.randn(8, 6, generator=g)
+        lo, hi = shard_range(8, rank, world)
+
+        class Wrap(torch.nn.Module):
+            def __init__(self, m):
+                super().__init__()
+                self.m = m
+
+            def forward(self, x):
+                return fwd(self.m, x)
+        w = make_ddp(Wrap(net))
+        w.zero_grad()
+        ((w(data[lo:hi])) ** 2).mean().backward()
+        if rank == 0:
+            torch.save({k: p.grad.clone() for k, p in w.module.m.named_parameters() if p.grad is not None}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_ddp_gradients_equal_full_batch(tmp_path):
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_ddp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    data = torch.randn(8, 6, generator=torch.Generator().manual_seed(7))
+    ((net(data)) ** 2).mean().backward()                          # equal shards: mean of shard means == full mean
+    for k, p in net.named_parameters():
+        assert torch.allclose(got[k], p.grad, atol=1e-6), k
+    assert not any(k.startswith("unused") for k in got)
