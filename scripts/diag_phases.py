@@ -5,6 +5,7 @@ from syntalker_amd.denoiser import MDM
 from syntalker_amd.process import create_gaussian_diffusion
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 mt = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+NOISE = (sys.argv[3] if len(sys.argv) > 3 else 'rng')      # rng | buf | none
 m = synth.synth_fill_(MDM(synth.default_args()).eval(), 0).cuda(); m.m_tile = mt
 pm = m.packed(); sb = m.buffers(B, 1)
 sb.cond.normal_(); sb.load_x(torch.randn(B, 1536, 1, 32, device='cuda'))
@@ -12,15 +13,26 @@ coef = engine.posterior_coefs(create_gaussian_diffusion().tables(), 'cuda')
 lib = _lib.load()
 nm = (B * 32 + min(mt, 64) - 1) // min(mt, 64)
 dm = torch.zeros(nm * 32, dtype=torch.int64, device='cuda')
+sb.set_rng(7, 0)
+kw = dict(use_noise=NOISE != 'none', fused_rng=NOISE == 'rng')
 for i in range(3):
-    engine.run_step(pm, sb, coef, True)
+    engine.run_step(pm, sb, coef, **kw)
 lib.syn_debug_timing.argtypes = [C.c_void_p, C.c_void_p]
 lib.syn_debug_timing(None, dm.data_ptr())
-engine.run_step(pm, sb, coef, True); torch.cuda.synchronize()
+engine.run_step(pm, sb, coef, **kw); torch.cuda.synchronize()
 lib.syn_debug_timing(None, None)
 t = dm.view(-1, 32).cpu().numpy().astype(np.int64)
-names = ["entry->LN1(l3) [h load + layers 0-2]", "QKV head0", "attention head0", "proj-partial head0", "heads 1-3", "LN2", "MLP", "layers 4-7 + store"]
-dur = np.diff(t[:, :9], axis=1)
-for n, d in zip(names, np.median(dur, axis=0)):
-    print(f"  {n:40s} {int(d):8d} cycles")
-print("  total per WG (median):", int(np.median(t[:, 8] - t[:, 0])))
+med = lambda a: int(np.median(a))
+print(f"B={B} workgroups {t.shape[0]}")
+print("  input stage (x.A^T + cond + rotary)      ", med(t[:, 9] - t[:, 0]))
+print("  blocks 0-2 (+LN1 of block 3)             ", med(t[:, 1] - t[:, 9]))
+print("  block 3: QKV head0                       ", med(t[:, 2] - t[:, 1]))
+print("  block 3: attention head0                 ", med(t[:, 3] - t[:, 2]))
+print("  block 3: proj-partial head0              ", med(t[:, 4] - t[:, 3]))
+print("  block 3: heads 1-3                       ", med(t[:, 5] - t[:, 4]))
+print("  block 3: LN2                             ", med(t[:, 6] - t[:, 5]))
+print("  block 3: MLP                             ", med(t[:, 7] - t[:, 6]))
+print("  blocks 4-7                               ", med(t[:, 10] - t[:, 7]))
+print("  output stage (3 x 512 cols + posterior)  ", med(t[:, 8] - t[:, 10]))
+print("  total per workgroup                      ", med(t[:, 8] - t[:, 0]))
+print("  output stage detail: to-LDS+gemm0, epi0, gemm1, epi1, gemm2, epi2:", [med(t[:, 11] - t[:, 10]), med(t[:, 12] - t[:, 11]), med(t[:, 13] - t[:, 12]), med(t[:, 14] - t[:, 13]), med(t[:, 15] - t[:, 14]), med(t[:, 16] - t[:, 15])])

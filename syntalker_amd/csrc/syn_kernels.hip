@@ -1113,6 +1113,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
         __syncthreads();        // region B (hidden slices) becomes q/k/v + LayerNorm scratch of the next block
         if (l == 3) stamp(a.dbg, 7);
     }
+    if (a.dbg) stamp(a.dbg, 10);
     if (a.out.Xn != nullptr) {
         // ---- output stage: x0 = h . Wout^T + b (there is no final LayerNorm, models/denoiser.py:188-195), then
         //      x_next = c0*x0 + c1*x_t + sigma*eps.  bf16(h) goes to XN with the usual swizzle.
@@ -1134,6 +1135,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
             uint4 ro[4][4];
             kloop_prime<4, 1, KS1, 4>(ro, wo, KS1, 0);
             kloop_run<MF, 4, 1, 0, KS1, 1024, 4>(acc, ro, XN, wo, KS1, 0);
+            if (a.dbg) stamp(a.dbg, 11 + 2 * c);
             const int ncol = c * kNT + wave * 64;
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
@@ -1155,6 +1157,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
                     if (a.out.X0) *reinterpret_cast<f32x4*>(a.out.X0 + off) = x0;
                 }
             }
+            if (a.dbg) stamp(a.dbg, 12 + 2 * c);
         }
     } else {
     // ---- out: y = bf16(h) (there is no final LayerNorm, models/denoiser.py:188-195), optionally fp32 h ------
