@@ -69,7 +69,9 @@ typedef struct syn_step {
     int32_t n_clips;        /* B                                                                 */
     int32_t n_variants;     /* V >= 1                                                            */
     int32_t m_tile;         /* rows per workgroup: 0 = auto, else 32 / 64 / 128                  */
-    int32_t reserved;
+    int32_t reserved;       /* kernel selection: 0 = auto (small-batch kernel when a group holds <= 3 sequences and
+                               ws_sync != NULL, else the whole-step kernel); 4 = whole-step kernel always;
+                               3 = small-batch kernel always; 1 / 2 = five / two kernels per block (A/B)   */
     /* conditioning, row (v*B + b)*32 + frame */
     const float*   cond;    /* [V*B*32][512] per-clip term: cbias + c_frame + seed/style term    */
     const int32_t* t_model; /* [V*B] ORIGINAL timestep -> row of syn_model.te                    */
@@ -96,6 +98,8 @@ typedef struct syn_step {
     void*  ws_o;      /* [R][512]  bf16 attention output                                         */
     void*  ws_hid;    /* [R][1024] bf16 MLP hidden                                               */
     void*  ws_hc;     /* [3][B*32][512] bf16 guidance-combined stream (only if V > 1)            */
+    uint32_t* ws_sync; /* [320] u32, zeroed ONCE by the caller; small-batch path only (group-barrier
+                          counters; word 256 = sticky error flag: a barrier wait ran out)        */
 } syn_step;
 
 /* Enqueue one full step (42 kernels) on `stream`. */

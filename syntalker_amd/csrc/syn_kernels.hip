@@ -1342,6 +1342,28 @@ int launch_stack(const SArgs& a, int mt, hipStream_t s) {
     return e == hipSuccess ? 0 : fail("k_stack launch", e);
 }
 
+#include "syn_latency.inc"
+
+int launch_latency(const lat::LArgs& a, hipStream_t s) {
+    static bool once = false;
+    if (!once) { allow_lds(lat::k_lat, lat::kLds); once = true; }
+    hipLaunchKernelGGL(lat::k_lat, dim3(lat::kGroups * lat::kP), dim3(kThreads), lat::kLds, s, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_lat launch", e);
+}
+
+// k_lat is written for 8 XCDs x 32 CUs (MI355X in SPX mode): one workgroup per CU, all co-resident.
+bool latency_path_ok() {
+    static int ok = -1;
+    if (ok < 0) {
+        int dev = 0, cus = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        ok = cus == lat::kGroups * lat::kP ? 1 : 0;
+    }
+    return ok == 1;
+}
+
 int pick_tile(int rows) {
     // enough workgroups to cover the 256 CUs first, then the larger tile (weight reuse per L2 byte).
     // 128-row tiles exist for the A/B paths only: with the 4-slot weight ring they exceed 256 VGPRs.
@@ -1463,7 +1485,33 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     GArgs a;
     auto mark = [&](int c) { if (tm) tm->mark(c); };
 
-    const int mode = st->reserved & 3;
+    int mode = st->reserved & 3;
+    // Small batches: the persistent feature-split kernel (syn_latency.inc) beats the token-resident one while a
+    // group (XCD) holds at most 3 sequences (measured: 175 / 260 / ~350 us against ~450 us).  reserved bit 2
+    // pins the whole-step kernel (A/B runs, bitwise cross-checks against layer modes 1 / 2).
+    if (mode == 0 && !(st->reserved & 4) && st->ws_sync && ((B + lat::kGroups - 1) / lat::kGroups) * V <= 3 && latency_path_ok())
+        mode = 3;
+    if (mode == 3) {
+        // small-batch path: one persistent kernel, output features split over the CUs of an XCD
+        if (!st->ws_sync) return fail_msg("syn_denoise_step: the latency path needs ws_sync");
+        if (!latency_path_ok()) return fail_msg("syn_denoise_step: the latency path needs a 256-CU (8 XCD x 32) device");
+        lat::LArgs la;
+        memset(&la, 0, sizeof(la));
+        la.w_in = (const uint4*)md->w_in; la.te = md->te; la.rcos = md->rot_cos; la.rsin = md->rot_sin;
+        for (int l = 0; l < SYN_LAYERS; ++l) la.layer[l] = md->layer[l];
+        la.w_out = (const uint4*)md->w_out; la.b_out = md->b_out;
+        la.B = B; la.V = V;
+        la.cond = st->cond; la.t_model = st->t_model; la.cfg_w = st->cfg_w;
+        la.xb = (const __bf16*)st->x_t_bf16; la.xt = st->x_t; la.noise = st->noise;
+        la.rng = (const unsigned long long*)st->rng; la.coef = st->coef; la.t_coef = st->t_coef;
+        la.xn = st->x_next; la.xnb = (__bf16*)st->x_next_bf16; la.x0 = st->pred_x0;
+        la.H = st->ws_h; la.Q = (__bf16*)st->ws_q; la.Kb = (__bf16*)st->ws_k; la.Vt = (__bf16*)st->ws_vt;
+        la.HID = (__bf16*)st->ws_hid; la.sync = st->ws_sync; la.dbg = g_dbg_mlp;
+        if ((rc = launch_latency(la, s))) return rc;
+        mark(ST_FC2);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : fail("syn_denoise_step", e);
+    }
     // input stage: h = rotary(x_t A^T + cond + te[t]) [; xn = LN1_0(h) for the unfused A/B paths]
     GArgs ain;
     memset(&ain, 0, sizeof(ain));

@@ -152,7 +152,8 @@ class MDM(nn.Module):
         self._packed, self._packed_key = None, None
         self._bufs, self._cond_entry = {}, None
         self.m_tile = 0
-        self.layer_mode = 0            # 0 whole-stack kernel (production); 2 / 1: two / five kernels per block (A/B)
+        self.layer_mode = 0            # syn_step.reserved: 0 library's choice (small-batch kernel for few sequences, else the
+                                       # whole-step kernel); 4 / 3 pin one of them; 2 / 1: two / five kernels per block (A/B)
         self.differentiable_eval = False   # eval() + autograd on: take the differentiable path (gradient tests)
 
     # ---- engine plumbing ----------------------------------------------------------------------

@@ -97,9 +97,12 @@ class StepBuffers:
         self.xn, self.q, self.k, self.o = e(R, D, dt=bf), e(R, D, dt=bf), e(R, D, dt=bf), e(R, D, dt=bf)
         self.vt, self.hid = e(R * D, dt=bf), e(R, FF, dt=bf)
         self.hc = e(3, Mb, D, dt=bf) if V > 1 else None
+        self.sync = torch.zeros(320, dtype=torch.int32, device=device)   # small-batch path: barrier counters + error flag
         s = _lib.SynStep()
         s.n_clips, s.n_variants, s.m_tile = B, V, m_tile
-        s.reserved = layer_mode                # 0 whole-stack kernel; 2 / 1 = two / five kernels per block (A/B, bisecting)
+        # 0 auto (small-batch kernel for few sequences, whole-step kernel otherwise); 4 / 3 pin one of them;
+        # 2 / 1 = two / five kernels per block (A/B, bisecting)
+        s.reserved = layer_mode
         s.cond, s.t_model, s.cfg_w = self.cond.data_ptr(), self.t_model.data_ptr(), _lib.ptr(self.cfg_w)
         s.x_t, s.x_t_bf16, s.noise = self.x.data_ptr(), self.xb.data_ptr(), self.noise.data_ptr()
         s.t_coef = self.t_coef.data_ptr()
@@ -107,6 +110,7 @@ class StepBuffers:
         s.x_next, s.x_next_bf16, s.pred_x0 = self.x.data_ptr(), self.xb.data_ptr(), _lib.ptr(self.x0)
         s.ws_h, s.ws_xn, s.ws_q, s.ws_k = self.h.data_ptr(), self.xn.data_ptr(), self.q.data_ptr(), self.k.data_ptr()
         s.ws_vt, s.ws_o, s.ws_hid, s.ws_hc = self.vt.data_ptr(), self.o.data_ptr(), self.hid.data_ptr(), _lib.ptr(self.hc)
+        s.ws_sync = self.sync.data_ptr()
         self.c = s
 
     # layout ------------------------------------------------------------------------------------
@@ -131,7 +135,16 @@ class StepBuffers:
         _lib.check(_lib.load().syn_randn(self.noise.data_ptr(), n, seed, step, first_clip * T * CH,
                                          _lib.current_stream()), "syn_randn")
 
+    def check_sync(self):
+        """The small-batch kernel's group barrier is bounded; a wait that ran out leaves a sticky flag."""
+        flag = int(self.sync[256].item())
+        if flag:
+            self.sync.zero_()
+            raise _lib.SynHipError(f"small-batch step kernel: group barrier wait ran out (flag {flag}); "
+                                   "is another kernel occupying CUs of this device?")
+
     def read(self, src: torch.Tensor) -> torch.Tensor:
+        self.check_sync()
         out = torch.empty(self.B, CH, 1, T, dtype=torch.float32, device=src.device)
         _lib.check(_lib.load().syn_from_token_major(src.data_ptr(), self.B, out.data_ptr(), _lib.current_stream()),
                    "syn_from_token_major")

@@ -36,7 +36,16 @@ def h3d():
     return _model("h3d")
 
 
-def test_forward_vs_golden(beatx, golden):
+@pytest.fixture(params=[4, 3], ids=["whole-step-kernel", "small-batch-kernel"])
+def kernel(request, beatx, h3d):
+    """Pin one of the two step kernels (syn_step.reserved: 4 = token-resident whole-step kernel, 3 = persistent
+    feature-split small-batch kernel); layer_mode 0 = the library's own choice by batch size."""
+    beatx.layer_mode = h3d.layer_mode = request.param
+    yield request.param
+    beatx.layer_mode = h3d.layer_mode = 0
+
+
+def test_forward_vs_golden(beatx, golden, kernel):
     y, x = synth.to_device(synth.synth_clip_inputs(2, seed=1), DEV), synth.synth_latent(2, seed=1).to(DEV)
     with torch.no_grad():
         o1 = beatx(x, torch.tensor([0, 3], device=DEV), y)
@@ -68,18 +77,36 @@ def test_forward_every_tile_size_and_ragged_batch(beatx, mt):
     t = torch.tensor([1, 250, 500, 750, 999])
     with torch.no_grad():
         want = dr.mdm_forward(synth_state_dict("beatx"), x, t, y)
-        beatx.m_tile = mt
+        beatx.m_tile, beatx.layer_mode = mt, 4
         try:
             got = beatx(x.to(DEV), t.to(DEV), synth.to_device(y, DEV)).cpu()
         finally:
-            beatx.m_tile = 0
+            beatx.m_tile, beatx.layer_mode = 0, 0
     assert rel_l2(got, want) < FWD_TOL
 
 
-def test_batch_rows_are_independent(beatx):
+@pytest.mark.parametrize("B", [1, 5, 9, 19])
+def test_small_batch_kernel_ragged_groups(beatx, B):
+    """The small-batch kernel splits the clips over 8 groups (XCDs): fewer clips than groups, uneven groups, more
+    than one chunk of two sequences per group - all against the CPU oracle."""
+    from oracle import denoiser_ref as dr
+    y, x = synth.synth_clip_inputs(B, seed=13), synth.synth_latent(B, seed=13)
+    t = (torch.arange(B) * 53 + 1) % 1000
+    with torch.no_grad():
+        want = dr.mdm_forward(synth_state_dict("beatx"), x, t, y)
+        beatx.layer_mode = 3
+        try:
+            got = beatx(x.to(DEV), t.to(DEV), synth.to_device(y, DEV)).cpu()
+        finally:
+            beatx.layer_mode = 0
+    assert rel_l2(got, want) < FWD_TOL
+
+
+@pytest.mark.parametrize("mode", [4, 3], ids=["whole-step-kernel", "small-batch-kernel"])
+def test_batch_rows_are_independent(beatx, mode):
     """Size-independent properties of the step kernels, bitwise: (1) repeat runs are deterministic,
-    (2) clip b of a batch equals the same clip evaluated alone, (3) every workgroup tile size gives
-    the same bits.  The per-clip conditioning tensor is computed once and shared, because the
+    (2) clip b of a batch equals the same clip evaluated alone (for the small-batch kernel: whichever group /
+    chunk it lands in), (3) every workgroup tile size of the whole-step kernel gives the same bits.  The per-clip conditioning tensor is computed once and shared, because the
     PyTorch/MIOpen conditioning ops are only fp32-reproducible (~3e-7) across batch sizes, and a
     perturbation of that size re-rolls bf16 roundings (measured: 3e-7 in -> 3e-3 out)."""
     from syntalker_amd import engine
@@ -90,7 +117,7 @@ def test_batch_rows_are_independent(beatx):
     ident = engine.identity_coefs(DEV)
 
     def run(B, xs, cs, ts, mt=0):
-        sb = engine.StepBuffers(B, 1, DEV, m_tile=mt)
+        sb = engine.StepBuffers(B, 1, DEV, m_tile=mt, layer_mode=mode)
         sb.cond.copy_(cs.reshape(-1, 512)); sb.load_x(xs); sb.t_model.copy_(ts.int()); sb.t_coef.zero_()
         engine.run_step(pm, sb, ident, False)
         return sb.read(sb.x).cpu()
@@ -98,19 +125,23 @@ def test_batch_rows_are_independent(beatx):
     full = run(3, x, cond, t)
     assert torch.equal(full, run(3, x, cond, t))
     assert torch.equal(run(1, x[1:2], cond[1:2], t[1:2]), full[1:2])
-    for mt in (32, 64, 128):
-        assert torch.equal(run(3, x, cond, t, mt), full)
+    if mode == 4:
+        for mt in (32, 64, 128):
+            assert torch.equal(run(3, x, cond, t, mt), full)
+    else:       # 20 copies of the 3 clips: groups of 7-8 clips, four chunks each; every copy must equal the original
+        big = run(60, x.repeat(20, 1, 1, 1), cond.repeat(20, 1, 1), t.repeat(20))
+        assert torch.equal(big, full.repeat(20, 1, 1, 1))
 
 
 def test_fused_layer_kernels_equal_unfused_bitwise(beatx):
-    """The whole-stack kernel (mode 0), the two-kernels-per-block path (mode 2) and the five-kernel path
+    """The whole-stack kernel (mode 4), the two-kernels-per-block path (mode 2) and the five-kernel path
     (mode 1) round at exactly the same points (LayerNorm outputs, q/k/v, P, o, hidden in bf16; fp32
     accumulation in the same k order) -> identical bits, for every tile size."""
     y, x = synth.to_device(synth.synth_clip_inputs(5, seed=41), DEV), synth.synth_latent(5, seed=41).to(DEV)
     t = torch.tensor([3, 100, 450, 800, 999], device=DEV)
     outs = {}
     with torch.no_grad():
-        for mode in (0, 1, 2):
+        for mode in (4, 1, 2):
             for mt in (32, 64, 128):
                 beatx.layer_mode, beatx.m_tile = mode, mt
                 try:
@@ -123,7 +154,7 @@ def test_fused_layer_kernels_equal_unfused_bitwise(beatx):
         assert torch.equal(v, ref), k
 
 
-def test_ddpm10_and_ddim50_vs_golden(beatx, golden):
+def test_ddpm10_and_ddim50_vs_golden(beatx, golden, kernel):
     from syntalker_amd.process import create_gaussian_diffusion
     y, xT = synth.to_device(synth.synth_clip_inputs(1, seed=2), DEV), synth.synth_latent(1, seed=2).to(DEV)
     s = create_gaussian_diffusion().p_sample_loop(beatx, (1, 1536, 1, 32), noise=xT.clone(), clip_denoised=False,
@@ -157,7 +188,7 @@ def test_fused_loop_equals_generic_loop(beatx):
     assert rel_l2(fused.cpu(), final.cpu()) < 1e-2
 
 
-def test_h3d_flags_vs_golden(h3d, golden):
+def test_h3d_flags_vs_golden(h3d, golden, kernel):
     y = synth.to_device(synth.synth_clip_inputs(2, seed=7, style_dim=256, style_zero=False), DEV)
     x, t = synth.synth_latent(2, seed=7).to(DEV), torch.tensor([10, 700], device=DEV)
     with torch.no_grad():
@@ -167,7 +198,7 @@ def test_h3d_flags_vs_golden(h3d, golden):
             assert e < FWD_TOL, (tag, e)
 
 
-def test_h3d_guidance_vs_golden(h3d, golden):
+def test_h3d_guidance_vs_golden(h3d, golden, kernel):
     from syntalker_amd import guidance as G
     y = synth.to_device(synth.synth_clip_inputs(2, seed=7, style_dim=256, style_zero=False), DEV)
     x, t = synth.synth_latent(2, seed=7).to(DEV), torch.tensor([10, 700], device=DEV)
@@ -189,7 +220,7 @@ def _bodypart_case():
     return synth.to_device(y, DEV), synth.synth_latent(1, seed=8).to(DEV), parts
 
 
-def test_h3d_bodypart_guidance_vs_golden(h3d, golden):
+def test_h3d_bodypart_guidance_vs_golden(h3d, golden, kernel):
     from syntalker_amd import guidance as G
     from syntalker_amd.process import create_gaussian_diffusion
     y, x, parts = _bodypart_case()
