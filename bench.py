@@ -94,6 +94,38 @@ def cpu_baseline(budget_s: float):
                       f"recomputed every step like the reference), {dt:.1f} s"}
 
 
+def small_batch_probe(pm, coef, dev, sizes=(1, 8, 32), reps=300):
+    """Step time at the batch sizes of the reference's own sampling scripts (test.py / demo.py denoise one window at
+    a time): the library picks the persistent feature-split kernel there.  Same graph-replayed step as the headline
+    number (posterior update + in-epilogue Philox noise), random conditioning, hipEvent-timed on the replay stream;
+    the whole-step kernel is timed beside it at B = 1."""
+    from syntalker_amd import engine
+
+    def timed(B, mode):
+        sb = engine.StepBuffers(B, 1, dev, layer_mode=mode)
+        sb.cond.normal_()
+        sb.load_x(torch.randn(B, 1536, 1, 32, device=dev))
+        sb.set_rng(7, 0)
+        sb.t_model.fill_(500); sb.t_coef.fill_(500)
+        g = engine.StepGraph(pm, sb, coef, True, fused_rng=True)
+        for _ in range(10):
+            g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        sb.check_sync()
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+    us = {B: timed(B, 0) for B in sizes}
+    return {"kernel": "k_lat: output features split over the 32 CUs of an XCD, one group per XCD, L2-local group barriers",
+            "us_per_step": {str(B): round(t, 1) for B, t in us.items()},
+            "clip_steps_per_s": {str(B): round(B / t * 1e6, 0) for B, t in us.items()},
+            "whole_step_kernel_us_per_step_B1": round(timed(1, 4), 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,7 +135,8 @@ def main():
     ap.add_argument("--m-tile", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--layer-mode", type=int, default=0, help="0 whole-stack kernel, 2 two kernels/block, 1 five kernels/block (A/B)")
+    ap.add_argument("--layer-mode", type=int, default=0, help="0 library's choice (whole-step kernel at the bench batch), 4 / 3 pin the whole-step / small-batch kernel, "
+                         "2 two kernels/block, 1 five kernels/block (A/B)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -124,7 +157,7 @@ def main():
     model = synth.synth_fill_(MDM(synth.default_args()).eval(), seed=0).to(dev)
     model.m_tile = args.m_tile
     model.layer_mode = args.layer_mode
-    STAGE_INFO = {0: STAGE_INFO_STACK, 1: STAGE_INFO_LEGACY, 2: STAGE_INFO_FUSED}[args.layer_mode]
+    STAGE_INFO = {0: STAGE_INFO_STACK, 4: STAGE_INFO_STACK, 3: STAGE_INFO_STACK, 1: STAGE_INFO_LEGACY, 2: STAGE_INFO_FUSED}[args.layer_mode]
     diff = create_gaussian_diffusion()
     pm = model.packed()
 
@@ -199,7 +232,8 @@ def main():
                        "syn_denoise_step_profile")
             for c in range(8):
                 tot[c] += ms[c]; launches[c] += cnt[c]
-        rename = {0: {"fc2_gemm": "step_kernel"}, 1: {}, 2: {"qkv_gemm": "attn_block", "fc2_gemm": "mlp_block"}}[args.layer_mode]
+        rename = {0: {"fc2_gemm": "step_kernel"}, 4: {"fc2_gemm": "step_kernel"}, 3: {"fc2_gemm": "step_kernel"}, 1: {},
+                  2: {"qkv_gemm": "attn_block", "fc2_gemm": "mlp_block"}}[args.layer_mode]
         stage_ms = {STAGES[c]: tot[c] / reps for c in range(8) if launches[c]}
         # group by kernel symbol (proj and fc2 share one)
         by_kernel = {}
@@ -213,7 +247,7 @@ def main():
         dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
         d = by_kernel[dom]
         avg_s = d["ms"] * 1e-3 / d["launches"]
-        if args.layer_mode == 0:       # the step IS one kernel: use the hipEvent brackets of the K timed replays
+        if args.layer_mode in (0, 3, 4):       # the step IS one kernel: use the hipEvent brackets of the K timed replays
             avg_s = replay_ms * 1e-3
         achieved = d["flops"] / d["launches"] / avg_s
         # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this
@@ -247,6 +281,8 @@ def main():
                             f"{cond_ms_per_clip / (dt / K * 1e3 / B):.0f} denoising steps' worth",
             "roofline": roofline,
         }
+        if args.layer_mode == 0:
+            out["small_batch"] = small_batch_probe(pm, coef, dev)
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

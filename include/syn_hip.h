@@ -69,7 +69,7 @@ typedef struct syn_step {
     int32_t n_clips;        /* B                                                                 */
     int32_t n_variants;     /* V >= 1                                                            */
     int32_t m_tile;         /* rows per workgroup: 0 = auto, else 32 / 64 / 128                  */
-    int32_t reserved;       /* kernel selection: 0 = auto (small-batch kernel when a group holds <= 3 sequences and
+    int32_t reserved;       /* kernel selection: 0 = auto (small-batch kernel when a group holds <= 4 sequences and
                                ws_sync != NULL, else the whole-step kernel); 4 = whole-step kernel always;
                                3 = small-batch kernel always; 1 / 2 = five / two kernels per block (A/B)   */
     /* conditioning, row (v*B + b)*32 + frame */

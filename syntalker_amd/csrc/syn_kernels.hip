@@ -1487,9 +1487,10 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
 
     int mode = st->reserved & 3;
     // Small batches: the persistent feature-split kernel (syn_latency.inc) beats the token-resident one while a
-    // group (XCD) holds at most 3 sequences (measured: 175 / 260 / ~350 us against ~450 us).  reserved bit 2
+    // group (XCD) holds at most 4 sequences (measured per step: 161 / 239 / 405 us at 1 / 2 / 4 sequences per
+    // group against ~445 us, and 733 us at 8).  reserved bit 2
     // pins the whole-step kernel (A/B runs, bitwise cross-checks against layer modes 1 / 2).
-    if (mode == 0 && !(st->reserved & 4) && st->ws_sync && ((B + lat::kGroups - 1) / lat::kGroups) * V <= 3 && latency_path_ok())
+    if (mode == 0 && !(st->reserved & 4) && st->ws_sync && ((B + lat::kGroups - 1) / lat::kGroups) * V <= 4 && latency_path_ok())
         mode = 3;
     if (mode == 3) {
         // small-batch path: one persistent kernel, output features split over the CUs of an XCD
