@@ -1,6 +1,6 @@
 """Training-step timing (not the contract bench): B clips per GPU, fwd+bwd+Adam, 1 GPU."""
 import sys, time, torch, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from syntalker_amd import synth, training
 from syntalker_amd.denoiser import MDM
 from syntalker_amd.process import create_gaussian_diffusion

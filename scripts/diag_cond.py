@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from syntalker_amd import synth
 from syntalker_amd.denoiser import MDM
 from tests.refmodel import synth_state_dict

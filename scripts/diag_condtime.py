@@ -1,5 +1,5 @@
 import sys, time, torch, torch.nn.functional as F
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from syntalker_amd import synth, conditioning
 from tests.refmodel import synth_state_dict
 sd = {k: v.cuda() for k, v in synth_state_dict('beatx').items()}

@@ -1,5 +1,5 @@
 import sys, ctypes as C, torch, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from syntalker_amd import _lib, engine, synth
 from syntalker_amd.denoiser import MDM
 from syntalker_amd.process import create_gaussian_diffusion

@@ -1,6 +1,6 @@
 """Micro-benchmark of the GEMM main loop with ablations (diagnostics)."""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from syntalker_amd import _lib, engine
 lib = _lib.load()
 def run(M, N, K, mt, abl, reps=20):
