@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--m-tile", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the B = 1 / 8 / 32 probe (clean per-kernel profiles)")
     ap.add_argument("--layer-mode", type=int, default=0, help="0 library's choice (whole-step kernel at the bench batch), 4 / 3 pin the whole-step / small-batch kernel, "
                          "2 two kernels/block, 1 five kernels/block (A/B)")
     args = ap.parse_args()
@@ -281,13 +282,14 @@ def main():
                             f"{cond_ms_per_clip / (dt / K * 1e3 / B):.0f} denoising steps' worth",
             "roofline": roofline,
         }
-        if args.layer_mode == 0:
+        if args.layer_mode == 0 and not args.no_small_batch:
             out["small_batch"] = small_batch_probe(pm, coef, dev)
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()                 # ranks leave together (rank 0 may still have been timing the CPU baseline)
         dist.destroy_process_group()
 
 

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_final_* and gpurun_out/pmc_* (scripts/prof_round.sh) into the committed summaries under
+profiles/ (kernel-stats tables, PMC tables, pmc_traffic.json read by bench.py).  Usage: scripts/collect_profiles.py rNN"""
+import json, os, subprocess, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rd = lambda p: open(os.path.join(R, p)).read().strip()
+def val(part, kernel, col):
+    lines = rd(f"gpurun_out/pmc_{part}/summary.txt").splitlines()
+    names = lines[0].split(",")
+    for l in lines[1:]:
+        f = l.split(",")
+        if kernel in f[0]:
+            return float(f[names.index(col)])
+    raise KeyError((part, kernel, col))
+notes = {"b1024": "bench.py --steps 30 --warmup 5 --no-small-batch, B = 1024 clips: whole-step kernel k_stack<64>",
+         "b8": "bench.py --batch 8 --steps 300 --warmup 20 --no-small-batch: persistent small-batch kernel k_lat, one clip per XCD"}
+for b, note in notes.items():
+    subprocess.run([sys.executable, os.path.join(R, "scripts/summarize_stats.py"), os.path.join(R, f"gpurun_out/prof_final_{b}/kernel_stats.csv"),
+                    os.path.join(R, f"profiles/{tag}_final_kernel_stats_{b}.txt"), f"{tag} final: {note}"], check=True)
+    open(os.path.join(R, f"profiles/{tag}_final_bench_{b}.json"), "w").write(rd(f"gpurun_out/prof_final_{b}/bench.json") + "\n")
+    with open(os.path.join(R, f"profiles/{tag}_final_pmc_{b}.txt"), "w") as f:
+        f.write(f"# {tag} final PMC (per-dispatch averages), separate rocprofv3 --kernel-trace --pmc passes (scripts/prof_round.sh); {note.split(':')[0]} (fewer steps)\n")
+        for part in ("sq", "fetch", "write"):
+            f.write(rd(f"gpurun_out/pmc_{b}_{part}/summary.txt") + "\n")
+        f.write("# FETCH_SIZE / WRITE_SIZE in KiB as reported; gfx950 FETCH_SIZE under-reports wide streaming reads by 2x (MI355X_MICROARCH.md, HBM section): "
+                "corrected bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024.\n"
+                "# SQ_WAVE_CYCLES / SQ_WAIT* / SQ_ACTIVE* in quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over 1024 SIMDs (= 16 x number of 16x16x32 bf16 MFMAs); "
+                "GRBM_GUI_ACTIVE summed over the 8 XCDs.\n")
+traffic = lambda b, k: int((2 * val(f"{b}_fetch", k, "FETCH_SIZE") + val(f"{b}_write", k, "WRITE_SIZE")) * 1024)
+json.dump({"batch": 1024, "layer_mode": 0, "source": f"profiles/{tag}_final_pmc_b1024.txt",
+           "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 (gfx950 FETCH_SIZE correction); fabric-side traffic, "
+                   "includes weight re-reads served by the Infinity Cache",
+           "hbm_bytes_per_launch": {"k_stack<MT>": traffic("b1024", "k_stack")},
+           "small_batch": {"batch": 8, "source": f"profiles/{tag}_final_pmc_b8.txt", "k_lat": traffic("b8", "k_lat"),
+                           "note": "each of the 8 XCD L2s pulls the 38 MB weight set once per step (304 MB) + activations"}},
+          open(os.path.join(R, "profiles/pmc_traffic.json"), "w"), indent=1)
+print(open(os.path.join(R, "profiles/pmc_traffic.json")).read())
