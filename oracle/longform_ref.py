@@ -1,0 +1,31 @@
+"""Oracle (test infrastructure only) for the chunked long-sequence loop: CPU restatement of
+diffusion_rvqvae_trainer.py:413-476 on top of oracle.process_ref / oracle.denoiser_ref.
+Pinned like the rest of the oracle: the per-window sampler is the one checked against the reference goldens;
+the window arithmetic (slices, seeding, concatenation) is restated line by line below."""
+import torch
+
+from .process_ref import RefProcess
+
+
+def sample_long_ref(model_fn, audio, word, seed_latent, n_pose, x_T, step_noise, use_ddim=False, skip_timesteps=0,
+                    pose_length=128, pre_frames=4, squeeze=4, style_dim=512):
+    """x_T: list of (B,1536,1,32) per window; step_noise: list of per-step noise tensors per window."""
+    overlap = pre_frames * squeeze
+    round_l = pose_length - overlap                                     # :416
+    roundt = (n_pose - overlap) // round_l                              # :414
+    proc = RefProcess(use_ddim)
+    loop = proc.ddim_sample_loop if use_ddim else proc.p_sample_loop
+    bs = word.shape[0]
+    out, last = [], None
+    for i in range(roundt):                                              # :419
+        w = word[:, i * round_l:(i + 1) * round_l + overlap]            # :420
+        a = audio[:, i * (16000 // 30 * round_l):(i + 1) * (16000 // 30 * round_l) + 16000 // 30 * overlap]   # :422
+        s = seed_latent[:, i * round_l // squeeze:(i + 1) * round_l // squeeze + pre_frames]                    # :424
+        s = s[:, :pre_frames] if i == 0 else last[:, -pre_frames:]       # :428-431
+        y = {"audio": a, "word": w, "seed": s, "mask": torch.ones(bs, 1, 1, pose_length, dtype=torch.bool),
+             "style_feature": torch.zeros(bs, style_dim)}                # :433-442
+        sample = loop(model_fn, (bs, 1536, 1, pose_length // squeeze), y, noise=x_T[i], step_noise=step_noise[i],
+                      skip_timesteps=skip_timesteps)
+        last = sample[:, :, 0, :].permute(0, 2, 1)                       # :458 (batched form of squeeze().permute(1,0))
+        out.append(last if i == 0 else last[:, pre_frames:])             # :468-476
+    return torch.cat(out, dim=1)

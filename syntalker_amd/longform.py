@@ -1,0 +1,69 @@
+"""Chunked long-sequence sampling: the window loop of the reference's `_g_test`
+(diffusion_rvqvae_trainer.py:413-531, same arithmetic in h3d_diffusion_new_trainer.py:514-640).
+
+A long take of n pose frames is generated window by window: windows are `pose_length` = 128 pose frames
+(32 latent frames), consecutive windows overlap by `pre_frames` latent frames (4; `pre_frames * vqvae_squeeze_scale`
+= 16 pose frames), and window i > 0 is *seeded* with the last `pre_frames` latent frames the previous window
+produced - a serial dependency, which is why the reference samples with batch size 1 and why the small-batch step
+kernel exists.  Several independent takes can be advanced together (batch dimension).
+
+Only the diffusion part is here (latents in, latents out): RVQ-VAE decoding and SMPL-X post-processing of the
+reference (`latent2origin`, rotation conversions) are outside the hot path.
+"""
+from __future__ import annotations
+
+import torch
+
+AUDIO_PER_POSE = 16000 // 30          # audio samples per pose frame (diffusion_rvqvae_trainer.py:422)
+
+
+def window_plan(n_pose: int, pose_length: int = 128, pre_frames: int = 4, squeeze: int = 4):
+    """(round_l, rounds, remain) exactly as diffusion_rvqvae_trainer.py:414-416."""
+    overlap = pre_frames * squeeze
+    round_l = pose_length - overlap
+    rounds = (n_pose - overlap) // round_l
+    remain = (n_pose - overlap) % round_l
+    return round_l, rounds, remain
+
+
+def window_inputs(i: int, audio, word, seed_latent, last_sample, round_l: int, pre_frames: int = 4, squeeze: int = 4,
+                  style_dim: int = 512):
+    """model_kwargs['y'] of window i (trainer lines 419-442).  audio (B, n*533[, 2]), word (B, n) int64,
+    seed_latent (B, n/squeeze, 1536) ground-truth latents (only its first pre_frames rows are ever used),
+    last_sample (B, 32, 1536) previous window's output or None."""
+    bs = word.shape[0]
+    lo, hi = i * round_l, (i + 1) * round_l + pre_frames * squeeze
+    y = {
+        "audio": audio[:, lo * AUDIO_PER_POSE:hi * AUDIO_PER_POSE],
+        "word": word[:, lo:hi],
+        "seed": seed_latent[:, :pre_frames] if i == 0 else last_sample[:, -pre_frames:],
+        "mask": torch.ones(bs, 1, 1, hi - lo, dtype=torch.bool, device=word.device),
+        "style_feature": torch.zeros(bs, style_dim, device=word.device),
+    }
+    return y
+
+
+def sample_long(diffusion, model, audio, word, seed_latent, n_pose: int | None = None, *, pose_length: int = 128,
+                pre_frames: int = 4, squeeze: int = 4, use_ddim: bool = False, style_dim: int = 512, noise_fn=None,
+                step_noise_fn=None, seed: int | None = None, skip_timesteps: int = 0, progress: bool = False):
+    """Returns latents (B, rounds*round_l/squeeze + pre_frames, 1536): window 0 whole, later windows without their
+    first pre_frames rows (trainer lines 468-476).
+    noise_fn(i) -> x_T of window i or None (library draws it); step_noise_fn(i) -> injected per-step noise or None;
+    seed: base key of the library's counter-based generator (window i uses seed + i)."""
+    n_pose = word.shape[1] if n_pose is None else n_pose
+    round_l, rounds, _ = window_plan(n_pose, pose_length, pre_frames, squeeze)
+    bs = word.shape[0]
+    loop = diffusion.ddim_sample_loop if use_ddim else diffusion.p_sample_loop
+    pieces, last = [], None
+    for i in range(rounds):
+        y = window_inputs(i, audio, word, seed_latent, last, round_l, pre_frames, squeeze, style_dim)
+        kw = {}
+        if step_noise_fn is not None:
+            kw["step_noise"] = step_noise_fn(i)
+        if seed is not None:
+            kw["seed"] = seed + i
+        sample = loop(model, (bs, 1536, 1, pose_length // squeeze), noise=None if noise_fn is None else noise_fn(i),
+                      clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=skip_timesteps, progress=progress, **kw)
+        last = sample[:, :, 0, :].permute(0, 2, 1).contiguous()          # (B, 32, 1536): trainer's squeeze/permute, batched
+        pieces.append(last if i == 0 else last[:, pre_frames:])
+    return torch.cat(pieces, dim=1)

@@ -1,0 +1,96 @@
+"""Chunked long-sequence driver: window arithmetic on CPU, end-to-end parity on the GPU."""
+import pytest
+import torch
+
+from syntalker_amd import longform, synth
+
+
+def test_window_plan_matches_reference_arithmetic():
+    # diffusion_rvqvae_trainer.py:414-416 with pose_length 128, pre_frames 4, vqvae_squeeze_scale 4
+    assert longform.window_plan(128) == (112, 1, 0)
+    assert longform.window_plan(128 + 112 * 3 + 5) == (112, 4, 5)
+    assert longform.window_plan(127) == (112, 0, 111)
+    round_l, rounds, _ = longform.window_plan(464)
+    assert rounds * round_l + 16 == 464                        # windows tile the take with 16-pose-frame overlaps
+
+
+def test_window_inputs_slices_and_seeding():
+    n = 128 + 112
+    audio = torch.arange(n * longform.AUDIO_PER_POSE).float().view(1, -1)
+    word = torch.arange(n).view(1, -1)
+    seed = torch.randn(1, n // 4, 1536)
+    last = torch.randn(1, 32, 1536)
+    y0 = longform.window_inputs(0, audio, word, seed, None, 112)
+    y1 = longform.window_inputs(1, audio, word, seed, last, 112)
+    assert y0["word"].shape == (1, 128) and y1["word"][0, 0] == 112 and y1["word"][0, -1] == n - 1
+    assert y0["audio"].shape == (1, 128 * 533) and y1["audio"][0, 0] == 112 * 533
+    assert torch.equal(y0["seed"], seed[:, :4]) and torch.equal(y1["seed"], last[:, -4:])
+    assert y0["mask"].shape == (1, 1, 1, 128) and y0["style_feature"].shape == (1, 512)
+
+
+class _Toy(torch.nn.Module):
+    """x0-predictor whose output depends on the seed rows: the generic (non-HIP) path of the loops, on CPU."""
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor(0.5))
+
+    def forward(self, x, t, y=None):
+        return self.w * x + y["seed"].mean() + 1e-3 * y["word"].float().mean()
+
+
+def test_sample_long_cpu_generic_path_equals_manual_loop():
+    from syntalker_amd.process import create_gaussian_diffusion
+    d = create_gaussian_diffusion()
+    n = 128 + 2 * 112
+    g = torch.Generator().manual_seed(0)
+    audio, word = torch.randn(2, n * 533, generator=g), torch.randint(0, 100, (2, n), generator=g)
+    seed = torch.randn(2, n // 4, 1536, generator=g)
+    xs = [torch.randn(2, 1536, 1, 32, generator=g) for _ in range(3)]
+    sn = [torch.randn(3, 2, 1536, 1, 32, generator=g) for _ in range(3)]
+    m = _Toy()
+    got = longform.sample_long(d, m, audio, word, seed, n, noise_fn=lambda i: xs[i].clone(), step_noise_fn=lambda i: sn[i],
+                               skip_timesteps=997)
+    assert got.shape == (2, 3 * 28 + 4, 1536)
+    last, pieces = None, []
+    for i in range(3):
+        y = longform.window_inputs(i, audio, word, seed, last, 112)
+        s = d.p_sample_loop(m, (2, 1536, 1, 32), noise=xs[i].clone(), clip_denoised=False, model_kwargs={"y": y},
+                            skip_timesteps=997, step_noise=sn[i])
+        last = s[:, :, 0].permute(0, 2, 1).contiguous()
+        pieces.append(last if i == 0 else last[:, 4:])
+    assert torch.equal(got, torch.cat(pieces, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_ddim", [False, True])
+def test_sample_long_vs_oracle(use_ddim):
+    """3 windows, batch of 2 takes, a short schedule tail (DDPM: last 6 steps; DDIM-50: last 6 of 50), injected noise:
+    HIP loop (small-batch kernel, seeded window to window) against the CPU oracle of the same loop."""
+    from oracle import denoiser_ref as dr
+    from oracle.longform_ref import sample_long_ref
+    from syntalker_amd.denoiser import MDM
+    from syntalker_amd.process import create_gaussian_diffusion
+    from tests.conftest import rel_l2
+    from tests.refmodel import synth_state_dict
+    dev = "cuda"
+    m = MDM(synth.default_args()).eval()
+    m.load_state_dict(synth_state_dict("beatx"), strict=False)
+    m = m.to(dev)
+    sd = synth_state_dict("beatx")
+    n, B, W = 128 + 2 * 112, 2, 3
+    g = torch.Generator().manual_seed(5)
+    audio = torch.randn(B, n * 533, 2, generator=g)
+    word = torch.randint(0, synth.VOCAB, (B, n), generator=g)
+    seed = torch.randn(B, n // 4, 1536, generator=g)
+    steps, skip = (6, 44) if use_ddim else (6, 994)
+    xs = [torch.randn(B, 1536, 1, 32, generator=g) for _ in range(W)]
+    sn = [torch.randn(steps, B, 1536, 1, 32, generator=g) for _ in range(W)]
+    d = create_gaussian_diffusion(use_ddim=use_ddim)
+    got = longform.sample_long(d, m, audio.to(dev), word.to(dev), seed.to(dev), n, use_ddim=use_ddim,
+                               noise_fn=lambda i: xs[i].to(dev), step_noise_fn=lambda i: sn[i], skip_timesteps=skip).cpu()
+    want = sample_long_ref(lambda a, b, c: dr.mdm_forward(sd, a, b, c), audio, word, seed, n, xs, sn, use_ddim=use_ddim,
+                           skip_timesteps=skip)
+    assert got.shape == want.shape == (B, W * 28 + 4, 1536)
+    e = rel_l2(got, want)
+    print(f"long-form ({'ddim' if use_ddim else 'ddpm'}) rel-L2 vs oracle: {e:.3e}")
+    assert e < 3e-2
