@@ -110,6 +110,28 @@ int syn_denoise_step(const syn_model* model, const syn_step* step, void* stream)
  * 4 fc1 GEMM, 5 fc2 GEMM, 6 guidance combine, 7 output GEMM}.  Synchronises `stream`; not graph-capturable. */
 int syn_denoise_step_profile(const syn_model* model, const syn_step* step, void* stream, float* ms_out, int32_t* count_out);
 
+/* ---- per-clip conditioning: audio encoder -------------------------------------
+ * WavEncoder.forward in eval mode (models/denoiser.py:304-322; BasicBlock models/utils/layer.py:144-184) with the
+ * BatchNorms folded into the convolutions by the caller.  wav [n_clips][n_samples][cin] fp32 ->
+ * out [n_clips][syn_wav_out_frames(n_samples)][256] fp32 (128 frames for the 68224 / 68266-sample clips).
+ * conv[i]: fragment-packed (syn_pack_weight) bf16 weights W'[cout][tap][cin'] and fp32 bias of, in order:
+ *   b0.conv2, b1.conv1|shortcut, b1.conv2, b2.conv1, b2.conv2, b3.conv1|shortcut, b3.conv2, b4.conv1, b4.conv2,
+ *   b5.conv1|shortcut, b5.conv2  ("conv1|shortcut": output channels concatenated; strided convs as stride-1 convs
+ *   over s-row groups: taps ceil(15/s), cin' = s*cin, taps >= 15 zero - syntalker_amd/conditioning.py builds them).
+ * w_first: block 0's conv1 and shortcut, fp32 [2][15*cin][64] (tap-major) followed by the biases [2][64].
+ * workspace: syn_wav_workspace_bytes() bytes, zeroed ONCE by the caller for a given (n_clips, n_samples). */
+typedef struct syn_wav_conv { const void* w; const float* bias; } syn_wav_conv;
+typedef struct syn_wavenc {
+    int32_t cin;            /* waveform channels: 1 or 2 */
+    int32_t reserved;
+    const float* w_first;
+    syn_wav_conv conv[11];
+} syn_wavenc;
+int32_t syn_wav_out_frames(int32_t n_samples);
+int64_t syn_wav_workspace_bytes(int32_t n_clips, int32_t n_samples);
+int syn_wav_encode(const syn_wavenc* enc, const float* wav, int32_t n_clips, int32_t n_samples, void* workspace, float* out,
+                   void* stream);
+
 /* ---- load-time helpers -------------------------------------------------------------------- */
 /* fp32 row-major W[n][k] (nn.Linear.weight layout) -> packed bf16 fragments (n*k*2 bytes).
  * n % 16 == 0, k % 32 == 0. */

@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get("SYN_HIP_LIB") or os.path.join(_HERE, "csrc", "libsyn_
 
 SYN_LAYERS = 8
 EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_step_profile", "syn_pack_weight", "syn_to_token_major",
-           "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_test_gemm", "syn_test_attention")
+           "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_test_gemm", "syn_test_attention",
+           "syn_wav_encode", "syn_wav_workspace_bytes", "syn_wav_out_frames")
 
 vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
 
@@ -36,6 +37,14 @@ class SynStep(C.Structure):
                 ("x_next", vp), ("x_next_bf16", vp), ("pred_x0", vp),
                 ("ws_h", vp), ("ws_xn", vp), ("ws_q", vp), ("ws_k", vp), ("ws_vt", vp), ("ws_o", vp),
                 ("ws_hid", vp), ("ws_hc", vp), ("ws_sync", vp)]
+
+
+class SynWavConv(C.Structure):
+    _fields_ = [("w", vp), ("bias", vp)]
+
+
+class SynWavEnc(C.Structure):
+    _fields_ = [("cin", i32), ("reserved", i32), ("w_first", vp), ("conv", SynWavConv * 11)]
 
 
 class SynHipError(RuntimeError):
@@ -67,10 +76,14 @@ def load():
     lib.syn_linear.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     lib.syn_test_gemm.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.syn_test_attention.argtypes = [vp, vp, vp, i32, vp, vp]
+    lib.syn_wav_encode.argtypes = [C.POINTER(SynWavEnc), vp, i32, i32, vp, vp, vp]
+    lib.syn_wav_workspace_bytes.argtypes = [i32, i32]
+    lib.syn_wav_out_frames.argtypes = [i32]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("syn_version", "syn_last_error"):
+        if name not in ("syn_version", "syn_last_error", "syn_wav_workspace_bytes"):
             fn.restype = C.c_int
+    lib.syn_wav_workspace_bytes.restype = C.c_int64
     _lib = lib
     return lib
 

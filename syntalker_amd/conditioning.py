@@ -59,6 +59,70 @@ def wav_features(blocks, wav):
     return x.transpose(1, 2)
 
 
+def wav_gemm_weight(w, stride: int):
+    """BN-folded Conv1d weight (cout, cin, 15) -> the GEMM matrix W'[cout][tap][cin'] of the HIP encoder
+    (syn_wavenc.inc): K index = tap*cin + ci; a stride-s conv is a stride-1 conv over s-row groups, i.e. the same
+    flattening with the taps zero-padded to ceil(15/s)*s."""
+    cout, cin, k = w.shape
+    kt = -(-k // stride)
+    wp = w.new_zeros(cout, kt * stride, cin)
+    wp[:, :k] = w.permute(0, 2, 1)
+    return wp.reshape(cout, kt * stride * cin).contiguous()
+
+
+class HipWavEncoder:
+    """WavEncoder.forward (eval mode) on the hand-written conv kernels through the C ABI (`syn_wav_encode`)."""
+
+    CHUNK = 64                          # clips per call: bounds the workspace (7.5 MB per clip at 68 k samples)
+
+    def __init__(self, blocks, device):
+        from . import _lib, engine
+        self._lib, self.device = _lib, device
+        dev = lambda t: t.detach().float().to(device).contiguous()
+        keep = []
+        c1, sc = blocks[0]["c1"], blocks[0]["sc"]
+        self.cin = c1[0].shape[1]
+        first = torch.cat([torch.stack([dev(c1[0]).permute(2, 1, 0).reshape(-1, 64), dev(sc[0]).permute(2, 1, 0).reshape(-1, 64)]).reshape(-1),
+                           dev(c1[1]), dev(sc[1])]).contiguous()
+        keep.append(first)
+        convs = [(blocks[0]["c2"], 1)]
+        for i in range(1, 6):
+            b = blocks[i]
+            if b["sc"] is not None:
+                convs.append(((torch.cat([b["c1"][0], b["sc"][0]], 0), torch.cat([b["c1"][1], b["sc"][1]], 0)), b["stride"]))
+            else:
+                convs.append((b["c1"], 1))
+            convs.append((b["c2"], 1))
+        assert len(convs) == 11
+        self.c = _lib.SynWavEnc()
+        self.c.cin, self.c.w_first = self.cin, first.data_ptr()
+        for i, ((w, b), stride) in enumerate(convs):
+            wp = engine.pack_weight(wav_gemm_weight(dev(w), stride))
+            bb = dev(b)
+            keep += [wp, bb]
+            self.c.conv[i].w, self.c.conv[i].bias = wp.data_ptr(), bb.data_ptr()
+        self._keep, self._ws = keep, {}
+
+    def __call__(self, wav):
+        """wav (B, L[, cin]) fp32 on the GPU -> (B, frames, 256) fp32."""
+        _lib, C = self._lib, __import__("ctypes")
+        lib = _lib.load()
+        wav = wav.detach().float().contiguous()
+        B, L = wav.shape[0], wav.shape[1]
+        if (wav.shape[2] if wav.dim() == 3 else 1) != self.cin:
+            raise _lib.SynHipError(f"waveform has {wav.shape[2:]} channels, the encoder was built for {self.cin}")
+        frames = lib.syn_wav_out_frames(L)
+        out = torch.empty(B, frames, 256, dtype=torch.float32, device=wav.device)
+        for b0 in range(0, B, self.CHUNK):
+            n = min(self.CHUNK, B - b0)
+            key = (n, L)
+            if key not in self._ws:         # zeroed once: the halo / tail rows the kernels rely on are never written
+                self._ws[key] = torch.zeros(lib.syn_wav_workspace_bytes(n, L), dtype=torch.uint8, device=wav.device)
+            _lib.check(lib.syn_wav_encode(C.byref(self.c), wav[b0:b0 + n].data_ptr(), n, L, self._ws[key].data_ptr(),
+                                          out[b0:b0 + n].data_ptr(), _lib.current_stream()), "syn_wav_encode")
+        return out
+
+
 def fold_input_stage(sd, with_style: bool):
     """Fold poseEmbedding -> input_process2 [-> input_process3] (all affine, no nonlinearity between)."""
     W2, b2 = sd["input_process2.weight"].double(), sd["input_process2.bias"].double()
@@ -93,6 +157,7 @@ class ClipConditioner:
     def __init__(self, sd, folded, variant: str, use_style: bool, pool: int = 4):
         self.sd, self.fw, self.variant, self.use_style, self.pool = sd, folded, variant, use_style, pool
         self.wav_blocks = fold_wav_encoder(sd)
+        self._hip_wav = None
         self.W2c_f = folded["W2c"].float()
         self.W2a_f = folded["W2a"].float()
         self.W3s_f = folded["W3s"].float() if folded["W3s"] is not None else None
@@ -101,7 +166,12 @@ class ClipConditioner:
     def frame_term(self, audio, word):
         """(B, 32, 512): pool(mix([wav | word])) W2c^T."""
         sd = self.sd
-        a = wav_features(self.wav_blocks, audio)
+        if audio.is_cuda:               # the HIP encoder (SURVEY 8 f1); CPU tensors only occur in host-logic tests
+            if self._hip_wav is None:
+                self._hip_wav = HipWavEncoder(self.wav_blocks, audio.device)
+            a = self._hip_wav(audio)
+        else:
+            a = wav_features(self.wav_blocks, audio)
         w = F.linear(F.embedding(word, sd["text_pre_encoder_body.weight"]),
                      sd["text_encoder_body.weight"], sd["text_encoder_body.bias"])
         at = F.linear(torch.cat([a, w], dim=2), sd["mix_audio_text.weight"], sd["mix_audio_text.bias"])

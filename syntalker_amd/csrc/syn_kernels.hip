@@ -1343,6 +1343,42 @@ int launch_stack(const SArgs& a, int mt, hipStream_t s) {
 }
 
 #include "syn_latency.inc"
+#include "syn_wavenc.inc"
+
+// ---- WavEncoder forward: lengths, workspace layout and the 12 launches ----------------------------------------
+struct WavPlan {
+    int L1, L2, L3, L4;                 // positions after blocks 0, 1(=2), 3(=4), 5
+    long z0, s0, x1, z1, s1, x2, z2, x3, z3, s3, x4, z4, x5, z5, s5, per_clip;   // element (bf16) offsets inside a clip's workspace
+};
+constexpr int kHalo = 7, kSlack = 16;   // zero rows in front of / behind padded tensors; zero tail rows of the grouped ones
+WavPlan wav_plan(int L) {
+    WavPlan p;
+    p.L1 = (L + 2 * 1700 - 15) / 5 + 1;
+    p.L2 = (p.L1 - 15) / 6 + 1;
+    p.L3 = (p.L2 - 15) / 6 + 1;
+    p.L4 = (p.L3 - 15) / 3 + 1;
+    long o = 0;
+    auto take = [&](long rows, int ch) { const long at = o; o += rows * ch; o = (o + 63) & ~63L; return at; };
+    const long h1 = p.L1 + 2 * kHalo + kSlack, h2 = p.L2 + 2 * kHalo + kSlack, h3 = p.L3 + 2 * kHalo + kSlack, h4 = p.L4 + 2 * kHalo + kSlack;
+    p.z0 = take(h1, 64);  p.s0 = take(p.L1, 64);  p.x1 = take(p.L1 + kSlack, 64);
+    p.z1 = take(h2, 64);  p.s1 = take(p.L2, 64);  p.x2 = take(h2, 64);
+    p.z2 = take(h2, 64);  p.x3 = take(p.L2 + kSlack, 64);
+    p.z3 = take(h3, 128); p.s3 = take(p.L3, 128); p.x4 = take(h3, 128);
+    p.z4 = take(h3, 128); p.x5 = take(p.L3 + kSlack, 128);
+    p.z5 = take(h4, 256); p.s5 = take(p.L4, 256);
+    p.per_clip = o;
+    return p;
+}
+
+template <int CINP, int KT, int WN, int WM, int RF, int EPI>
+int launch_conv(const wav::CArgs& a, int n_clips, hipStream_t s) {
+    constexpr int MW = WM * RF * 16, lds = (MW + KT - 1) * (CINP * 2 + 16);
+    static bool once = false;
+    if (!once) { allow_lds(wav::k_conv<CINP, KT, WN, WM, RF, EPI>, lds); once = true; }
+    hipLaunchKernelGGL((wav::k_conv<CINP, KT, WN, WM, RF, EPI>), dim3((a.L_out + MW - 1) / MW, n_clips), dim3(kThreads), lds, s, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv launch", e);
+}
 
 int launch_latency(const lat::LArgs& a, hipStream_t s) {
     static bool once = false;
@@ -1453,6 +1489,70 @@ int syn_test_attention(const void* q, const void* k, const void* vt, int32_t n_s
                        (const __bf16*)vt, (__bf16*)o, n_seq);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_attn launch", e);
+}
+
+int32_t syn_wav_out_frames(int32_t n_samples) { return n_samples >= 15 ? wav_plan(n_samples).L4 : 0; }
+
+int64_t syn_wav_workspace_bytes(int32_t n_clips, int32_t n_samples) {
+    if (n_clips <= 0 || n_samples < 15) return 0;
+    return (int64_t)wav_plan(n_samples).per_clip * n_clips * 2;
+}
+
+int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, int32_t n_samples, void* workspace, float* out,
+                   void* stream) {
+    if (!enc || !wav_in || !workspace || !out || n_clips <= 0) return fail_msg("syn_wav_encode: null argument");
+    if (enc->cin != 1 && enc->cin != 2) return fail_msg("syn_wav_encode: 1 or 2 input channels");
+    const WavPlan p = wav_plan(n_samples);
+    if (p.L4 <= 0) return fail_msg("syn_wav_encode: clip too short");
+    hipStream_t s = (hipStream_t)stream;
+    __bf16* const ws = (__bf16*)workspace;
+    const long cs = p.per_clip;
+    int rc;
+    {   // block 0: conv1 + shortcut from the waveform
+        wav::FArgs f;
+        f.wav = wav_in; f.wav_clip_stride = (long)n_samples * enc->cin; f.L = n_samples; f.cin = enc->cin; f.L_out = p.L1;
+        f.w = enc->w_first;
+        f.Z = ws + p.z0; f.z_clip_stride = cs; f.z_off = kHalo * 64; f.S = ws + p.s0; f.s_clip_stride = cs;
+        hipLaunchKernelGGL(wav::k_first, dim3((p.L1 + 63) / 64, n_clips), dim3(256), 0, s, f);
+    }
+    auto base = [&](int i) {
+        wav::CArgs a;
+        memset(&a, 0, sizeof(a));
+        a.W = (const uint4*)enc->conv[i].w; a.bias = enc->conv[i].bias;
+        a.x_clip_stride = a.z_clip_stride = a.s_clip_stride = a.r_clip_stride = cs;
+        return a;
+    };
+    wav::CArgs a;
+    // block 0 conv2 (+ shortcut) -> x1
+    a = base(0); a.X = ws + p.z0; a.x_rows = p.L1 + 2 * kHalo; a.L_out = p.L1; a.Z = ws + p.x1; a.R = ws + p.s0;
+    if ((rc = launch_conv<64, 15, 1, 8, 4, wav::E_C2>(a, n_clips, s))) return rc;
+    // block 1: conv1 | shortcut (stride 6 = 3 taps over 6-row groups), conv2 -> x2 (halo: block 2 pads by 7)
+    a = base(1); a.X = ws + p.x1; a.x_rows = (p.L1 + 5) / 6; a.L_out = p.L2; a.Z = ws + p.z1; a.z_off = kHalo * 64; a.S = ws + p.s1;
+    if ((rc = launch_conv<384, 3, 2, 4, 2, wav::E_C1SC>(a, n_clips, s))) return rc;
+    a = base(2); a.X = ws + p.z1; a.x_rows = p.L2 + 2 * kHalo; a.L_out = p.L2; a.Z = ws + p.x2; a.z_off = kHalo * 64; a.R = ws + p.s1;
+    if ((rc = launch_conv<64, 15, 1, 8, 4, wav::E_C2>(a, n_clips, s))) return rc;
+    // block 2 (identity shortcut): conv1, conv2 + x2 -> x3
+    a = base(3); a.X = ws + p.x2; a.x_rows = p.L2 + 2 * kHalo; a.L_out = p.L2; a.Z = ws + p.z2; a.z_off = kHalo * 64;
+    if ((rc = launch_conv<64, 15, 1, 8, 4, wav::E_C1>(a, n_clips, s))) return rc;
+    a = base(4); a.X = ws + p.z2; a.x_rows = p.L2 + 2 * kHalo; a.L_out = p.L2; a.Z = ws + p.x3; a.R = ws + p.x2; a.r_off = kHalo * 64;
+    if ((rc = launch_conv<64, 15, 1, 8, 4, wav::E_C2>(a, n_clips, s))) return rc;
+    // block 3: 64 -> 128, stride 6
+    a = base(5); a.X = ws + p.x3; a.x_rows = (p.L2 + 5) / 6; a.L_out = p.L3; a.Z = ws + p.z3; a.z_off = kHalo * 128; a.S = ws + p.s3;
+    if ((rc = launch_conv<384, 3, 4, 2, 4, wav::E_C1SC>(a, n_clips, s))) return rc;
+    a = base(6); a.X = ws + p.z3; a.x_rows = p.L3 + 2 * kHalo; a.L_out = p.L3; a.Z = ws + p.x4; a.z_off = kHalo * 128; a.R = ws + p.s3;
+    if ((rc = launch_conv<128, 15, 2, 4, 4, wav::E_C2>(a, n_clips, s))) return rc;
+    // block 4 (identity shortcut)
+    a = base(7); a.X = ws + p.x4; a.x_rows = p.L3 + 2 * kHalo; a.L_out = p.L3; a.Z = ws + p.z4; a.z_off = kHalo * 128;
+    if ((rc = launch_conv<128, 15, 2, 4, 4, wav::E_C1>(a, n_clips, s))) return rc;
+    a = base(8); a.X = ws + p.z4; a.x_rows = p.L3 + 2 * kHalo; a.L_out = p.L3; a.Z = ws + p.x5; a.R = ws + p.x4; a.r_off = kHalo * 128;
+    if ((rc = launch_conv<128, 15, 2, 4, 4, wav::E_C2>(a, n_clips, s))) return rc;
+    // block 5: 128 -> 256, stride 3 (5 taps over 3-row groups); conv2 writes the fp32 result
+    a = base(9); a.X = ws + p.x5; a.x_rows = (p.L3 + 2) / 3; a.L_out = p.L4; a.Z = ws + p.z5; a.z_off = kHalo * 256; a.S = ws + p.s5;
+    if ((rc = launch_conv<384, 5, 8, 1, 4, wav::E_C1SC>(a, n_clips, s))) return rc;
+    a = base(10); a.X = ws + p.z5; a.x_rows = p.L4 + 2 * kHalo; a.L_out = p.L4; a.R = ws + p.s5; a.Yf = out; a.yf_clip_stride = (long)p.L4 * 256;
+    if ((rc = launch_conv<256, 15, 4, 2, 4, wav::E_C2>(a, n_clips, s))) return rc;
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_wav_encode", e);
 }
 
 // Stage classes reported by syn_denoise_step_profile (index into ms[] / count[]).

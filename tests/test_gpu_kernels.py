@@ -94,3 +94,25 @@ def test_randn_is_standard_normal_and_shard_invariant(lib):
     c = torch.empty(n, device="cuda")
     lib.check(lib.load().syn_randn(c.data_ptr(), n, 1234, 8, 0, lib.current_stream()), "randn")
     assert abs(float((a * c).mean())) < 5e-3                 # different step -> independent
+
+
+@pytest.mark.parametrize("B,L", [(3, 68224), (2, 68266), (1, 20000)])
+def test_wav_encoder_vs_torch(B, L):
+    """the HIP WavEncoder (channels-last bf16 implicit-GEMM convs, BN folded) against the fp32 PyTorch
+    convolutions of the same folded weights on the CPU (models/denoiser.py:304-322).  bf16 activations through
+    12 convolutions: rel-L2 <= 2e-2 (same budget as one denoiser evaluation)."""
+    from syntalker_amd import conditioning, synth
+    from tests.refmodel import synth_state_dict
+    from tests.conftest import rel_l2
+    sd = synth_state_dict("beatx")
+    blocks = conditioning.fold_wav_encoder(sd)
+    g = torch.Generator().manual_seed(L)
+    wav = torch.randn(B, L, 2, generator=g)
+    want = conditioning.wav_features(blocks, wav)
+    enc = conditioning.HipWavEncoder(blocks, torch.device("cuda"))
+    got = enc(wav.to("cuda")).cpu()
+    assert got.shape == want.shape
+    e = rel_l2(got, want)
+    print(f"wav encoder B={B} L={L}: out {tuple(got.shape)} rel-L2 {e:.3e}")
+    assert e < 2e-2
+    assert torch.equal(enc(wav.to("cuda")).cpu(), got)          # deterministic, workspace halos intact on reuse

@@ -192,7 +192,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     """Every function declared in include/syn_hip.h is exported by the built shared object (no compute calls)."""
     from syntalker_amd import _lib
     header = open(os.path.join(REPO, "include", "syn_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(syn_[a-z_0-9]+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int32_t|int64_t|const char\*)\s+(syn_[a-z_0-9]+)\s*\(", header, flags=re.M))
     assert declared and declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     if not os.path.exists(_lib.LIB_PATH):
         pytest.fail(f"{_lib.LIB_PATH} missing: run __graft_entry__.build()")
