@@ -277,8 +277,8 @@ def main():
                                    f"{B} clips/GPU x (1536,1,32) latents, MDM denoiser 8x512, random-init",
                        "clips_per_gpu": B, "global_clips": world * B, "parallelism": f"clip-sharded x{world}, no collective",
                        "m_tile": args.m_tile or "auto"},
-            "latency_note": "one step advances every clip of the batch; per-clip conditioning (audio/word/seed encoders, "
-                            f"PyTorch-ROCm/MIOpen, once per clip, outside the timed region): {cond_ms_per_clip:.3f} ms/clip = "
+            "latency_note": "one step advances every clip of the batch; per-clip conditioning (audio encoder: HIP implicit-GEMM convs; "
+                            f"word/seed projections: PyTorch-ROCm; once per clip, outside the timed region): {cond_ms_per_clip:.3f} ms/clip = "
                             f"{cond_ms_per_clip / (dt / K * 1e3 / B):.0f} denoising steps' worth",
             "roofline": roofline,
         }

@@ -13,9 +13,11 @@ ONCE per clip and handed to the step kernels as a single additive tensor ``cond`
   models/denoiser_h3d.py:199-200, or use_motionclip) every term is left-multiplied by W3a and
   ``style W3s^T + b3`` joins cond.
 
-SURVEY.md §8 marks the conditioning encoders (a13-a16) as "next" for hand-written kernels; this round
-they run as PyTorch-ROCm ops (MIOpen conv) once per clip, with eval-mode BatchNorm folded into the
-convolutions.  Everything is computed from a flat ``{name: tensor}`` view of MDM.state_dict().
+SURVEY.md §8 marks the conditioning encoders (a13-a16) as "next" (f1): the WavEncoder - 98 % of the
+conditioning FLOPs - runs on hand-written implicit-GEMM convolution kernels (`HipWavEncoder`, C ABI
+`syn_wav_encode`, eval-mode BatchNorm folded into the convolutions); the word / seed / mixing projections
+(0.07 GFLOP per clip) are PyTorch-ROCm ops.  Everything is computed from a flat ``{name: tensor}`` view of
+MDM.state_dict().
 """
 from __future__ import annotations
 
