@@ -100,6 +100,8 @@ typedef struct syn_step {
     void*  ws_hc;     /* [3][B*32][512] bf16 guidance-combined stream (only if V > 1)            */
     uint32_t* ws_sync; /* [320] u32, zeroed ONCE by the caller; small-batch path only (group-barrier
                           counters; word 256 = sticky error flag: a barrier wait ran out)        */
+    float* ws_x0v;     /* [V*B*32][1536] fp32 or NULL; small-batch path with V > 1: lets the variants of a clip run on
+                          different XCDs (each writes its x0_hat here, a small second kernel combines them)   */
 } syn_step;
 
 /* Enqueue one full step (42 kernels) on `stream`. */

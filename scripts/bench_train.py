@@ -14,7 +14,7 @@ y["audio"] = torch.randn(B, 68266, 2, device='cuda')          # training clip le
 x0 = synth.synth_latent(B, seed=1, name="x0").cuda()
 for _ in range(3): training.train_step(m, d, s, opt, x0, {"y": y})
 torch.cuda.synchronize(); t0 = time.perf_counter()
-n = 10
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 for _ in range(n): training.train_step(m, d, s, opt, x0, {"y": y})
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print(f"train step B={B}: {dt*1e3:.1f} ms  ({B/dt:.0f} samples/s on 1 GPU)")

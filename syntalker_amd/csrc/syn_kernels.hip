@@ -1190,6 +1190,33 @@ __global__ void k_combine(const float* __restrict__ H, const float* __restrict__
     *reinterpret_cast<bf16x4*>(hc + (size_t)c * Mb * kNT + e) = to_bf16x4(s);
 }
 
+// Guided small batches (k_lat with per-sequence groups): x0 = sum_v w[blk][v] * x0_v, then the same posterior /
+// DDIM update and noise as the fused epilogues.  One float4 per thread.
+struct UArgs {
+    const float* X0v; const float* w; int V, B;
+    const float* Xt; const float* noise; const unsigned long long* rng; const float* coef; const int* t_coef;
+    float* Xn; __bf16* Xnb; float* X0;
+};
+__global__ void k_guided_update(const UArgs a) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per_clip = (size_t)SYN_T * SYN_C / 4, n4 = (size_t)a.B * per_clip;
+    if (i >= n4) return;
+    const int clip = (int)(i / per_clip);
+    const size_t off = i * 4;                                    // element offset in the [B*32][1536] tensors
+    const int blk = (int)((off % SYN_C) / kNT);
+    f32x4 x0 = {0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < a.V; ++v)
+        x0 = x0 + *reinterpret_cast<const f32x4*>(a.X0v + (size_t)v * a.B * SYN_T * SYN_C + off) * a.w[blk * a.V + v];
+    const int tc = a.t_coef[clip];
+    const f32x4 cf = *reinterpret_cast<const f32x4*>(a.coef + (size_t)tc * 4);
+    f32x4 xn = x0 * cf[0] + *reinterpret_cast<const f32x4*>(a.Xt + off) * cf[1];
+    if (a.noise) xn = xn + *reinterpret_cast<const f32x4*>(a.noise + off) * cf[2];
+    else if (a.rng) xn = xn + randn4(a.rng[0], (uint64_t)tc, (a.rng[1] * (uint64_t)(SYN_T * SYN_C) + off) >> 2) * cf[2];
+    *reinterpret_cast<f32x4*>(a.Xn + off) = xn;
+    *reinterpret_cast<bf16x4*>(a.Xnb + off) = to_bf16x4(xn);
+    if (a.X0) *reinterpret_cast<f32x4*>(a.X0 + off) = x0;
+}
+
 // fp32 W[n][k] -> packed bf16 fragments: out[((nf*KS + ks)*64 + lane)*8 + e] = W[16nf + (lane&15)][32ks + 8(lane>>4) + e]
 __global__ void k_pack(const float* __restrict__ W, int N, int K, uint4* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1588,10 +1615,13 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     int mode = st->reserved & 3;
     // Small batches: the persistent feature-split kernel (syn_latency.inc) beats the token-resident one while a
     // group (XCD) holds at most 4 sequences (measured per step: 161 / 239 / 405 us at 1 / 2 / 4 sequences per
-    // group against ~445 us, and 733 us at 8).  reserved bit 2
-    // pins the whole-step kernel (A/B runs, bitwise cross-checks against layer modes 1 / 2).
-    if (mode == 0 && !(st->reserved & 4) && st->ws_sync && ((B + lat::kGroups - 1) / lat::kGroups) * V <= 4 && latency_path_ok())
-        mode = 3;
+    // group against ~445 us, and 733 us at 8).  Guided batches (V > 1) deal SEQUENCES to the XCDs when the caller
+    // provides ws_x0v (each variant's x0_hat is produced on its own XCD, k_guided_update combines them), else whole
+    // clips with all their variants.  reserved bit 2 pins the whole-step kernel (A/B runs, bitwise cross-checks
+    // against layer modes 1 / 2).
+    const bool by_seq = V > 1 && st->ws_x0v != nullptr;
+    const int per_group = by_seq ? (B * V + lat::kGroups - 1) / lat::kGroups : ((B + lat::kGroups - 1) / lat::kGroups) * V;
+    if (mode == 0 && !(st->reserved & 4) && st->ws_sync && per_group <= 4 && latency_path_ok()) mode = 3;
     if (mode == 3) {
         // small-batch path: one persistent kernel, output features split over the CUs of an XCD
         if (!st->ws_sync) return fail_msg("syn_denoise_step: the latency path needs ws_sync");
@@ -1608,8 +1638,18 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
         la.xn = st->x_next; la.xnb = (__bf16*)st->x_next_bf16; la.x0 = st->pred_x0;
         la.H = st->ws_h; la.Q = (__bf16*)st->ws_q; la.Kb = (__bf16*)st->ws_k; la.Vt = (__bf16*)st->ws_vt;
         la.HID = (__bf16*)st->ws_hid; la.sync = st->ws_sync; la.dbg = g_dbg_mlp;
+        la.X0v = by_seq ? st->ws_x0v : nullptr;
         if ((rc = launch_latency(la, s))) return rc;
         mark(ST_FC2);
+        if (by_seq) {
+            UArgs u;
+            u.X0v = st->ws_x0v; u.w = st->cfg_w; u.V = V; u.B = B; u.Xt = st->x_t; u.noise = st->noise;
+            u.rng = (const unsigned long long*)st->rng; u.coef = st->coef; u.t_coef = st->t_coef;
+            u.Xn = st->x_next; u.Xnb = (__bf16*)st->x_next_bf16; u.X0 = st->pred_x0;
+            const size_t n4 = (size_t)B * SYN_T * SYN_C / 4;
+            hipLaunchKernelGGL(k_guided_update, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, u);
+            mark(ST_OUT);
+        }
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : fail("syn_denoise_step", e);
     }

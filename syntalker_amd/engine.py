@@ -111,6 +111,9 @@ class StepBuffers:
         s.ws_h, s.ws_xn, s.ws_q, s.ws_k = self.h.data_ptr(), self.xn.data_ptr(), self.q.data_ptr(), self.k.data_ptr()
         s.ws_vt, s.ws_o, s.ws_hid, s.ws_hc = self.vt.data_ptr(), self.o.data_ptr(), self.hid.data_ptr(), _lib.ptr(self.hc)
         s.ws_sync = self.sync.data_ptr()
+        # guided small batches: per-variant x0_hat, so that the variants of a clip can run on different XCDs
+        self.x0v = e(R, CH) if (V > 1 and B * V <= 32) else None
+        s.ws_x0v = _lib.ptr(self.x0v)
         self.c = s
 
     # layout ------------------------------------------------------------------------------------
