@@ -356,3 +356,35 @@ def test_train_mode_step_runs_and_updates(beatx):
     with torch.no_grad():                                                         # packed weights follow the update
         out = m(x0, torch.tensor([5, 6, 7, 8], device=DEV), y)
     assert torch.isfinite(out).all()
+
+
+def test_guided_small_batch_both_group_layouts(h3d):
+    """Small-batch kernel with guidance variants: (a) sequences dealt to the XCDs + k_guided_update (ws_x0v given),
+    (b) whole clips per XCD with the combination inside the kernel (ws_x0v = NULL), (c) the whole-step kernel path.
+    Same step, same noise: all three agree to the bf16 re-rounding floor, (a) and (b) are each deterministic."""
+    from syntalker_amd import engine
+    from syntalker_amd.process import create_gaussian_diffusion
+    B, V = 3, 3
+    pm = h3d.packed()
+    g = torch.Generator().manual_seed(77)
+    cond = (torch.randn(V * B * 32, 512, generator=g) * 0.5).to(DEV)
+    x = torch.randn(B, 1536, 1, 32, generator=g).to(DEV)
+    w = torch.tensor([[2.5, -1.0, -0.5], [1.0, 0.0, 0.0], [0.2, 0.3, 0.5]], device=DEV)
+    coef = engine.ddim_coefs(create_gaussian_diffusion(use_ddim=True).tables(), 0.0, DEV)
+
+    def run(mode, by_seq):
+        sb = engine.StepBuffers(B, V, DEV, want_x0=True, layer_mode=mode)
+        if not by_seq:
+            sb.c.ws_x0v = None
+        sb.cond.copy_(cond); sb.cfg_w.copy_(w); sb.load_x(x); sb.set_rng(5, 0)
+        sb.t_model.copy_(torch.tensor([40] * (V * B), dtype=torch.int32)); sb.t_coef.fill_(40)
+        engine.run_step(pm, sb, coef, True, True)
+        return sb.read(sb.x).cpu(), sb.read(sb.x0).cpu()
+
+    a1, a0 = run(3, True)
+    b1, b0 = run(3, False)
+    c1, c0 = run(4, True)
+    assert torch.equal(run(3, True)[0], a1) and torch.equal(run(3, False)[0], b1)
+    for got in (a0, b0):
+        assert rel_l2(got, c0) < 1.5e-2
+    assert rel_l2(a1, c1) < 1.5e-2 and rel_l2(b1, c1) < 1.5e-2
