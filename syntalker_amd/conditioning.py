@@ -75,7 +75,8 @@ def wav_gemm_weight(w, stride: int):
 class HipWavEncoder:
     """WavEncoder.forward (eval mode) on the hand-written conv kernels through the C ABI (`syn_wav_encode`)."""
 
-    CHUNK = 64                          # clips per call: bounds the workspace (7.5 MB per clip at 68 k samples)
+    CHUNK = 256                         # clips per call: bounds the workspace (7.5 MB per clip at 68 k samples) while giving the
+                                        # short late layers (128-396 positions per clip) enough workgroups to fill 256 CUs
 
     def __init__(self, blocks, device):
         from . import _lib, engine
