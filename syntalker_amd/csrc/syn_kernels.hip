@@ -1386,8 +1386,8 @@ WavPlan wav_plan(int L) {
     p.L4 = (p.L3 - 15) / 3 + 1;
     long o = 0;
     auto take = [&](long rows, int ch) { const long at = o; o += rows * ch; o = (o + 63) & ~63L; return at; };
-    const long h1 = p.L1 + 2 * kHalo + kSlack, h2 = p.L2 + 2 * kHalo + kSlack, h3 = p.L3 + 2 * kHalo + kSlack, h4 = p.L4 + 2 * kHalo + kSlack;
-    p.z0 = take(h1, 64);  p.s0 = take(p.L1, 64);  p.x1 = take(p.L1 + kSlack, 64);
+    const long h2 = p.L2 + 2 * kHalo + kSlack, h3 = p.L3 + 2 * kHalo + kSlack, h4 = p.L4 + 2 * kHalo + kSlack;
+    p.z0 = p.s0 = 0;      /* block 0's intermediates never leave the chip (k_block0) */  p.x1 = take(p.L1 + kSlack, 64);
     p.z1 = take(h2, 64);  p.s1 = take(p.L2, 64);  p.x2 = take(h2, 64);
     p.z2 = take(h2, 64);  p.x3 = take(p.L2 + kSlack, 64);
     p.z3 = take(h3, 128); p.s3 = take(p.L3, 128); p.x4 = take(h3, 128);
@@ -1535,12 +1535,14 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, 
     __bf16* const ws = (__bf16*)workspace;
     const long cs = p.per_clip;
     int rc;
-    {   // block 0: conv1 + shortcut from the waveform
-        wav::FArgs f;
-        f.wav = wav_in; f.wav_clip_stride = (long)n_samples * enc->cin; f.L = n_samples; f.cin = enc->cin; f.L_out = p.L1;
-        f.w = enc->w_first;
-        f.Z = ws + p.z0; f.z_clip_stride = cs; f.z_off = kHalo * 64; f.S = ws + p.s0; f.s_clip_stride = cs;
-        hipLaunchKernelGGL(wav::k_first, dim3((p.L1 + 63) / 64, n_clips), dim3(256), 0, s, f);
+    {   // block 0 in one kernel: conv1 recomputed into the LDS tile, shortcut as the accumulators' initial value
+        static bool once = false;
+        if (!once) { allow_lds(wav::k_block0, wav::kB0Lds); once = true; }
+        wav::B0Args b;
+        b.wav = wav_in; b.wav_clip_stride = (long)n_samples * enc->cin; b.L = n_samples; b.cin = enc->cin; b.L1 = p.L1;
+        b.w_first = enc->w_first; b.W2 = (const uint4*)enc->conv[0].w; b.bias2 = enc->conv[0].bias;
+        b.X1 = ws + p.x1; b.x1_clip_stride = cs;
+        hipLaunchKernelGGL(wav::k_block0, dim3((p.L1 + 511) / 512, n_clips), dim3(kThreads), wav::kB0Lds, s, b);
     }
     auto base = [&](int i) {
         wav::CArgs a;
@@ -1550,9 +1552,6 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, 
         return a;
     };
     wav::CArgs a;
-    // block 0 conv2 (+ shortcut) -> x1
-    a = base(0); a.X = ws + p.z0; a.x_rows = p.L1 + 2 * kHalo; a.L_out = p.L1; a.Z = ws + p.x1; a.R = ws + p.s0;
-    if ((rc = launch_conv<64, 15, 1, 8, 4, wav::E_C2>(a, n_clips, s))) return rc;
     // block 1: conv1 | shortcut (stride 6 = 3 taps over 6-row groups), conv2 -> x2 (halo: block 2 pads by 7)
     a = base(1); a.X = ws + p.x1; a.x_rows = (p.L1 + 5) / 6; a.L_out = p.L2; a.Z = ws + p.z1; a.z_off = kHalo * 64; a.S = ws + p.s1;
     if ((rc = launch_conv<384, 3, 2, 4, 2, wav::E_C1SC>(a, n_clips, s))) return rc;
