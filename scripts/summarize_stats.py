@@ -5,7 +5,8 @@ import sys
 
 src, dst, note = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "")
 rows = list(csv.DictReader(open(src)))
-OURS = ("k_stack", "k_lat", "k_gemm", "k_attn", "k_mlp", "k_pack", "k_to_token", "k_from_token", "k_randn", "k_combine", "k_axpby")
+OURS = ("k_stack", "k_lat", "k_gemm", "k_attn", "k_mlp", "k_pack", "k_to_token", "k_from_token", "k_randn", "k_combine", "k_axpby",
+        "k_conv", "k_block0", "k_guided")
 ours = [r for r in rows if any(t in r["Name"] for t in OURS) and "at::native" not in r["Name"]]
 other = [r for r in rows if r not in ours][:8]
 with open(dst, "w") as f:
@@ -16,7 +17,7 @@ with open(dst, "w") as f:
         n = r["Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
         f.write(f"{int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:10.3f} {float(r['AverageNs'])/1e3:10.2f} "
                 f"{float(r['Percentage']):6.2f} {float(r['MinNs'])/1e3:9.2f} {float(r['MaxNs'])/1e3:9.2f}  {n[:90]}\n")
-    f.write("## largest other kernels (PyTorch-ROCm/MIOpen conditioning encoders, once per clip, outside the timed region)\n")
+    f.write("## largest other kernels (PyTorch-ROCm ops of the per-clip conditioning, fills, copies)\n")
     for r in other:
         f.write(f"{int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:10.3f} {float(r['AverageNs'])/1e3:10.2f} "
                 f"{float(r['Percentage']):6.2f} {float(r['MinNs'])/1e3:9.2f} {float(r['MaxNs'])/1e3:9.2f}  {r['Name'][:90]}\n")
