@@ -112,6 +112,20 @@ int syn_denoise_step(const syn_model* model, const syn_step* step, void* stream)
  * 4 fc1 GEMM, 5 fc2 GEMM, 6 guidance combine, 7 output GEMM}.  Synchronises `stream`; not graph-capturable. */
 int syn_denoise_step_profile(const syn_model* model, const syn_step* step, void* stream, float* ms_out, int32_t* count_out);
 
+/* ---- training path: fp32 forward / backward of the non-GEMM pieces of a transformer block ----
+ * LayerNorm(512, eps 1e-5) of `rows` rows (models/timm_transformer/transformer.py:160,162,183,193); the backward
+ * needs scratch of ceil(rows/64)*1024 floats and writes dgamma[512], dbeta[512] (deterministic two-stage sums). */
+int syn_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int32_t rows, void* stream);
+int syn_ln_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma,
+               float* dbeta, float* scratch, int32_t rows, void* stream);
+/* nn.GELU() (exact erf form, transformer.py:117-151), n % 4 == 0 elements. */
+int syn_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* Attention core (transformer.py:83-104, 4 heads x 128, 32 tokens, no mask, no dropout) on the packed output of the
+ * qkv Linear: qkv [n_seq][32][3][4][128] -> o [n_seq][32][512]; backward recomputes the probabilities. */
+int syn_attn_fwd(const float* qkv, float* o, int32_t n_seq, void* stream);
+int syn_attn_bwd(const float* qkv, const float* d_o, float* dqkv, int32_t n_seq, void* stream);
+
 /* ---- per-clip conditioning: audio encoder -------------------------------------
  * WavEncoder.forward in eval mode (models/denoiser.py:304-322; BasicBlock models/utils/layer.py:144-184) with the
  * BatchNorms folded into the convolutions by the caller.  wav [n_clips][n_samples][cin] fp32 ->

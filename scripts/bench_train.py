@@ -6,6 +6,7 @@ from syntalker_amd.denoiser import MDM
 from syntalker_amd.process import create_gaussian_diffusion
 from syntalker_amd.resample import create_named_schedule_sampler
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+if len(sys.argv) > 3: training.HIP_BLOCK_OPS = bool(int(sys.argv[3]))
 m = synth.synth_fill_(MDM(synth.default_args()).train(), 0).cuda()
 d = create_gaussian_diffusion(); s = create_named_schedule_sampler("uniform", d)
 opt = torch.optim.Adam(m.parameters(), lr=5e-5, betas=(0.5, 0.999))

@@ -1371,6 +1371,7 @@ int launch_stack(const SArgs& a, int mt, hipStream_t s) {
 
 #include "syn_latency.inc"
 #include "syn_wavenc.inc"
+#include "syn_train.inc"
 
 // ---- WavEncoder forward: lengths, workspace layout and the 12 launches ----------------------------------------
 struct WavPlan {
@@ -1516,6 +1517,55 @@ int syn_test_attention(const void* q, const void* k, const void* vt, int32_t n_s
                        (const __bf16*)vt, (__bf16*)o, n_seq);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_attn launch", e);
+}
+
+// ---- training path: fp32 forward / backward of LayerNorm(512), GELU and the 32-token attention ---------------
+int syn_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int32_t rows, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0) return fail_msg("syn_ln_fwd: bad arguments");
+    hipLaunchKernelGGL(trn::k_ln_fwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, rows);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_ln_fwd launch", e);
+}
+
+int syn_ln_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma,
+               float* dbeta, float* scratch, int32_t rows, void* stream) {
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !scratch || rows <= 0) return fail_msg("syn_ln_bwd: bad arguments");
+    const int per = 64, nwg = (rows + per - 1) / per;             // scratch: [nwg][2][512] floats
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(trn::k_ln_bwd, dim3(nwg), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, scratch, rows, per);
+    hipLaunchKernelGGL(trn::k_colsum, dim3(4), dim3(256), 0, s, scratch, nwg, 2 * SYN_D, SYN_D, dgamma, dbeta);   // partials [p][dgamma | dbeta]
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_ln_bwd launch", e);
+}
+
+int syn_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0 || n % 4) return fail_msg("syn_gelu_fwd: n must be a positive multiple of 4");
+    hipLaunchKernelGGL(trn::k_gelu_fwd, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)(n / 4));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_gelu_fwd launch", e);
+}
+
+int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+    if (!x || !dy || !dx || n <= 0 || n % 4) return fail_msg("syn_gelu_bwd: n must be a positive multiple of 4");
+    hipLaunchKernelGGL(trn::k_gelu_bwd, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (size_t)(n / 4));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_gelu_bwd launch", e);
+}
+
+int syn_attn_fwd(const float* qkv, float* o, int32_t n_seq, void* stream) {
+    if (!qkv || !o || n_seq <= 0) return fail_msg("syn_attn_fwd: bad arguments");
+    hipLaunchKernelGGL(trn::k_attn_fwd, dim3(n_seq * SYN_HEADS), dim3(256), 0, (hipStream_t)stream, qkv, o);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_attn_fwd launch", e);
+}
+
+int syn_attn_bwd(const float* qkv, const float* d_o, float* dqkv, int32_t n_seq, void* stream) {
+    if (!qkv || !d_o || !dqkv || n_seq <= 0) return fail_msg("syn_attn_bwd: bad arguments");
+    static bool once = false;
+    if (!once) { allow_lds(trn::k_attn_bwd, trn::kAttnBwdLds); once = true; }
+    hipLaunchKernelGGL(trn::k_attn_bwd, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnBwdLds, (hipStream_t)stream, qkv, d_o, dqkv);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_attn_bwd launch", e);
 }
 
 int32_t syn_wav_out_frames(int32_t n_samples) { return n_samples >= 15 ? wav_plan(n_samples).L4 : 0; }

@@ -4,9 +4,11 @@ Structure this round
   * every nn.Linear of the denoiser (qkv, proj, fc1, fc2, poseEmbedding, input_process2/3, poseFinal, embed_text,
     time MLP, word/mix projections) runs forward, dgrad and wgrad on the hand-written MFMA GEMM through the C ABI
     entry `syn_linear` (bf16 operands, fp32 accumulate/output) — `HipLinearFn`;
-  * LayerNorm, softmax attention, GELU, rotary, DropPath and the SmoothL1 loss are fp32 PyTorch-ROCm ops here
-    (fused HIP backward kernels for them are the next step), and the WavEncoder convolutions (78 % of the
-    training FLOPs) run on MIOpen, as SURVEY.md §7 stage 6 prescribes for the first cut;
+  * LayerNorm, the 32-token softmax attention and GELU of the 8 blocks run forward and backward on fp32 HIP kernels
+    (`syn_ln_*`, `syn_attn_*`, `syn_gelu_*`; `HipLayerNormFn`, `HipAttentionFn`, `HipGeluFn`);
+  * rotary, DropPath and the SmoothL1 loss are fp32 PyTorch-ROCm ops, and the WavEncoder convolutions + BatchNorms
+    (78 % of the training FLOPs, batch statistics in training) run on MIOpen, as SURVEY.md §7 stage 6 prescribes for
+    the first cut;
   * data parallelism: one process per GPU, torch DDP over RCCL (`make_ddp`), gradients averaged by bucketed
     all-reduce overlapped with backward; optional SyncBatchNorm for the WavEncoder (the reference's DDP branch,
     train.py:90).
@@ -88,6 +90,91 @@ def lin(x, module: nn.Linear):
     return HipLinearFn.apply(x, module.weight, module.bias)
 
 
+# fp32 block ops on the hand-written kernels (True) or on the PyTorch-ROCm ops (False).  Same numerics to 1e-5
+# (tests/test_gpu_kernels.py::test_training_block_ops_vs_torch_autograd); see DESIGN.md §7 for the timings.
+HIP_BLOCK_OPS = True
+
+
+def _f32c(t):
+    t = t.detach()
+    if t.dtype is not torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class HipLayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm(512, eps 1e-5): fp32 forward / backward kernels (syn_ln_fwd / syn_ln_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, g, b):
+        engine._require_cuda(x, "LayerNorm input")
+        xc, gc, bc = _f32c(x).view(-1, 512), _f32c(g), _f32c(b)
+        rows = xc.shape[0]
+        y = torch.empty_like(xc)
+        mean, rstd = torch.empty(rows, device=x.device), torch.empty(rows, device=x.device)
+        _lib.check(_lib.load().syn_ln_fwd(xc.data_ptr(), gc.data_ptr(), bc.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                          rows, _lib.current_stream()), "syn_ln_fwd")
+        ctx.save_for_backward(xc, gc, mean, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, gc, mean, rstd = ctx.saved_tensors
+        rows = xc.shape[0]
+        dyc = _f32c(dy).view(-1, 512)
+        dx = torch.empty_like(xc)
+        dg, db = torch.empty(512, device=dy.device), torch.empty(512, device=dy.device)
+        scratch = torch.empty((rows + 63) // 64 * 1024, device=dy.device)
+        _lib.check(_lib.load().syn_ln_bwd(dyc.data_ptr(), xc.data_ptr(), gc.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                          dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), rows, _lib.current_stream()), "syn_ln_bwd")
+        return dx.view(dy.shape), dg, db
+
+
+class HipGeluFn(torch.autograd.Function):
+    """nn.GELU() (exact erf form)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        engine._require_cuda(x, "GELU input")
+        xc = _f32c(x)
+        y = torch.empty_like(xc)
+        _lib.check(_lib.load().syn_gelu_fwd(xc.data_ptr(), y.data_ptr(), xc.numel(), _lib.current_stream()), "syn_gelu_fwd")
+        ctx.save_for_backward(xc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, = ctx.saved_tensors
+        dyc = _f32c(dy)
+        dx = torch.empty_like(xc)
+        _lib.check(_lib.load().syn_gelu_bwd(xc.data_ptr(), dyc.data_ptr(), dx.data_ptr(), xc.numel(), _lib.current_stream()), "syn_gelu_bwd")
+        return dx
+
+
+class HipAttentionFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(128)) v for 4 heads x 128 dims over 32 tokens, on the packed (B, 32, 1536) output of the qkv Linear
+    (models/timm_transformer/transformer.py:83-104; no mask, attention dropout 0)."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        engine._require_cuda(qkv, "attention input")
+        q = _f32c(qkv)
+        bs, T, _ = q.shape
+        assert T == 32 and q.shape[2] == 1536, q.shape
+        o = torch.empty(bs, T, 512, device=q.device)
+        _lib.check(_lib.load().syn_attn_fwd(q.data_ptr(), o.data_ptr(), bs, _lib.current_stream()), "syn_attn_fwd")
+        ctx.save_for_backward(q)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, = ctx.saved_tensors
+        doc = _f32c(do)
+        dqkv = torch.empty_like(q)
+        _lib.check(_lib.load().syn_attn_bwd(q.data_ptr(), doc.data_ptr(), dqkv.data_ptr(), q.shape[0], _lib.current_stream()), "syn_attn_bwd")
+        return dqkv
+
+
 def _drop_path(x, p: float, training: bool):
     if p == 0. or not training:
         return x
@@ -154,12 +241,19 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
         seq = lin(torch.cat((seq, st.unsqueeze(0).repeat(T, 1, 1)), dim=2), m.input_process3)
     h = _rotary(m, seq.permute(1, 0, 2))
     for blk in m.mytimmblocks:
-        z = F.layer_norm(h, (512,), blk.norm1.weight, blk.norm1.bias, 1e-5)
-        qkv = lin(z, blk.attn.qkv).reshape(bs, T, 3, 4, 128).permute(2, 0, 3, 1, 4)
-        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], dropout_p=0.0).transpose(1, 2).reshape(bs, T, 512)
-        h = h + _drop_path(lin(o, blk.attn.proj), drop_path, training)
-        z = F.layer_norm(h, (512,), blk.norm2.weight, blk.norm2.bias, 1e-5)
-        h = h + _drop_path(lin(F.gelu(lin(z, blk.mlp.fc1)), blk.mlp.fc2), drop_path, training)
+        if HIP_BLOCK_OPS:
+            z = HipLayerNormFn.apply(h, blk.norm1.weight, blk.norm1.bias)
+            o = HipAttentionFn.apply(lin(z, blk.attn.qkv))           # (B, T, 3 x 4 heads x 128) -> (B, T, 512)
+            h = h + _drop_path(lin(o, blk.attn.proj), drop_path, training)
+            z = HipLayerNormFn.apply(h, blk.norm2.weight, blk.norm2.bias)
+            h = h + _drop_path(lin(HipGeluFn.apply(lin(z, blk.mlp.fc1)), blk.mlp.fc2), drop_path, training)
+        else:
+            z = F.layer_norm(h, (512,), blk.norm1.weight, blk.norm1.bias, 1e-5)
+            qkv = lin(z, blk.attn.qkv).reshape(bs, T, 3, 4, 128).permute(2, 0, 3, 1, 4)
+            o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], dropout_p=0.0).transpose(1, 2).reshape(bs, T, 512)
+            h = h + _drop_path(lin(o, blk.attn.proj), drop_path, training)
+            z = F.layer_norm(h, (512,), blk.norm2.weight, blk.norm2.bias, 1e-5)
+            h = h + _drop_path(lin(F.gelu(lin(z, blk.mlp.fc1)), blk.mlp.fc2), drop_path, training)
     out = lin(h.permute(1, 0, 2), m.output_process.poseFinal)
     return out.reshape(T, bs, C, 1).permute(1, 2, 3, 0)
 

@@ -116,3 +116,39 @@ def test_wav_encoder_vs_torch(B, L):
     print(f"wav encoder B={B} L={L}: out {tuple(got.shape)} rel-L2 {e:.3e}")
     assert e < 2e-2
     assert torch.equal(enc(wav.to("cuda")).cpu(), got)          # deterministic, workspace halos intact on reuse
+
+
+def test_training_block_ops_vs_torch_autograd():
+    """fp32 forward / backward kernels of the training path (LayerNorm, GELU, 32-token attention) against PyTorch
+    autograd on the same inputs (fp32 vs fp32: 1e-5)."""
+    import torch.nn.functional as F
+    from syntalker_amd import training
+    dev = "cuda"
+    g = torch.Generator().manual_seed(3)
+    # LayerNorm
+    x = (torch.randn(200, 512, generator=g) * 2 + 0.5).to(dev).requires_grad_()
+    w, b = torch.randn(512, generator=g).to(dev).requires_grad_(), torch.randn(512, generator=g).to(dev).requires_grad_()
+    up = torch.randn(200, 512, generator=g).to(dev)
+    y = training.HipLayerNormFn.apply(x, w, b)
+    gx, gw, gb = torch.autograd.grad(y, (x, w, b), up)
+    yr = F.layer_norm(x, (512,), w, b, 1e-5)
+    rx, rw, rb = torch.autograd.grad(yr, (x, w, b), up)
+    for a_, b_ in ((y, yr), (gx, rx), (gw, rw), (gb, rb)):
+        assert rel_l2(a_.detach().cpu(), b_.detach().cpu()) < 1e-5
+    # GELU
+    x = (torch.randn(64, 1024, generator=g) * 3).to(dev).requires_grad_()
+    up = torch.randn(64, 1024, generator=g).to(dev)
+    y = training.HipGeluFn.apply(x)
+    gx, = torch.autograd.grad(y, x, up)
+    yr = F.gelu(x)
+    rx, = torch.autograd.grad(yr, x, up)
+    assert rel_l2(y.detach().cpu(), yr.detach().cpu()) < 1e-6 and rel_l2(gx.cpu(), rx.cpu()) < 1e-5
+    # attention on the packed qkv tensor
+    qkv = torch.randn(5, 32, 1536, generator=g).to(dev).requires_grad_()
+    up = torch.randn(5, 32, 512, generator=g).to(dev)
+    o = training.HipAttentionFn.apply(qkv)
+    gq, = torch.autograd.grad(o, qkv, up)
+    t = qkv.reshape(5, 32, 3, 4, 128).permute(2, 0, 3, 1, 4)
+    orf = F.scaled_dot_product_attention(t[0], t[1], t[2]).transpose(1, 2).reshape(5, 32, 512)
+    rq, = torch.autograd.grad(orf, qkv, up)
+    assert rel_l2(o.detach().cpu(), orf.detach().cpu()) < 1e-5 and rel_l2(gq.cpu(), rq.cpu()) < 1e-5
