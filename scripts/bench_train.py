@@ -7,15 +7,16 @@ from syntalker_amd.process import create_gaussian_diffusion
 from syntalker_amd.resample import create_named_schedule_sampler
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 if len(sys.argv) > 3: training.HIP_BLOCK_OPS = bool(int(sys.argv[3]))
-m = synth.synth_fill_(MDM(synth.default_args()).train(), 0).cuda()
+if len(sys.argv) > 4: training.WAV_CHANNELS_LAST = bool(int(sys.argv[4]))
 d = create_gaussian_diffusion(); s = create_named_schedule_sampler("uniform", d)
-opt = torch.optim.Adam(m.parameters(), lr=5e-5, betas=(0.5, 0.999))
 y = synth.to_device(synth.synth_clip_inputs(B, seed=1, mask_batch=B), 'cuda')
 y["audio"] = torch.randn(B, 68266, 2, device='cuda')          # training clip length (beat_sep_lower.py:678)
 x0 = synth.synth_latent(B, seed=1, name="x0").cuda()
+m = synth.synth_fill_(MDM(synth.default_args()).train(), 0).cuda()
+opt = torch.optim.Adam(m.parameters(), lr=5e-5, betas=(0.5, 0.999))
 for _ in range(3): training.train_step(m, d, s, opt, x0, {"y": y})
 torch.cuda.synchronize(); t0 = time.perf_counter()
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 for _ in range(n): training.train_step(m, d, s, opt, x0, {"y": y})
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(f"train step B={B}: {dt*1e3:.1f} ms  ({B/dt:.0f} samples/s on 1 GPU)")
+print(f"train step B={B}: {dt*1e3:.1f} ms  ({B/dt:.0f} samples/s on 1 GPU)", flush=True)

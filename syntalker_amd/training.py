@@ -195,8 +195,24 @@ def _rotary(m, h):
     return g.reshape(B, 8, T, -1).permute(0, 2, 1, 3).reshape(B, T, -1)
 
 
+WAV_CHANNELS_LAST = True     # run the encoder's convolutions as (N, C, 1, L) channels-last conv2d: MIOpen's NHWC kernels without
+                             # the NCHW <-> NHWC transposes it otherwise inserts around every convolution
+
+
+def _conv_bn(conv, bn, x, training):
+    """Conv1d + BatchNorm1d of the module (batch statistics in training, running statistics in eval) on (N, C, 1, L)."""
+    y = F.conv2d(x, conv.weight.unsqueeze(2), conv.bias, stride=(1, conv.stride[0]), padding=(0, conv.padding[0]))
+    return F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
+
+
 def _wav_block(blk, x):
     """models/utils/layer.py:171-184 with the module's own Conv1d / BatchNorm1d (train or eval statistics)."""
+    if WAV_CHANNELS_LAST and x.dim() == 4:
+        tr = blk.training
+        z = F.leaky_relu(_conv_bn(blk.conv1, blk.bn1, x, tr), 0.01)
+        z = _conv_bn(blk.conv2, blk.bn2, z, tr)
+        short = x if blk.downsample is None else _conv_bn(blk.downsample[0], blk.downsample[1], x, tr)
+        return F.leaky_relu(z + short, 0.01)
     short = x
     z = F.leaky_relu(blk.bn1(blk.conv1(x)), 0.01)
     z = blk.bn2(blk.conv2(z))
@@ -220,8 +236,12 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     if h3d and y.get("uncond_audio", False):
         audio, word = torch.zeros_like(audio), torch.zeros_like(word)
     a = audio.unsqueeze(1) if audio.dim() == 2 else audio.transpose(1, 2)
+    if WAV_CHANNELS_LAST:
+        a = a.unsqueeze(2).contiguous(memory_format=torch.channels_last)       # (B, C, 1, L), channel innermost
     for blk in m.WavEncoder.feat_extractor:
         a = _wav_block(blk, a)
+    if a.dim() == 4:
+        a = a.squeeze(2)
     a_feat = a.transpose(1, 2).permute(1, 0, 2)                                  # (128, B, 256)
     w_feat = lin(m.text_pre_encoder_body(word), m.text_encoder_body).permute(1, 0, 2)
     at = lin(torch.cat([a_feat, w_feat], dim=2), m.mix_audio_text)
@@ -279,3 +299,4 @@ def train_step(model, diffusion, sampler, optimizer, x0, model_kwargs, grad_norm
         torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm)
     optimizer.step()
     return loss.detach()
+
