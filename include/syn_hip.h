@@ -13,8 +13,8 @@
  *   - plain C, no exceptions; every entry point returns 0 on success, <0 on error;
  *     syn_last_error() returns a thread-local message for the last failure.
  *   - every pointer is a DEVICE pointer owned by the caller unless stated otherwise;
- *     nothing is allocated, freed or synchronised inside an entry point, so all of them can be
- *     captured in a hipGraph.  `stream` is a hipStream_t (NULL = default stream).
+ *     nothing is allocated, freed or synchronised inside an entry point (syn_denoise_step_profile excepted), so
+ *     all of them can be captured in a hipGraph.  `stream` is a hipStream_t (NULL = default stream).
  *   - "token-major" latent = [clip][frame 0..31][channel 0..1535]; the reference's layout
  *     (B, 1536, 1, 32) is "channel-major".  The sampling loop keeps x token-major across steps.
  *   - bf16 buffers are passed as void*; "packed" weights are in MFMA fragment order, produced
@@ -104,7 +104,8 @@ typedef struct syn_step {
                           different XCDs (each writes its x0_hat here, a small second kernel combines them)   */
 } syn_step;
 
-/* Enqueue one full step (42 kernels) on `stream`. */
+/* Enqueue one full step on `stream`: one kernel (k_stack, or k_lat for small batches; + k_guided_update when the
+ * variants of a small guided batch were dealt to different XCDs), or the 42-kernel A/B path (reserved = 1). */
 int syn_denoise_step(const syn_model* model, const syn_step* step, void* stream);
 
 /* Same step, eagerly, with a hipEvent after every launch: fills ms_out[8] / count_out[8] with the elapsed
