@@ -20,3 +20,14 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 for _ in range(n): training.train_step(m, d, s, opt, x0, {"y": y})
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print(f"train step B={B}: {dt*1e3:.1f} ms  ({B/dt:.0f} samples/s on 1 GPU)", flush=True)
+
+# the same step captured in a hipGraph (single process)
+m2 = synth.synth_fill_(MDM(synth.default_args()).train(), 0).cuda()
+opt2 = torch.optim.Adam(m2.parameters(), lr=5e-5, betas=(0.5, 0.999), capturable=True)
+step = training.GraphedTrainStep(m2, d, opt2, x0, {"y": y})
+for _ in range(3): step(x0, s.sample(B, x0.device)[0], {"y": y})
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(n): loss = step(x0, s.sample(B, x0.device)[0], {"y": y})
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+print(f"graph-replayed train step B={B}: {dt*1e3:.1f} ms  ({B/dt:.0f} samples/s on 1 GPU), loss {float(loss):.4f}", flush=True)
+step.close()

@@ -388,3 +388,21 @@ def test_guided_small_batch_both_group_layouts(h3d):
     for got in (a0, b0):
         assert rel_l2(got, c0) < 1.5e-2
     assert rel_l2(a1, c1) < 1.5e-2 and rel_l2(b1, c1) < 1.5e-2
+
+
+def test_graph_replayed_train_step(beatx):
+    """training.GraphedTrainStep: the captured step trains (parameters move, loss finite and falling on a fixed batch)."""
+    from syntalker_amd import training
+    from syntalker_amd.process import create_gaussian_diffusion
+    m = _model("beatx").train()
+    d = create_gaussian_diffusion()
+    opt = torch.optim.Adam(m.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True)
+    y = synth.to_device(synth.synth_clip_inputs(4, seed=61), DEV)
+    x0 = synth.synth_latent(4, seed=61, name="x0").to(DEV)
+    t = torch.tensor([100, 300, 500, 700], device=DEV)
+    step = training.GraphedTrainStep(m, d, opt, x0, {"y": y})
+    before = m.mytimmblocks[0].attn.qkv.weight.detach().clone()
+    losses = [float(step(x0, t, {"y": y})) for _ in range(25)]
+    step.close()
+    assert all(np.isfinite(losses)) and not torch.equal(before, m.mytimmblocks[0].attn.qkv.weight)
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
