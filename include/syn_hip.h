@@ -108,6 +108,12 @@ typedef struct syn_step {
  * variants of a small guided batch were dealt to different XCDs), or the 42-kernel A/B path (reserved = 1). */
 int syn_denoise_step(const syn_model* model, const syn_step* step, void* stream);
 
+/* Loop helper: fills t_coef[0..n_t_coef) with sched[2i] and t_model[0..n_t_model) with sched[2i + 1], i = *counter, then
+ * advances *counter - a whole p_sample_loop iteration (gaussian_diffusion.py:714-739) becomes one graph replay
+ * (this launch + syn_denoise_step) with no host work in between. */
+int syn_step_advance(const int32_t* sched, int32_t* counter, int32_t* t_model, int32_t n_t_model, int32_t* t_coef, int32_t n_t_coef,
+                     void* stream);
+
 /* Same step, eagerly, with a hipEvent after every launch: fills ms_out[8] / count_out[8] with the elapsed
  * milliseconds and launch count per stage class {0 input GEMM, 1 qkv GEMM, 2 attention, 3 proj GEMM,
  * 4 fc1 GEMM, 5 fc2 GEMM, 6 guidance combine, 7 output GEMM}.  Synchronises `stream`; not graph-capturable. */

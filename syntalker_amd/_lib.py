@@ -16,7 +16,7 @@ SYN_LAYERS = 8
 EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_step_profile", "syn_pack_weight", "syn_to_token_major",
            "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_test_gemm", "syn_test_attention",
            "syn_wav_encode", "syn_wav_workspace_bytes", "syn_wav_out_frames",
-           "syn_ln_fwd", "syn_ln_bwd", "syn_gelu_fwd", "syn_gelu_bwd", "syn_attn_fwd", "syn_attn_bwd")
+           "syn_step_advance", "syn_ln_fwd", "syn_ln_bwd", "syn_gelu_fwd", "syn_gelu_bwd", "syn_attn_fwd", "syn_attn_bwd")
 
 vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
 
@@ -77,6 +77,7 @@ def load():
     lib.syn_linear.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     lib.syn_test_gemm.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.syn_test_attention.argtypes = [vp, vp, vp, i32, vp, vp]
+    lib.syn_step_advance.argtypes = [vp, vp, vp, i32, vp, i32, vp]
     lib.syn_ln_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
     lib.syn_ln_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.syn_gelu_fwd.argtypes = [vp, vp, i64, vp]

@@ -1278,6 +1278,19 @@ __global__ void k_axpby_rows(const float* __restrict__ x, const float* __restric
     reinterpret_cast<f32x4*>(out)[i] = xv * a + yv * b;
 }
 
+// Sampling loops: the timestep vectors of the next step from a device-resident schedule, so that a loop iteration is
+// one graph replay and nothing else on the host.  sched[i] = {row of the coefficient table, original timestep};
+// *counter is advanced by the kernel (single workgroup).
+__global__ void k_step_advance(const int* __restrict__ sched, int* __restrict__ counter, int* __restrict__ t_model, int n_tm,
+                               int* __restrict__ t_coef, int n_tc) {
+    const int i = *counter;
+    const int tc = sched[2 * i], tm = sched[2 * i + 1];
+    for (int j = threadIdx.x; j < n_tm; j += blockDim.x) t_model[j] = tm;
+    for (int j = threadIdx.x; j < n_tc; j += blockDim.x) t_coef[j] = tc;
+    __syncthreads();
+    if (threadIdx.x == 0) *counter = i + 1;
+}
+
 __global__ void k_randn(float* __restrict__ out, long n4, uint64_t seed, uint64_t stream_id, long first4) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
@@ -1477,6 +1490,15 @@ int syn_axpby_rows(const float* x, const float* y, const float* coef_ab, const i
                        t_row, n4, per_clip / 4, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_axpby_rows launch", e);
+}
+
+int syn_step_advance(const int32_t* sched, int32_t* counter, int32_t* t_model, int32_t n_t_model, int32_t* t_coef, int32_t n_t_coef,
+                     void* stream) {
+    if (!sched || !counter || !t_model || !t_coef || n_t_model <= 0 || n_t_coef <= 0) return fail_msg("syn_step_advance: bad arguments");
+    hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(256), 0, (hipStream_t)stream, (const int*)sched, (int*)counter, (int*)t_model,
+                       n_t_model, (int*)t_coef, n_t_coef);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_step_advance launch", e);
 }
 
 int syn_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t first_index, void* stream) {

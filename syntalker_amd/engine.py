@@ -5,9 +5,10 @@ Layout in HBM (one GPU, everything resident for the whole loop):
     x                token-major fp32 [B*32][1536] + bf16 shadow copy (GEMM operand), updated in place
     cond             fp32 [V*B*32][512], computed once per clip (conditioning.py)
     workspace        h fp32 [R][512]; xn/q/k/o bf16 [R][512]; vt bf16 [R*512]; hid bf16 [R][1024]   (R = V*B*32)
-One step = one ``syn_denoise_step`` call = 3 kernel launches (input GEMM, the 8-block stack, output GEMM +
-posterior), hipGraph-captured and replayed; the
-timestep enters through two device int32 vectors so the same graph serves every step.
+One step = one ``syn_denoise_step`` call = one kernel launch (k_stack for large batches, the persistent k_lat for
+small ones), hipGraph-captured and replayed; the timestep enters through two device int32 vectors so the same graph
+serves every step, and in the sampling loops those vectors are advanced on the device (`syn_step_advance`), so a loop
+iteration is one graph replay and nothing else.
 """
 from __future__ import annotations
 
@@ -164,10 +165,18 @@ def run_step(pm: PackedModel, sb: StepBuffers, coef: torch.Tensor, use_noise: bo
 
 
 class StepGraph:
-    """hipGraph of one step; replays read the timestep from sb.t_model / sb.t_coef (device memory)."""
+    """hipGraph of one step; replays read the timestep from sb.t_model / sb.t_coef (device memory).
+    With ``scheduled=True`` the graph starts with `syn_step_advance`: the timestep vectors come from a device-resident
+    schedule (`set_schedule`) and a loop iteration is nothing but `replay()`."""
 
-    def __init__(self, pm: PackedModel, sb: StepBuffers, coef: torch.Tensor, use_noise: bool = True, fused_rng: bool = False):
-        self.pm, self.sb, self.coef = pm, sb, coef
+    MAX_STEPS = 1024
+
+    def __init__(self, pm: PackedModel, sb: StepBuffers, coef: torch.Tensor, use_noise: bool = True, fused_rng: bool = False,
+                 scheduled: bool = False):
+        self.pm, self.sb, self.coef, self.scheduled = pm, sb, coef, scheduled
+        if scheduled:
+            self.sched = torch.zeros(self.MAX_STEPS, 2, dtype=torch.int32, device=pm.device)
+            self.counter = torch.zeros(1, dtype=torch.int32, device=pm.device)
         side = torch.cuda.Stream(device=pm.device)
         side.wait_stream(torch.cuda.current_stream(pm.device))
         with torch.cuda.stream(side):          # warm-up launch outside capture (module load, etc.)
@@ -177,7 +186,20 @@ class StepGraph:
         torch.cuda.current_stream(pm.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
+            if scheduled:
+                _lib.check(_lib.load().syn_step_advance(self.sched.data_ptr(), self.counter.data_ptr(), sb.t_model.data_ptr(),
+                                                        sb.t_model.numel(), sb.t_coef.data_ptr(), sb.t_coef.numel(),
+                                                        _lib.current_stream()), "syn_step_advance")
             run_step(pm, sb, coef, use_noise, fused_rng)
+
+    def set_schedule(self, t_coef_rows, t_model_rows):
+        """Rows of the coefficient table and original timesteps of the coming replays, in order (<= MAX_STEPS)."""
+        n = len(t_coef_rows)
+        if n > self.MAX_STEPS:
+            raise ValueError(f"schedule of {n} steps exceeds {self.MAX_STEPS}")
+        host = torch.tensor(list(zip(t_coef_rows, t_model_rows)), dtype=torch.int32).reshape(-1, 2)
+        self.sched[:n].copy_(host)
+        self.counter.zero_()
 
     def replay(self):
         self.graph.replay()

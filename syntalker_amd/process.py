@@ -269,8 +269,10 @@ class GaussianDiffusion:
             if gkey not in graphs:
                 if len(graphs) > 8:
                     graphs.clear()
-                graphs[gkey] = engine.StepGraph(pm, sb, coef, noisy, fused_rng)
+                graphs[gkey] = engine.StepGraph(pm, sb, coef, noisy, fused_rng, scheduled=True)
             graph = graphs[gkey]
+            indices = list(indices)
+            graph.set_schedule(indices, [int(tmap[i]) for i in indices])     # timesteps advance on the device
             if progress:
                 try:
                     from tqdm.auto import tqdm
@@ -278,8 +280,6 @@ class GaussianDiffusion:
                 except ImportError:
                     pass
             for k, i in enumerate(indices):
-                sb.t_coef.fill_(i)
-                sb.t_model.fill_(tmap[i])
                 if noisy and step_noise is not None:
                     sb.load_noise(step_noise[k].to(dev))
                 graph.replay()
