@@ -24,6 +24,11 @@
 // row-major [token][feature] tensors.  v_mfma_f32_16x16x32_bf16 layouts (gfx950):
 //   A: lane l holds A[i = l&15][k = 8*(l>>4) .. +7]     B: lane l holds B[k = 8*(l>>4) .. +7][j = l&15]
 //   D: lane l, reg r holds D[i = 4*(l>>4) + r][j = l&15]
+//
+// Files: this one holds the token-resident whole-step kernel k_stack (large batches), the A/B kernels, the small
+// kernels and every C-ABI entry point; syn_latency.inc the persistent small-batch kernel k_lat; syn_wavenc.inc the
+// WavEncoder convolutions (per-clip conditioning); syn_train.inc the fp32 forward / backward kernels of the
+// training path.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
