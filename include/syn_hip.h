@@ -159,6 +159,9 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav, int32_t n_clips, int
 /* fp32 row-major W[n][k] (nn.Linear.weight layout) -> packed bf16 fragments (n*k*2 bytes).
  * n % 16 == 0, k % 32 == 0. */
 int syn_pack_weight(const float* w, int32_t n, int32_t k, void* out_packed, void* stream);
+/* Same fragments for W = S^T, S row-major [k][n], fp32 (is_bf16 = 0) or bf16: the training path packs W^T (dgrad) and
+ * x^T (wgrad) without materialising transposed copies. */
+int syn_pack_weight_t(const void* s_kn, int32_t is_bf16, int32_t n, int32_t k, void* out_packed, void* stream);
 
 /* ---- layout at loop entry / exit ----------------------------------------------------------- */
 /* (B,1536,1,32) fp32 -> token-major fp32 (nullable) and bf16 (nullable). */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SYN_HIP_LIB") or os.path.join(_HERE, "csrc", "libsyn_hip.so")   # env override: kernel A/B builds
 
 SYN_LAYERS = 8
-EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_step_profile", "syn_pack_weight", "syn_to_token_major",
+EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_step_profile", "syn_pack_weight", "syn_pack_weight_t", "syn_to_token_major",
            "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_test_gemm", "syn_test_attention",
            "syn_wav_encode", "syn_wav_workspace_bytes", "syn_wav_out_frames",
            "syn_step_advance", "syn_ln_fwd", "syn_ln_bwd", "syn_gelu_fwd", "syn_gelu_bwd", "syn_attn_fwd", "syn_attn_bwd")
@@ -70,6 +70,7 @@ def load():
     lib.syn_denoise_step.argtypes = [C.POINTER(SynModel), C.POINTER(SynStep), vp]
     lib.syn_denoise_step_profile.argtypes = [C.POINTER(SynModel), C.POINTER(SynStep), vp, vp, vp]
     lib.syn_pack_weight.argtypes = [vp, i32, i32, vp, vp]
+    lib.syn_pack_weight_t.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.syn_to_token_major.argtypes = [vp, i32, vp, vp, vp]
     lib.syn_from_token_major.argtypes = [vp, i32, vp, vp]
     lib.syn_axpby_rows.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]

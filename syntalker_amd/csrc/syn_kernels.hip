@@ -1236,6 +1236,21 @@ __global__ void k_pack(const float* __restrict__ W, int N, int K, uint4* __restr
     out[idx] = __builtin_bit_cast(uint4, r);
 }
 
+// Same fragments for W = S^T, S row-major [K][N] in fp32 or bf16: the training path packs W^T (dgrad) and x^T (wgrad)
+// straight from the tensors it already has instead of materialising transposed fp32 copies first.
+template <typename T>
+__global__ void k_pack_t(const T* __restrict__ S, int N, int K, uint4* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int KS = K / 32;
+    if (idx >= (N / 16) * KS * 64) return;
+    const int lane = idx & 63, f = idx >> 6, ks = f % KS, nf = f / KS;
+    const T* src = S + (size_t)(32 * ks + 8 * (lane >> 4)) * N + 16 * nf + (lane & 15);
+    bf16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (__bf16)(float)src[(size_t)e * N];
+    out[idx] = __builtin_bit_cast(uint4, r);
+}
+
 // (B,1536,32) <-> (B,32,1536): 64 channels x 32 frames per block through a padded LDS tile.
 __global__ __launch_bounds__(256) void k_to_token_major(const float* __restrict__ x, float* __restrict__ of,
                                                          __bf16* __restrict__ ob) {
@@ -1470,6 +1485,19 @@ int syn_pack_weight(const float* w, int32_t n, int32_t k, void* out_packed, void
     hipLaunchKernelGGL(k_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, n, k, (uint4*)out_packed);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_pack launch", e);
+}
+
+int syn_pack_weight_t(const void* s_kn, int32_t is_bf16, int32_t n, int32_t k, void* out_packed, void* stream) {
+    if (!s_kn || !out_packed || n % 16 || k % 32) return fail_msg("syn_pack_weight_t: need n%16==0, k%32==0, non-null pointers");
+    const int total = (n / 16) * (k / 32) * 64;
+    if (is_bf16)
+        hipLaunchKernelGGL(k_pack_t<__bf16>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const __bf16*)s_kn, n, k,
+                           (uint4*)out_packed);
+    else
+        hipLaunchKernelGGL(k_pack_t<float>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)s_kn, n, k,
+                           (uint4*)out_packed);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_pack_t launch", e);
 }
 
 int syn_to_token_major(const float* x_bct, int32_t n_clips, float* out_f32, void* out_bf16, void* stream) {

@@ -57,6 +57,22 @@ def hip_matmul_nt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = 
     return y if Np == N else y[:, :N]
 
 
+def _pack_t(src: torch.Tensor, n: int, k: int) -> torch.Tensor:
+    """Packed fragments of W = src^T for a row-major src [k][n] (fp32 or bf16), no transposed copy."""
+    out = torch.empty(n * k * 2, dtype=torch.uint8, device=src.device)
+    _lib.check(_lib.load().syn_pack_weight_t(src.data_ptr(), int(src.dtype is torch.bfloat16), n, k, out.data_ptr(),
+                                             _lib.current_stream()), "syn_pack_weight_t")
+    return out
+
+
+def _gemm_packed(xb: torch.Tensor, wp: torch.Tensor, n: int, k: int) -> torch.Tensor:
+    """fp32 y[M][n] = xb[M][k] (bf16, contiguous) . W^T for packed W[n][k]; n % 512 == 0, k % 128 == 0."""
+    y = torch.empty(xb.shape[0], n, dtype=torch.float32, device=xb.device)
+    _lib.check(_lib.load().syn_linear(xb.data_ptr(), wp.data_ptr(), None, xb.shape[0], n, k, y.data_ptr(), _lib.current_stream()),
+               "syn_linear")
+    return y
+
+
 class HipLinearFn(torch.autograd.Function):
     """y = x W^T + b with forward, dgrad and wgrad on syn_linear."""
 
@@ -73,14 +89,21 @@ class HipLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         xb, w = ctx.saved_tensors
-        N = w.shape[0]
+        N, K = w.shape
+        M = xb.shape[0]
         dy2 = dy.reshape(-1, N)
-        dyb = dy2.to(torch.bfloat16)
+        dyb = dy2.to(torch.bfloat16).contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = hip_matmul_nt(dyb, w.t()).reshape(ctx.in_shape)              # dy . W
+            if K % 512 == 0 and N % 128 == 0 and w.dtype is torch.float32 and w.is_contiguous():
+                dx = _gemm_packed(dyb, _pack_t(w, K, N), K, N).reshape(ctx.in_shape)       # dy . W, W^T packed in place
+            else:
+                dx = hip_matmul_nt(dyb, w.t()).reshape(ctx.in_shape)
         if ctx.needs_input_grad[1]:
-            dw = hip_matmul_nt(dyb.t(), xb.t()).to(w.dtype)                   # dy^T . x  (contraction over tokens)
+            if K % 512 == 0 and M % 128 == 0 and xb.is_contiguous():
+                dw = _gemm_packed(dyb.t().contiguous(), _pack_t(xb, K, M), K, M).to(w.dtype)   # dy^T . x, x^T packed in place
+            else:
+                dw = hip_matmul_nt(dyb.t(), xb.t()).to(w.dtype)                    # contraction over tokens
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy2.sum(0)
         return dx, dw, db
