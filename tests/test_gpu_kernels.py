@@ -152,3 +152,22 @@ def test_training_block_ops_vs_torch_autograd():
     orf = F.scaled_dot_product_attention(t[0], t[1], t[2]).transpose(1, 2).reshape(5, 32, 512)
     rq, = torch.autograd.grad(orf, qkv, up)
     assert rel_l2(o.detach().cpu(), orf.detach().cpu()) < 1e-5 and rel_l2(gq.cpu(), rq.cpu()) < 1e-5
+
+
+def test_wav_encoder_single_channel():
+    """audio_rep variants with one waveform channel (models/denoiser.py:64-67): the first layer has cin = 1."""
+    from syntalker_amd import conditioning
+    from syntalker_amd.denoiser import _WavEncoder
+    torch.manual_seed(5)
+    enc = _WavEncoder(256, 1).eval()
+    with torch.no_grad():
+        for mod in enc.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.uniform_(0.8, 1.2); mod.bias.normal_(0, 0.1)
+    sd = {"WavEncoder." + k: v for k, v in enc.state_dict().items()}
+    blocks = conditioning.fold_wav_encoder(sd)
+    wav = torch.randn(2, 30000, generator=torch.Generator().manual_seed(6))
+    want = conditioning.wav_features(blocks, wav)
+    got = conditioning.HipWavEncoder(blocks, torch.device("cuda"))(wav.to("cuda")).cpu()
+    assert got.shape == want.shape and rel_l2(got, want) < 2e-2
