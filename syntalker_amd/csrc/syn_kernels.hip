@@ -1436,7 +1436,7 @@ int launch_conv(const wav::CArgs& a, int n_clips, hipStream_t s) {
     constexpr int MW = WM * RF * 16, lds = (MW + KT - 1) * (CINP * 2 + 16);
     static bool once = false;
     if (!once) { allow_lds(wav::k_conv<CINP, KT, WN, WM, RF, EPI>, lds); once = true; }
-    hipLaunchKernelGGL((wav::k_conv<CINP, KT, WN, WM, RF, EPI>), dim3((a.L_out + MW - 1) / MW, n_clips), dim3(kThreads), lds, s, a);
+    hipLaunchKernelGGL((wav::k_conv<CINP, KT, WN, WM, RF, EPI>), dim3((a.L_out + MW - 1) / MW, n_clips), dim3(WN * WM * 64), lds, s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv launch", e);
 }
@@ -1659,29 +1659,29 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, 
     wav::CArgs a;
     // block 1: conv1 | shortcut (stride 6 = 3 taps over 6-row groups), conv2 -> x2 (halo: block 2 pads by 7)
     a = base(1); a.X = ws + p.x1; a.x_rows = (p.L1 + 5) / 6; a.L_out = p.L2; a.Z = ws + p.z1; a.z_off = kHalo * 64; a.S = ws + p.s1;
-    if ((rc = launch_conv<384, 3, 2, 4, 2, wav::E_C1SC>(a, n_clips, s))) return rc;
+    if ((rc = launch_conv<384, 3, 2, 2, 2, wav::E_C1SC>(a, n_clips, s))) return rc;
     a = base(2); a.X = ws + p.z1; a.x_rows = p.L2 + 2 * kHalo; a.L_out = p.L2; a.Z = ws + p.x2; a.z_off = kHalo * 64; a.R = ws + p.s1;
-    if ((rc = launch_conv<64, 15, 1, 8, 4, wav::E_C2>(a, n_clips, s))) return rc;
+    if ((rc = launch_conv<64, 15, 1, 4, 4, wav::E_C2>(a, n_clips, s))) return rc;
     // block 2 (identity shortcut): conv1, conv2 + x2 -> x3
     a = base(3); a.X = ws + p.x2; a.x_rows = p.L2 + 2 * kHalo; a.L_out = p.L2; a.Z = ws + p.z2; a.z_off = kHalo * 64;
-    if ((rc = launch_conv<64, 15, 1, 8, 4, wav::E_C1>(a, n_clips, s))) return rc;
+    if ((rc = launch_conv<64, 15, 1, 4, 4, wav::E_C1>(a, n_clips, s))) return rc;
     a = base(4); a.X = ws + p.z2; a.x_rows = p.L2 + 2 * kHalo; a.L_out = p.L2; a.Z = ws + p.x3; a.R = ws + p.x2; a.r_off = kHalo * 64;
-    if ((rc = launch_conv<64, 15, 1, 8, 4, wav::E_C2>(a, n_clips, s))) return rc;
+    if ((rc = launch_conv<64, 15, 1, 4, 4, wav::E_C2>(a, n_clips, s))) return rc;
     // block 3: 64 -> 128, stride 6
     a = base(5); a.X = ws + p.x3; a.x_rows = (p.L2 + 5) / 6; a.L_out = p.L3; a.Z = ws + p.z3; a.z_off = kHalo * 128; a.S = ws + p.s3;
-    if ((rc = launch_conv<384, 3, 4, 2, 4, wav::E_C1SC>(a, n_clips, s))) return rc;
+    if ((rc = launch_conv<384, 3, 4, 1, 4, wav::E_C1SC>(a, n_clips, s))) return rc;
     a = base(6); a.X = ws + p.z3; a.x_rows = p.L3 + 2 * kHalo; a.L_out = p.L3; a.Z = ws + p.x4; a.z_off = kHalo * 128; a.R = ws + p.s3;
-    if ((rc = launch_conv<128, 15, 2, 4, 4, wav::E_C2>(a, n_clips, s))) return rc;
+    if ((rc = launch_conv<128, 15, 2, 2, 4, wav::E_C2>(a, n_clips, s))) return rc;
     // block 4 (identity shortcut)
     a = base(7); a.X = ws + p.x4; a.x_rows = p.L3 + 2 * kHalo; a.L_out = p.L3; a.Z = ws + p.z4; a.z_off = kHalo * 128;
-    if ((rc = launch_conv<128, 15, 2, 4, 4, wav::E_C1>(a, n_clips, s))) return rc;
+    if ((rc = launch_conv<128, 15, 2, 2, 4, wav::E_C1>(a, n_clips, s))) return rc;
     a = base(8); a.X = ws + p.z4; a.x_rows = p.L3 + 2 * kHalo; a.L_out = p.L3; a.Z = ws + p.x5; a.R = ws + p.x4; a.r_off = kHalo * 128;
-    if ((rc = launch_conv<128, 15, 2, 4, 4, wav::E_C2>(a, n_clips, s))) return rc;
+    if ((rc = launch_conv<128, 15, 2, 2, 4, wav::E_C2>(a, n_clips, s))) return rc;
     // block 5: 128 -> 256, stride 3 (5 taps over 3-row groups); conv2 writes the fp32 result
     a = base(9); a.X = ws + p.x5; a.x_rows = (p.L3 + 2) / 3; a.L_out = p.L4; a.Z = ws + p.z5; a.z_off = kHalo * 256; a.S = ws + p.s5;
     if ((rc = launch_conv<384, 5, 8, 1, 4, wav::E_C1SC>(a, n_clips, s))) return rc;
     a = base(10); a.X = ws + p.z5; a.x_rows = p.L4 + 2 * kHalo; a.L_out = p.L4; a.R = ws + p.s5; a.Yf = out; a.yf_clip_stride = (long)p.L4 * 256;
-    if ((rc = launch_conv<256, 15, 4, 2, 4, wav::E_C2>(a, n_clips, s))) return rc;
+    if ((rc = launch_conv<256, 15, 4, 1, 4, wav::E_C2>(a, n_clips, s))) return rc;
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("syn_wav_encode", e);
 }
