@@ -172,8 +172,10 @@ class StepGraph:
     MAX_STEPS = 1024
 
     def __init__(self, pm: PackedModel, sb: StepBuffers, coef: torch.Tensor, use_noise: bool = True, fused_rng: bool = False,
-                 scheduled: bool = False):
-        self.pm, self.sb, self.coef, self.scheduled = pm, sb, coef, scheduled
+                 scheduled: bool = False, steps: int = 1):
+        """``steps`` > 1 (scheduled graphs only): that many consecutive steps per replay - no launch gaps between them."""
+        assert steps == 1 or scheduled
+        self.pm, self.sb, self.coef, self.scheduled, self.steps = pm, sb, coef, scheduled, steps
         if scheduled:
             self.sched = torch.zeros(self.MAX_STEPS, 2, dtype=torch.int32, device=pm.device)
             self.counter = torch.zeros(1, dtype=torch.int32, device=pm.device)
@@ -186,11 +188,12 @@ class StepGraph:
         torch.cuda.current_stream(pm.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            if scheduled:
-                _lib.check(_lib.load().syn_step_advance(self.sched.data_ptr(), self.counter.data_ptr(), sb.t_model.data_ptr(),
-                                                        sb.t_model.numel(), sb.t_coef.data_ptr(), sb.t_coef.numel(),
-                                                        _lib.current_stream()), "syn_step_advance")
-            run_step(pm, sb, coef, use_noise, fused_rng)
+            for _ in range(steps):
+                if scheduled:
+                    _lib.check(_lib.load().syn_step_advance(self.sched.data_ptr(), self.counter.data_ptr(), sb.t_model.data_ptr(),
+                                                            sb.t_model.numel(), sb.t_coef.data_ptr(), sb.t_coef.numel(),
+                                                            _lib.current_stream()), "syn_step_advance")
+                run_step(pm, sb, coef, use_noise, fused_rng)
 
     def set_schedule(self, t_coef_rows, t_model_rows):
         """Rows of the coefficient table and original timesteps of the coming replays, in order (<= MAX_STEPS)."""
@@ -200,6 +203,11 @@ class StepGraph:
         host = torch.tensor(list(zip(t_coef_rows, t_model_rows)), dtype=torch.int32).reshape(-1, 2)
         self.sched[:n].copy_(host)
         self.counter.zero_()
+
+    def copy_schedule_from(self, other: "StepGraph"):
+        """Continue `other`'s schedule where it stands (a multi-step graph handing over to the single-step one)."""
+        self.sched.copy_(other.sched)
+        self.counter.copy_(other.counter)
 
     def replay(self):
         self.graph.replay()

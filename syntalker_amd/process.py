@@ -264,22 +264,38 @@ class GaussianDiffusion:
             fused_rng = noisy and step_noise is None     # noise drawn inside the output GEMM's epilogue
             if fused_rng:
                 sb.set_rng(seed, first_clip)
-            gkey = ("graph", id(pm), id(sb), coef.data_ptr(), noisy, fused_rng)
             graphs = mdm.__dict__.setdefault("_graphs", {})
-            if gkey not in graphs:
-                if len(graphs) > 8:
-                    graphs.clear()
-                graphs[gkey] = engine.StepGraph(pm, sb, coef, noisy, fused_rng, scheduled=True)
-            graph = graphs[gkey]
+
+            def graph_of(steps):
+                gkey = ("graph", id(pm), id(sb), coef.data_ptr(), noisy, fused_rng, steps)
+                if gkey not in graphs:
+                    if len(graphs) > 8:
+                        graphs.clear()
+                    graphs[gkey] = engine.StepGraph(pm, sb, coef, noisy, fused_rng, scheduled=True, steps=steps)
+                return graphs[gkey]
+
             indices = list(indices)
-            graph.set_schedule(indices, [int(tmap[i]) for i in indices])     # timesteps advance on the device
+            sched = (indices, [int(tmap[i]) for i in indices])              # timesteps advance on the device
+            hooks = each is not None or (noisy and step_noise is not None) or progress
+            CH = 10                                                         # steps per replay when nothing happens in between
+            n_multi = 0 if hooks or sb.B * sb.V > 64 else len(indices) // CH
+            graph = graph_of(1)                                             # (both captured before the loop starts)
+            if n_multi:
+                multi = graph_of(CH)
+                multi.set_schedule(*sched)
+                for _ in range(n_multi):
+                    multi.replay()
+                graph.copy_schedule_from(multi)
+            else:
+                graph.set_schedule(*sched)
+            rest = indices[n_multi * CH:]
             if progress:
                 try:
                     from tqdm.auto import tqdm
-                    indices = tqdm(indices)
+                    rest = tqdm(rest)
                 except ImportError:
                     pass
-            for k, i in enumerate(indices):
+            for k, i in enumerate(rest):
                 if noisy and step_noise is not None:
                     sb.load_noise(step_noise[k].to(dev))
                 graph.replay()
