@@ -934,21 +934,87 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
     f32x4 h[4][MF];
     if (a.in.X != nullptr) {
         // ---- input stage: h = rotary(x_t . A^T + cond + te[t]); K = 1536 streamed through region B ----------
+        // x_t goes through LDS 512 columns at a time, in the same swizzled row layout LayerNorm writes, alternating
+        // between XN and region B, so that the three K pieces run on the barrier-free loop of the blocks (a 64-column
+        // tile per barrier, as the stand-alone GEMM does it, spends more time in barriers than in MFMAs here).
+        // A wave copies one whole row per instruction: 1 KB contiguous from HBM, 64 distinct LDS slots.
+        {
+            constexpr int KSI = SYN_C / 32, NCH = SYN_C / 512;
+            constexpr int RW = MT / 8;     // rows per wave
+            const uint4* wi = a.in.W + ((size_t)(wave * 4) * KSI) * 64 + lane;
+            int sl = lane;
+            asm volatile("" : "+v"(sl));
+            uint4 st[RW];
+            auto load = [&](int c) {
 #pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-            const int m = m0 + mf * 16 + lr;
-            const bool ok = m < a.M;
-            const int ts = ok ? a.in.t_model[m >> 5] : 0;
+                for (int i = 0; i < RW; ++i) {
+                    const int m = m0 + wave + 8 * i;
+                    const int rm = m < a.in.x_rows ? m : m % a.in.x_rows;
+                    st[i] = m < a.M ? *reinterpret_cast<const uint4*>(a.in.X + (size_t)rm * a.in.ldx + c * 512 + sl * 8)
+                                    : make_uint4(0, 0, 0, 0);
+                }
+            };
+            auto store = [&](char* buf) {
 #pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-                const int n = wave * 64 + nf * 16 + g * 4;
-                f32x4 c = {0.f, 0.f, 0.f, 0.f};
-                if (ok) c = *reinterpret_cast<const f32x4*>(a.in.cond + (size_t)m * kNT + n);
-                h[nf][mf] = c + *reinterpret_cast<const f32x4*>(a.in.te + (size_t)ts * kNT + n);
+                for (int i = 0; i < RW; ++i) {
+                    const int r = wave + 8 * i;
+                    *reinterpret_cast<uint4*>(buf + r * 1024 + ((sl ^ (r & 15)) << 4)) = st[i];
+                }
+            };
+            uint4 ri[4][4];
+            load(0);
+            kloop_prime<4, 1, 16, 4>(ri, wi, KSI, 0);
+            {
+                // h starts as conditioning + time row.  The conditioning tile (128 KB per workgroup) is read with 16
+                // lanes on 256 contiguous bytes of a row and turned into the fragment layout through region B (free
+                // until the second K piece lands there); read in the fragment layout directly it moves at a third of
+                // the rate (16 half cache lines per instruction).
+                const int er = sl >> 4, ec = (sl & 15) * 4;
+                float* const T = reinterpret_cast<float*>(RB) + wave * (16 * 68);
+                f32x4 cq[2][4];
+                auto cfetch = [&](int mf, int slot) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = min(m0 + mf * 16 + i * 4 + er, a.M - 1);
+                        cq[slot][i] = *reinterpret_cast<const f32x4*>(a.in.cond + (size_t)m * kNT + wave * 64 + ec);
+                    }
+                };
+                cfetch(0, 0);
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) {
+                    if (mf + 1 < MF) cfetch(mf + 1, (mf + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int ts = a.in.t_model[min(m0 + mf * 16, a.M - 1) >> 5];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(T + (i * 4 + er) * 68 + ec) = cq[mf & 1][i];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int nf = 0; nf < 4; ++nf) {
+                        const f32x4 cv = *reinterpret_cast<const f32x4*>(T + lr * 68 + nf * 16 + g * 4);
+                        const f32x4 tv = *reinterpret_cast<const f32x4*>(a.in.te + (size_t)ts * kNT + wave * 64 + nf * 16 + g * 4);
+                        h[nf][mf] = (m0 + mf * 16 + lr < a.M ? cv : f32x4{0.f, 0.f, 0.f, 0.f}) + tv;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            store(XN);
+            load(1);
+            __syncthreads();
+            if (a.dbg) stamp(a.dbg, 17);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                char* const cur = (c & 1) ? RB : XN;
+                char* const nxt = (c & 1) ? XN : RB;
+                kloop_run<MF, 4, 1, 0, 16, 1024, 4>(h, ri, cur, wi, KSI, c * 16);
+                if (a.dbg) stamp(a.dbg, 18 + c);
+                if (c + 1 < NCH) {
+                    kloop_prime<4, 1, 16, 4>(ri, wi, KSI, (c + 1) * 16);
+                    store(nxt);
+                    if (c + 2 < NCH) load(c + 2);
+                    __syncthreads();
+                }
             }
         }
-        gemm_mainloop<MT, 4, 1, 0>(h, a.in.X, a.in.ldx, a.in.x_rows, m0, a.M, a.in.K,
-                                   a.in.W + ((size_t)(wave * 4) * (a.in.K / 32)) * 64 + lane, RB);
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
             const int pos = (m0 + mf * 16 + lr) & 31;
@@ -1141,25 +1207,53 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
             kloop_prime<4, 1, KS1, 4>(ro, wo, KS1, 0);
             kloop_run<MF, 4, 1, 0, KS1, 1024, 4>(acc, ro, XN, wo, KS1, 0);
             if (a.dbg) stamp(a.dbg, 11 + 2 * c);
-            const int ncol = c * kNT + wave * 64;
+            // Epilogue.  An accumulator fragment holds 4 features of 16 tokens per lane, which would touch global
+            // memory as 16 half cache lines per instruction; each wave turns its 16 x 64 tile through LDS (region B is
+            // free here) so that 16 consecutive lanes cover 256 contiguous bytes of one row.  x_t of a row tile is
+            // requested one tile ahead: this is a read-modify-write of 960 KB per workgroup and every workgroup of the
+            // chip is in it at the same time.
+            int el = lane;
+            asm volatile("" : "+v"(el));       // keeps the row addresses below out of the registers live across the GEMM
+            const int er = el >> 4, ec = (el & 15) * 4, ncol = c * kNT + wave * 64 + ec;
+            float* const T = reinterpret_cast<float*>(RB) + wave * (16 * 68);
+            const bool nz_buf = a.out.noise != nullptr, nz_rng = !nz_buf && a.out.rng != nullptr;
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(a.out.bias + ncol);
+            f32x4 xt[2][4];
+            auto fetch = [&](int mf, int slot) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = min(m0 + mf * 16 + i * 4 + er, a.M - 1);
+                    xt[slot][i] = *reinterpret_cast<const f32x4*>(a.out.Xt + (size_t)m * SYN_C + ncol);
+                }
+            };
+            fetch(0, 0);
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
-                const int m = m0 + mf * 16 + lr;
-                if (m >= a.M) continue;
-                const int tc = a.out.t_coef[m >> 5];
+                if (mf + 1 < MF) fetch(mf + 1, (mf + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nf = 0; nf < 4; ++nf) *reinterpret_cast<f32x4*>(T + lr * 68 + nf * 16 + g * 4) = acc[nf][mf];
+                __builtin_amdgcn_wave_barrier();
+                f32x4 av[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const f32x4*>(T + (i * 4 + er) * 68 + ec);
+                __builtin_amdgcn_wave_barrier();
+                const int tc = a.out.t_coef[min(m0 + mf * 16, a.M - 1) >> 5];
                 const f32x4 cf = *reinterpret_cast<const f32x4*>(a.out.coef + (size_t)tc * 4);
 #pragma unroll
-                for (int nf = 0; nf < 4; ++nf) {
-                    const int n = ncol + nf * 16 + g * 4;
-                    const size_t off = (size_t)m * SYN_C + n;
-                    const f32x4 x0 = acc[nf][mf] + *reinterpret_cast<const f32x4*>(a.out.bias + n);
-                    const f32x4 xt = *reinterpret_cast<const f32x4*>(a.out.Xt + off);
-                    f32x4 xn = x0 * cf[0] + xt * cf[1];
-                    if (a.out.noise) xn = xn + *reinterpret_cast<const f32x4*>(a.out.noise + off) * cf[2];
-                    else if (a.out.rng) xn = xn + randn4(a.out.rng[0], (uint64_t)tc, (a.out.rng[1] * (uint64_t)(SYN_T * SYN_C) + off) >> 2) * cf[2];
-                    *reinterpret_cast<f32x4*>(a.out.Xn + off) = xn;
-                    *reinterpret_cast<bf16x4*>(a.out.Xnb + off) = to_bf16x4(xn);
-                    if (a.out.X0) *reinterpret_cast<f32x4*>(a.out.X0 + off) = x0;
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + mf * 16 + i * 4 + er;
+                    const bool ok = m < a.M;
+                    const size_t off = (size_t)m * SYN_C + ncol;
+                    const f32x4 x0 = av[i] + bias;
+                    f32x4 xn = x0 * cf[0] + xt[mf & 1][i] * cf[1];
+                    if (nz_buf) xn = xn + *reinterpret_cast<const f32x4*>(a.out.noise + (ok ? off : 0)) * cf[2];
+                    else if (nz_rng) xn = xn + randn4(a.out.rng[0], (uint64_t)tc, (a.out.rng[1] * (uint64_t)(SYN_T * SYN_C) + off) >> 2) * cf[2];
+                    if (ok) {
+                        *reinterpret_cast<f32x4*>(a.out.Xn + off) = xn;
+                        *reinterpret_cast<bf16x4*>(a.out.Xnb + off) = to_bf16x4(xn);
+                        if (a.out.X0) *reinterpret_cast<f32x4*>(a.out.X0 + off) = x0;
+                    }
                 }
             }
             if (a.dbg) stamp(a.dbg, 12 + 2 * c);
