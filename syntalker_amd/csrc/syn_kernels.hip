@@ -300,11 +300,11 @@ __device__ __forceinline__ f32x4 randn4(uint64_t seed, uint64_t stream_id, uint6
     for (int p = 0; p < 2; ++p) {
         const float u1 = ((float)c[2 * p] + 0.5f) * inv32;           // (0,1)
         const float u2 = ((float)c[2 * p + 1] + 0.5f) * inv32;
-        const float rad = sqrtf(-2.0f * __logf(u1));
-        float sn, cs;
-        __sincosf(6.283185307179586f * u2, &sn, &cs);
-        z[2 * p] = rad * cs;
-        z[2 * p + 1] = rad * sn;
+        // hardware transcendentals as they are: v_log_f32 is log2 (u1 >= 2^-33 is a normal number, so none of the
+        // library's denormal scaling is needed), v_sin/v_cos take their argument in revolutions
+        const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+        z[2 * p] = rad * __builtin_amdgcn_cosf(u2);
+        z[2 * p + 1] = rad * __builtin_amdgcn_sinf(u2);
     }
     return z;
 }
