@@ -178,6 +178,32 @@ int syn_axpby_rows(const float* x, const float* y, const float* coef_ab /*[n][2]
  * for any batch sharding across GPUs.  n % 4 == 0. */
 int syn_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t first_index, void* stream);
 
+/* ---- RVQ-VAE either side of the loop (eval mode) ---------------------------------------------
+ * One Conv1d of models/vq/encdec.py / resnet.py on channels-last activations:
+ *   out[t][co] = bias[co] + sum_{tap,ci} W[co][ci][tap] * relu_in?(in[(t*stride + tap*dil - pad) >> up][ci])  (+ resid[t][co])
+ * x_bf16 [clips][t_in][cin] (MFMA operand), outputs fp32 [clips][t_out][ldy] (first cout_valid channels) and/or bf16
+ * [clips][t_out][cout].  w_packed: fragments [taps][cout/16][cin/32][64 lanes][8 bf16] (host: rvqvae.pack_conv).
+ * up = 1 folds nn.Upsample(scale_factor=2, nearest) (encdec.py:56) into the read.  cin % 32 == 0, cout % 128 == 0
+ * (callers zero-pad; cout_valid = real channel count). */
+typedef struct syn_vq_conv {
+    const void*  w_packed;
+    const float* bias;            /* [cout] */
+    int32_t cin, cout, cout_valid, taps, stride, dil, pad, up, relu_in, relu_out;
+} syn_vq_conv;
+int syn_vq_conv1d(const syn_vq_conv* cv, const void* x_bf16, const float* resid, float* y_f32, int32_t ldy, void* y_bf16,
+                  int32_t clips, int32_t t_in, int32_t t_out, void* stream);
+
+/* ResidualVQ.forward in eval mode (models/vq/residual_vq.py:91-140 over quantizer.py:62-69,143-171), fp32, 6 layers
+ * of 512 codes x 512 dims: x [rows][512] -> q_f32 / q_bf16 [rows][512] (sum of the straight-through outputs), idx
+ * [rows][6], sqerr [syn_vq_quantize_groups(rows)][6] (per-group sums of |residual - code|^2: commit loss numerators),
+ * hist [6][512] (code usage for the perplexity; the caller zeroes it).  codebooks [6][512][512], codebooks_t
+ * [6][dim][code] (transposed), code_sq [6][512] = |code|^2. */
+int32_t syn_vq_quantize_groups(int32_t rows);
+int syn_vq_quantize(const float* x, const float* codebooks, const float* codebooks_t, const float* code_sq, float* q_f32,
+                    void* q_bf16, int32_t* idx, float* sqerr, int32_t* hist, int32_t rows, void* stream);
+/* Sum of the codes of given indices (RVQVAE.forward_decoder, models/vq/model.py:86-89): idx [rows][n_q], -1 = no code. */
+int syn_vq_codes(const int32_t* idx, const float* codebooks, float* q_f32, void* q_bf16, int32_t rows, int32_t n_q, void* stream);
+
 /* ---- training building block ------------------------------------------------------------------------
  * y[m][n] = sum_k x[m][k] * W[n][k] (+ bias[n]): nn.Linear forward on the MFMA GEMM (bf16 operands, fp32 accumulate
  * and output).  The same entry point serves the backward passes with re-packed operands:

@@ -16,6 +16,7 @@ SYN_LAYERS = 8
 EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_step_profile", "syn_pack_weight", "syn_pack_weight_t", "syn_to_token_major",
            "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_test_gemm", "syn_test_attention",
            "syn_wav_encode", "syn_wav_workspace_bytes", "syn_wav_out_frames",
+           "syn_vq_conv1d", "syn_vq_quantize", "syn_vq_quantize_groups", "syn_vq_codes",
            "syn_step_advance", "syn_ln_fwd", "syn_ln_bwd", "syn_gelu_fwd", "syn_gelu_bwd", "syn_attn_fwd", "syn_attn_bwd")
 
 vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
@@ -46,6 +47,11 @@ class SynWavConv(C.Structure):
 
 class SynWavEnc(C.Structure):
     _fields_ = [("cin", i32), ("reserved", i32), ("w_first", vp), ("conv", SynWavConv * 11)]
+
+
+class SynVqConv(C.Structure):
+    _fields_ = [("w_packed", vp), ("bias", vp), ("cin", i32), ("cout", i32), ("cout_valid", i32), ("taps", i32),
+                ("stride", i32), ("dil", i32), ("pad", i32), ("up", i32), ("relu_in", i32), ("relu_out", i32)]
 
 
 class SynHipError(RuntimeError):
@@ -88,6 +94,10 @@ def load():
     lib.syn_wav_encode.argtypes = [C.POINTER(SynWavEnc), vp, i32, i32, vp, vp, vp]
     lib.syn_wav_workspace_bytes.argtypes = [i32, i32]
     lib.syn_wav_out_frames.argtypes = [i32]
+    lib.syn_vq_conv1d.argtypes = [C.POINTER(SynVqConv), vp, vp, vp, i32, vp, i32, i32, i32, vp]
+    lib.syn_vq_quantize_groups.argtypes = [i32]
+    lib.syn_vq_quantize.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.syn_vq_codes.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("syn_version", "syn_last_error", "syn_wav_workspace_bytes"):

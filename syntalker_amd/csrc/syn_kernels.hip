@@ -1499,6 +1499,7 @@ int launch_stack(const SArgs& a, int mt, hipStream_t s) {
 #include "syn_latency.inc"
 #include "syn_wavenc.inc"
 #include "syn_train.inc"
+#include "syn_rvq.inc"
 
 // ---- WavEncoder forward: lengths, workspace layout and the 12 launches ----------------------------------------
 struct WavPlan {
@@ -1617,6 +1618,51 @@ int syn_axpby_rows(const float* x, const float* y, const float* coef_ab, const i
                        t_row, n4, per_clip / 4, out);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_axpby_rows launch", e);
+}
+
+// ---- RVQ-VAE (syn_rvq.inc) ----------------------------------------------------------------------------------------
+int syn_vq_conv1d(const syn_vq_conv* cv, const void* x_bf16, const float* resid, float* y_f32, int32_t ldy, void* y_bf16,
+                  int32_t clips, int32_t t_in, int32_t t_out, void* stream) {
+    if (!cv || !cv->w_packed || !cv->bias || !x_bf16 || (!y_f32 && !y_bf16) || clips <= 0 || t_in <= 0 || t_out <= 0)
+        return fail_msg("syn_vq_conv1d: bad arguments");
+    if (cv->cin % 32 || cv->cout % 128 || cv->taps < 1 || cv->stride < 1 || cv->dil < 1 || cv->up < 0 || cv->up > 1)
+        return fail_msg("syn_vq_conv1d: cin must be a multiple of 32, cout of 128, up 0 or 1");
+    rvq::CvArgs a;
+    a.X = (const __bf16*)x_bf16; a.W = (const uint4*)cv->w_packed; a.bias = cv->bias; a.R = resid; a.Yf = y_f32; a.Yb = (__bf16*)y_bf16;
+    a.t_in = t_in; a.t_out = t_out; a.cin = cv->cin; a.cout = cv->cout; a.cout_valid = cv->cout_valid; a.ldy = ldy;
+    a.taps = cv->taps; a.stride = cv->stride; a.dil = cv->dil; a.pad = cv->pad; a.up = cv->up; a.relu_in = cv->relu_in; a.relu_out = cv->relu_out;
+    const int mf = (t_out <= 32 || cv->stride > 1) ? 2 : 4, mt = mf * 16;
+    const int rows = (((mt - 1) * cv->stride + (cv->taps - 1) * cv->dil) >> cv->up) + 2;
+    const int lds = rows * (cv->cin * 2 + 16);
+    if (lds > 160 * 1024) return fail_msg("syn_vq_conv1d: input window does not fit LDS");
+    static bool once = false;
+    if (!once) { allow_lds(rvq::k_conv1d<2>, 160 * 1024); allow_lds(rvq::k_conv1d<4>, 160 * 1024); once = true; }
+    const dim3 grid((t_out + mt - 1) / mt, cv->cout / 128, clips);
+    if (mf == 2) hipLaunchKernelGGL(rvq::k_conv1d<2>, grid, dim3(rvq::kCvThreads), lds, (hipStream_t)stream, a);
+    else         hipLaunchKernelGGL(rvq::k_conv1d<4>, grid, dim3(rvq::kCvThreads), lds, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv1d launch", e);
+}
+
+int32_t syn_vq_quantize_groups(int32_t rows) { return (rows + rvq::kQRows - 1) / rvq::kQRows; }
+
+int syn_vq_quantize(const float* x, const float* codebooks, const float* codebooks_t, const float* code_sq, float* q_f32,
+                    void* q_bf16, int32_t* idx, float* sqerr, int32_t* hist, int32_t rows, void* stream) {
+    if (!x || !codebooks || !codebooks_t || !code_sq || !q_f32 || !idx || !sqerr || !hist || rows <= 0)
+        return fail_msg("syn_vq_quantize: bad arguments");
+    rvq::QArgs a;
+    a.X = x; a.CB = codebooks; a.CBT = codebooks_t; a.CC = code_sq; a.Qf = q_f32; a.Qb = (__bf16*)q_bf16; a.idx = idx;
+    a.sqerr = sqerr; a.hist = hist; a.rows = rows;
+    hipLaunchKernelGGL(rvq::k_quantize, dim3(syn_vq_quantize_groups(rows)), dim3(rvq::kQThreads), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_quantize launch", e);
+}
+
+int syn_vq_codes(const int32_t* idx, const float* codebooks, float* q_f32, void* q_bf16, int32_t rows, int32_t n_q, void* stream) {
+    if (!idx || !codebooks || !q_f32 || rows <= 0 || n_q < 1 || n_q > rvq::kQ) return fail_msg("syn_vq_codes: bad arguments");
+    hipLaunchKernelGGL(rvq::k_codes, dim3(rows), dim3(rvq::kDim), 0, (hipStream_t)stream, idx, codebooks, q_f32, (__bf16*)q_bf16, rows, n_q);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_codes launch", e);
 }
 
 int syn_step_advance(const int32_t* sched, int32_t* counter, int32_t* t_model, int32_t n_t_model, int32_t* t_coef, int32_t n_t_coef,

@@ -1,0 +1,253 @@
+"""RVQ-VAE either side of the denoising loop: the reference's ``models.vq.model.RVQVAE`` surface on the
+HIP kernels of csrc/syn_rvq.inc.
+
+Same constructor arguments, same ``state_dict`` keys (a trained ``net`` checkpoint of the reference loads with
+``load_state_dict``, diffusion_rvqvae_trainer.py:153-155), same entry points and shapes:
+  map2latent(pose (N,T,D))            -> (N, T/4, 512)                      models/vq/model.py:95-100
+  latent2origin(latent (N,T/4,512))   -> ((N,T,D), commit loss, perplexity) :102-109
+  encode(pose)                        -> (indices (N,T/4,6), codes (6,N,512,T/4))   :53-65
+  forward_decoder(indices)            -> (N,T,D)                            :86-93
+Inference only (the reference keeps these models in eval(), trainer :159-161, :174-177).  CUDA(ROCm) tensors only:
+there is no CPU fallback, a missing extension raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib, synth
+
+NUM_Q, NB_CODE, CODE_DIM = 6, 512, 512
+
+
+def _conv_specs(dim, width=512, down_t=2, depth=3, growth=3):
+    """(key, cin, cout, taps, stride, dil, pad) of every Conv1d, in state_dict order (models/vq/encdec.py, resnet.py)."""
+    enc = [("encoder.model.0", dim, width, 3, 1, 1, 1)]
+    dec = [("decoder.model.0", width, width, 3, 1, 1, 1)]
+    for i in range(down_t):
+        enc.append((f"encoder.model.{2 + i}.0", width, width, 4, 2, 1, 1))
+        for j in range(depth):
+            d = growth ** (depth - 1 - j)                                  # reverse_dilation: 9, 3, 1
+            enc.append((f"encoder.model.{2 + i}.1.model.{j}.conv1", width, width, 3, 1, d, d))
+            enc.append((f"encoder.model.{2 + i}.1.model.{j}.conv2", width, width, 1, 1, 1, 0))
+            dec.append((f"decoder.model.{2 + i}.0.model.{j}.conv1", width, width, 3, 1, d, d))
+            dec.append((f"decoder.model.{2 + i}.0.model.{j}.conv2", width, width, 1, 1, 1, 0))
+        dec.append((f"decoder.model.{2 + i}.2", width, width, 3, 1, 1, 1))
+    enc.append((f"encoder.model.{2 + down_t}", width, width, 3, 1, 1, 1))
+    dec.append((f"decoder.model.{2 + down_t}", width, width, 3, 1, 1, 1))
+    dec.append((f"decoder.model.{4 + down_t}", width, dim, 3, 1, 1, 1))
+    return enc, dec
+
+
+def _register(root: nn.Module, key: str, value: torch.Tensor, buffer=False):
+    """Create the nested (empty) modules a dotted state_dict key implies and hang the tensor on the leaf."""
+    *path, leaf = key.split(".")
+    m = root
+    for p in path:
+        if p not in m._modules:
+            m.add_module(p, nn.Module())
+        m = m._modules[p]
+    if buffer:
+        m.register_buffer(leaf, value)
+    else:
+        m.register_parameter(leaf, nn.Parameter(value, requires_grad=False))
+
+
+def pack_conv(w: torch.Tensor, cin_p: int, cout_p: int) -> torch.Tensor:
+    """Conv1d weight (cout, cin, taps) -> MFMA A-operand fragments [taps][cout_p/16][cin_p/32][lane = g*16 + r][8] bf16:
+    lane (r, g) of fragment (tap, co/16, ci/32) holds W[co = 16*f + r][ci = 32*ks + 8*g .. +7][tap]."""
+    cout, cin, taps = w.shape
+    wp = torch.zeros(taps, cout_p, cin_p, dtype=torch.float32, device=w.device)
+    wp[:, :cout, :cin] = w.permute(2, 0, 1)
+    wp = wp.view(taps, cout_p // 16, 16, cin_p // 32, 4, 8).permute(0, 1, 3, 4, 2, 5)
+    return wp.contiguous().to(torch.bfloat16)
+
+
+def _up(n, m):
+    return (n + m - 1) // m * m
+
+
+class RVQVAE(nn.Module):
+    def __init__(self, args, input_width=263, nb_code=1024, code_dim=512, output_emb_width=512, down_t=3, stride_t=2,
+                 width=512, depth=3, dilation_growth_rate=3, activation="relu", norm=None):
+        super().__init__()
+        if (nb_code, code_dim, output_emb_width, width, stride_t) != (NB_CODE, CODE_DIM, CODE_DIM, 512, 2) or down_t != 2 \
+                or depth != 3 or dilation_growth_rate != 3 or activation != "relu" or norm is not None \
+                or getattr(args, "num_quantizers", NUM_Q) != NUM_Q or getattr(args, "shared_codebook", False):
+            raise NotImplementedError("RVQVAE: built for the configuration diffusion_rvqvae_trainer.py:89-103 constructs "
+                                      "(6 x 512 codes of 512 dims, width 512, down_t 2, depth 3, ReLU, no norm)")
+        self.code_dim, self.num_code, self.input_width = code_dim, nb_code, input_width
+        self._enc, self._dec = _conv_specs(input_width)
+        for key, cin, cout, taps, *_ in self._enc + self._dec:
+            _register(self, key + ".weight", torch.zeros(cout, cin, taps))
+            _register(self, key + ".bias", torch.zeros(cout))
+        for q in range(NUM_Q):
+            _register(self, f"quantizer.layers.{q}.codebook", torch.zeros(nb_code, code_dim), buffer=True)
+        self._packed = None
+        self.eval()
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("RVQVAE is an inference module here (the reference keeps it in eval(), trainer :159-161)")
+        return super().train(False)
+
+    # ---- device-side parameters ----------------------------------------------------------------------------------
+    def packed(self):
+        """Fragment-packed conv weights, padded biases, codebook views; rebuilt when a parameter changes."""
+        sd = self.state_dict()
+        ver = tuple((v._version, v.data_ptr()) for v in sd.values())
+        if self._packed is not None and self._packed["ver"] == ver:
+            return self._packed
+        dev = sd["decoder.model.0.weight"].device
+        if dev.type != "cuda":
+            raise _lib.SynHipError("RVQVAE runs on the HIP kernels only: move the module to the GPU (no CPU fallback)")
+        _lib.load()
+        convs = {}
+        for key, cin, cout, taps, stride, dil, pad in self._enc + self._dec:
+            cin_p, cout_p = _up(cin, 32), _up(cout, 128)
+            w = pack_conv(sd[key + ".weight"].float(), cin_p, cout_p)
+            b = torch.zeros(cout_p, device=dev)
+            b[:cout] = sd[key + ".bias"].float()
+            cv = _lib.SynVqConv(w.data_ptr(), b.data_ptr(), cin_p, cout_p, cout, taps, stride, dil, pad, 0, 0, 0)
+            convs[key] = (cv, w, b)
+        cb = torch.stack([sd[f"quantizer.layers.{q}.codebook"].float() for q in range(NUM_Q)]).contiguous()
+        self._packed = {"ver": ver, "convs": convs, "cb": cb, "cbt": cb.transpose(1, 2).contiguous(),
+                        "cc": torch.sum(cb.transpose(1, 2) ** 2, dim=1).contiguous()}       # quantizer.py:66: sum(k_w**2, dim=0)
+        return self._packed
+
+    def _conv(self, key, x_b, t_in, t_out, clips, *, resid=None, want_f32=True, want_b16=True, relu_in=False, relu_out=False,
+              up=0, ldy=None):
+        cv, _, _ = self.packed()["convs"][key]
+        cv.up, cv.relu_in, cv.relu_out = up, int(relu_in), int(relu_out)
+        dev = x_b.device
+        ldy = cv.cout if ldy is None else ldy
+        yf = torch.empty(clips, t_out, ldy, device=dev) if want_f32 else None
+        yb = torch.empty(clips, t_out, cv.cout, device=dev, dtype=torch.bfloat16) if want_b16 else None
+        _lib.check(_lib.load().syn_vq_conv1d(C.byref(cv), x_b.data_ptr(), _lib.ptr(resid), _lib.ptr(yf), ldy, _lib.ptr(yb), clips,
+                                             t_in, t_out, torch.cuda.current_stream().cuda_stream), "syn_vq_conv1d")
+        return yf, yb
+
+    def _resnet(self, key, xf, xb, t, n):
+        for j in range(3):
+            _, hb = self._conv(f"{key}.model.{j}.conv1", xb, t, t, n, want_f32=False, relu_in=True)
+            xf, xb = self._conv(f"{key}.model.{j}.conv2", hb, t, t, n, resid=xf, relu_in=True)
+        return xf, xb
+
+    def _encoder(self, pose):
+        n, t, d = pose.shape
+        if t % 4:
+            raise ValueError("RVQVAE: the number of frames must be a multiple of 4 (two stride-2 stages)")
+        cin_p = _up(d, 32)
+        xb = torch.zeros(n, t, cin_p, device=pose.device, dtype=torch.bfloat16)
+        xb[..., :d] = pose
+        xf, xb = self._conv("encoder.model.0", xb, t, t, n, relu_out=True)
+        for i in range(2):
+            xf, xb = self._conv(f"encoder.model.{2 + i}.0", xb, t, t // 2, n)
+            t //= 2
+            xf, xb = self._resnet(f"encoder.model.{2 + i}.1", xf, xb, t, n)
+        yf, _ = self._conv("encoder.model.4", xb, t, t, n, want_b16=False)
+        return yf                                                           # (N, T/4, 512)
+
+    def _decoder(self, qb, n, t):
+        xf, xb = self._conv("decoder.model.0", qb, t, t, n, relu_out=True)
+        for i in range(2):
+            xf, xb = self._resnet(f"decoder.model.{2 + i}.0", xf, xb, t, n)
+            xf, xb = self._conv(f"decoder.model.{2 + i}.2", xb, t, 2 * t, n, up=1)
+            t *= 2
+        _, xb = self._conv("decoder.model.4", xb, t, t, n, want_f32=False, relu_out=True)
+        yf, _ = self._conv("decoder.model.6", xb, t, t, n, want_b16=False, ldy=self.input_width)
+        return yf                                                           # (N, 4 T', D)
+
+    def _quantize(self, lat):
+        """lat (N, T', 512) fp32 -> quantised fp32 + bf16 rows, indices (N, T', 6), commit loss, perplexity."""
+        p = self.packed()
+        lib = _lib.load()
+        n, t, c = lat.shape
+        rows = n * t
+        x = lat.contiguous().float()
+        qf = torch.empty(rows, c, device=x.device)
+        qb = torch.empty(rows, c, device=x.device, dtype=torch.bfloat16)
+        idx = torch.empty(rows, NUM_Q, device=x.device, dtype=torch.int32)
+        sq = torch.empty(lib.syn_vq_quantize_groups(rows), NUM_Q, device=x.device)
+        hist = torch.zeros(NUM_Q, NB_CODE, device=x.device, dtype=torch.int32)
+        _lib.check(lib.syn_vq_quantize(x.data_ptr(), p["cb"].data_ptr(), p["cbt"].data_ptr(), p["cc"].data_ptr(), qf.data_ptr(),
+                                       qb.data_ptr(), idx.data_ptr(), sq.data_ptr(), hist.data_ptr(), rows,
+                                       torch.cuda.current_stream().cuda_stream), "syn_vq_quantize")
+        commit = (sq.sum(0) / (rows * c)).mean()                            # F.mse_loss per layer, mean over layers (:137)
+        prob = hist.float() / rows
+        perp = torch.exp(-(prob * torch.log(prob + 1e-7)).sum(1)).mean()   # quantizer.py:84-90, residual_vq.py:138
+        return qf.view(n, t, c), qb.view(n, t, c), idx.view(n, t, NUM_Q).long(), commit, perp
+
+    # ---- the reference's entry points ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def map2latent(self, x):
+        return self._encoder(x.float())
+
+    @torch.no_grad()
+    def latent2origin(self, x):
+        n, t, _ = x.shape
+        _, qb, _, commit, perp = self._quantize(x)
+        return self._decoder(qb, n, t), commit, perp
+
+    @torch.no_grad()
+    def encode(self, x):
+        lat = self._encoder(x.float())
+        n, t, c = lat.shape
+        _, _, idx, _, _ = self._quantize(lat)
+        cb = self.packed()["cb"]
+        res, codes = lat.reshape(n * t, c), []
+        for q in range(NUM_Q):                                              # the per-layer straight-through outputs (:150-160)
+            cq = cb[q][idx[..., q].reshape(-1)]
+            qd = res + (cq - res)
+            res = res - qd
+            codes.append(qd.view(n, t, c).permute(0, 2, 1))
+        return idx, torch.stack(codes, dim=0)
+
+    @torch.no_grad()
+    def forward_decoder(self, x):
+        n, t, nq = x.shape
+        idx = x.to(torch.int32).contiguous()
+        qf = torch.empty(n * t, CODE_DIM, device=x.device)
+        qb = torch.empty(n * t, CODE_DIM, device=x.device, dtype=torch.bfloat16)
+        _lib.check(_lib.load().syn_vq_codes(idx.data_ptr(), self.packed()["cb"].data_ptr(), qf.data_ptr(), qb.data_ptr(), n * t, nq,
+                                            torch.cuda.current_stream().cuda_stream), "syn_vq_codes")
+        return self._decoder(qb.view(n, t, CODE_DIM), n, t)
+
+    @torch.no_grad()
+    def forward(self, x):
+        lat = self._encoder(x.float())
+        y, commit, perp = self.latent2origin(lat)
+        return {"rec_pose": y, "commit_loss": commit, "perplexity": perp}
+
+
+# ---- deterministic synthetic weights / inputs (tests, goldens, benches) ------------------------------------------------
+def vq_args():
+    from types import SimpleNamespace
+    return SimpleNamespace(num_quantizers=NUM_Q, shared_codebook=False, quantize_dropout_prob=0.2, mu=0.99)   # trainer :89-92
+
+
+def build(dim: int) -> "RVQVAE":
+    """The constructor call of diffusion_rvqvae_trainer.py:107-150 for a body part of `dim` pose channels."""
+    return RVQVAE(vq_args(), dim, NB_CODE, CODE_DIM, CODE_DIM, 2, 2, 512, 3, 3, "relu", None)
+
+
+def synth_state_dict(dim: int, seed: int = 11) -> dict:
+    sd = {k: torch.zeros_like(v) for k, v in build(dim).state_dict().items()}
+    return synth.synth_fill_(sd, seed)
+
+
+def synth_pose(part: str, dim: int, n: int = 2, t: int = 64, seed: int = 3) -> torch.Tensor:
+    return synth.synth_tensor(f"vq.pose.{part}", (n, t, dim), seed=seed) * dim ** 0.5           # N(0,1) entries
+
+
+def synth_rec_latent(sd: dict, part: str, n: int = 2, t: int = 16) -> torch.Tensor:
+    """A latent the residual quantiser has something to say about: a sum of one code per layer (indices from a seeded
+    generator) plus noise at 30 % of the last layer's scale -- what the sampler's output looks like after training."""
+    g = synth._gen(f"vq.rec.idx.{part}", 4)
+    rec = 0.3 * 0.06 * 0.6 ** 5 * synth.synth_tensor(f"vq.rec.{part}", (n, t, 512), seed=4) * (n * t * 512) ** 0.5
+    for q in range(NUM_Q):
+        idx = torch.randint(0, NB_CODE, (n, t), generator=g)
+        rec = rec + sd[f"quantizer.layers.{q}.codebook"].cpu()[idx]
+    return rec

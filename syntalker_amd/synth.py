@@ -54,6 +54,9 @@ def synth_tensor(name: str, shape, seed: int = 0) -> torch.Tensor | None:
         return 0.5 + torch.rand(shape, generator=g)
     if leaf == "running_mean":
         return 0.1 * torch.randn(shape, generator=g)
+    if leaf == "codebook":              # residual VQ: layer q quantises what layers < q left over (models/vq/residual_vq.py)
+        q = int(name.split(".")[-2])
+        return 0.06 * (0.6 ** q) * torch.randn(shape, generator=g)
     if name.startswith("uncon_"):
         return 0.5 * torch.randn(shape, generator=g)
     if name == "text_pre_encoder_body.weight":
