@@ -38,6 +38,6 @@ def test_gpu_paths_never_read_the_reference_tree():
     for rel in ("bench.py", "__graft_entry__.py"):
         assert "/root/reference" not in open(os.path.join(REPO, rel)).read()
     for path in _py_files(os.path.join(REPO, "tests")):
-        if path.endswith("make_golden.py") or path.endswith("test_layout.py"):
+        if path.endswith(("make_golden.py", "make_vq_golden.py", "test_layout.py")):   # golden generators run in the build container only
             continue
         assert "/root/reference" not in open(path).read(), path
