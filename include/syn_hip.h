@@ -193,6 +193,30 @@ typedef struct syn_vq_conv {
 int syn_vq_conv1d(const syn_vq_conv* cv, const void* x_bf16, const float* resid, float* y_f32, int32_t ldy, void* y_bf16,
                   int32_t clips, int32_t t_in, int32_t t_out, void* stream);
 
+/* The whole model of one body part (models/vq/model.py:RVQVAE as diffusion_rvqvae_trainer.py:105-150 builds it):
+ * enc = model.0, then per down stage { k4 s2 conv, 3 x (conv1, conv2) with dilations 9, 3, 1 }, final conv (16 convs);
+ * dec = model.0, per up stage { 3 x (conv1, conv2), the conv behind nn.Upsample }, model.4, model.6 (17 convs). */
+typedef struct syn_vq_model {
+    int32_t pose_dim, reserved;
+    syn_vq_conv enc[16];
+    syn_vq_conv dec[17];
+    const float* codebooks;       /* [6][512][512] */
+    const float* codebooks_t;     /* [6][dim][code] */
+    const float* code_sq;         /* [6][512] */
+} syn_vq_model;
+/* bytes of scratch for `clips` clips of `t_pose` pose frames (t_pose = 4 x latent rows) */
+int64_t syn_vq_workspace_bytes(int32_t clips, int32_t t_pose, int32_t pose_dim);
+/* RVQVAE.map2latent (models/vq/model.py:95-100): pose fp32 [clips][t_pose][pose_dim] -> latent fp32 [clips][t_pose/4][512] */
+int syn_vq_map2latent(const syn_vq_model* m, const float* pose, int32_t clips, int32_t t_pose, void* workspace, float* latent,
+                      void* stream);
+/* RVQVAE.latent2origin (:102-109): latent fp32 [clips][t_lat][512] -> pose fp32 [clips][4 t_lat][pose_dim]; idx, sqerr,
+ * hist as in syn_vq_quantize (hist zeroed by the caller). */
+int syn_vq_latent2origin(const syn_vq_model* m, const float* latent, int32_t clips, int32_t t_lat, void* workspace, float* pose_out,
+                         int32_t* idx, float* sqerr, int32_t* hist, void* stream);
+/* RVQVAE.forward_decoder (:86-93): indices [clips][t_lat][n_q] -> pose fp32 [clips][4 t_lat][pose_dim] */
+int syn_vq_forward_decoder(const syn_vq_model* m, const int32_t* idx, int32_t n_q, int32_t clips, int32_t t_lat, void* workspace,
+                           float* pose_out, void* stream);
+
 /* ResidualVQ.forward in eval mode (models/vq/residual_vq.py:91-140 over quantizer.py:62-69,143-171), fp32, 6 layers
  * of 512 codes x 512 dims: x [rows][512] -> q_f32 / q_bf16 [rows][512] (sum of the straight-through outputs), idx
  * [rows][6], sqerr [syn_vq_quantize_groups(rows)][6] (per-group sums of |residual - code|^2: commit loss numerators),

@@ -29,3 +29,21 @@ def sample_long_ref(model_fn, audio, word, seed_latent, n_pose, x_T, step_noise,
         last = sample[:, :, 0, :].permute(0, 2, 1)                       # :458 (batched form of squeeze().permute(1,0))
         out.append(last if i == 0 else last[:, pre_frames:])             # :468-476
     return torch.cat(out, dim=1)
+
+
+def decode_take_ref(vq_sds, latents, latent_scale=5.0, use_trans=True, trans_mean=None, trans_std=None):
+    """diffusion_rvqvae_trainer.py:458-500 on the RVQ-VAE restatement (oracle/rvq_ref.py): vq_sds = {"upper": sd, ...}."""
+    from oracle import rvq_ref as rr
+    parts = {}
+    for k, name in enumerate(("upper", "hands", "lower")):
+        parts[name] = rr.latent2origin(vq_sds[name], latents[..., 512 * k:512 * (k + 1)] * latent_scale)[0]
+    trans = None
+    if use_trans:
+        v = parts["lower"][..., -3:]
+        if trans_std is not None:
+            v = v * trans_std + trans_mean
+        trans = torch.cumsum(v, dim=-2)
+        trans[..., 1] = v[..., 1]
+        parts["lower"] = parts["lower"][..., :-3]
+    parts["trans"] = trans
+    return parts

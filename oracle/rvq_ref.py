@@ -73,7 +73,7 @@ def residual_vq(sd, x):
         rows_in = res
         qd, idx = quantize_layer(cb, rows_in)
         losses.append(F.mse_loss(rows_in, F.embedding(idx, cb)))
-        onehot_cnt = torch.zeros(cb.shape[0]).scatter_add_(0, idx, torch.ones(idx.shape[0]))
+        onehot_cnt = torch.zeros(cb.shape[0], device=idx.device).scatter_add_(0, idx, torch.ones(idx.shape[0], device=idx.device))
         prob = onehot_cnt / onehot_cnt.sum()
         perps.append(torch.exp(-torch.sum(prob * torch.log(prob + 1e-7))))
         res = res - qd

@@ -17,6 +17,7 @@ EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_ste
            "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_test_gemm", "syn_test_attention",
            "syn_wav_encode", "syn_wav_workspace_bytes", "syn_wav_out_frames",
            "syn_vq_conv1d", "syn_vq_quantize", "syn_vq_quantize_groups", "syn_vq_codes",
+           "syn_vq_workspace_bytes", "syn_vq_map2latent", "syn_vq_latent2origin", "syn_vq_forward_decoder",
            "syn_step_advance", "syn_ln_fwd", "syn_ln_bwd", "syn_gelu_fwd", "syn_gelu_bwd", "syn_attn_fwd", "syn_attn_bwd")
 
 vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
@@ -52,6 +53,11 @@ class SynWavEnc(C.Structure):
 class SynVqConv(C.Structure):
     _fields_ = [("w_packed", vp), ("bias", vp), ("cin", i32), ("cout", i32), ("cout_valid", i32), ("taps", i32),
                 ("stride", i32), ("dil", i32), ("pad", i32), ("up", i32), ("relu_in", i32), ("relu_out", i32)]
+
+
+class SynVqModel(C.Structure):
+    _fields_ = [("pose_dim", i32), ("reserved", i32), ("enc", SynVqConv * 16), ("dec", SynVqConv * 17),
+                ("codebooks", vp), ("codebooks_t", vp), ("code_sq", vp)]
 
 
 class SynHipError(RuntimeError):
@@ -98,11 +104,16 @@ def load():
     lib.syn_vq_quantize_groups.argtypes = [i32]
     lib.syn_vq_quantize.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.syn_vq_codes.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    lib.syn_vq_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.syn_vq_map2latent.argtypes = [C.POINTER(SynVqModel), vp, i32, i32, vp, vp, vp]
+    lib.syn_vq_latent2origin.argtypes = [C.POINTER(SynVqModel), vp, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.syn_vq_forward_decoder.argtypes = [C.POINTER(SynVqModel), vp, i32, i32, i32, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("syn_version", "syn_last_error", "syn_wav_workspace_bytes"):
+        if name not in ("syn_version", "syn_last_error", "syn_wav_workspace_bytes", "syn_vq_workspace_bytes"):
             fn.restype = C.c_int
     lib.syn_wav_workspace_bytes.restype = C.c_int64
+    lib.syn_vq_workspace_bytes.restype = C.c_int64
     _lib = lib
     return lib
 

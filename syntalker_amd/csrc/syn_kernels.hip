@@ -1644,7 +1644,107 @@ int syn_vq_conv1d(const syn_vq_conv* cv, const void* x_bf16, const float* resid,
     return e == hipSuccess ? 0 : fail("k_conv1d launch", e);
 }
 
-int32_t syn_vq_quantize_groups(int32_t rows) { return (rows + rvq::kQRows - 1) / rvq::kQRows; }
+namespace {
+int vq_conv(const syn_vq_conv& base, int up, int relu_in, int relu_out, const void* x, const float* resid, float* yf, int ldy, void* yb,
+            int clips, int t_in, int t_out, void* stream) {
+    syn_vq_conv cv = base;
+    cv.up = up; cv.relu_in = relu_in; cv.relu_out = relu_out;
+    return syn_vq_conv1d(&cv, x, resid, yf, ldy, yb, clips, t_in, t_out, stream);
+}
+
+struct VqWs { float* af; __bf16* ab; float* bf; __bf16* bb; __bf16* hb; __bf16* in; };
+VqWs vq_ws(void* ws, int clips, int t_max, int cin_p) {
+    const size_t n = (size_t)clips * t_max * rvq::kDim;
+    char* p = (char*)ws;
+    VqWs w;
+    w.af = (float*)p; p += n * 4;
+    w.bf = (float*)p; p += n * 4;
+    w.ab = (__bf16*)p; p += n * 2;
+    w.bb = (__bf16*)p; p += n * 2;
+    w.hb = (__bf16*)p; p += n * 2;
+    w.in = (__bf16*)p;
+    (void)cin_p;
+    return w;
+}
+
+// Resnet1D (models/vq/resnet.py:71-83): 3 x { x += conv2(relu(conv1(relu(x)))) }, dilations 9, 3, 1, on (af, ab) in place
+int vq_resnet(const syn_vq_conv* c, VqWs& w, int clips, int t, void* stream) {
+    for (int j = 0; j < 3; ++j) {
+        int rc = vq_conv(c[2 * j], 0, 1, 0, w.ab, nullptr, nullptr, 0, w.hb, clips, t, t, stream);
+        if (rc) return rc;
+        if ((rc = vq_conv(c[2 * j + 1], 0, 1, 0, w.hb, w.af, w.af, rvq::kDim, w.ab, clips, t, t, stream))) return rc;
+    }
+    return 0;
+}
+
+__global__ void k_vq_pose_in(const float* pose, __bf16* out, long rows, int d, int dp) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * dp) return;
+    const long r = i / dp; const int c = (int)(i - r * dp);
+    out[i] = c < d ? (__bf16)pose[r * d + c] : (__bf16)0.f;
+}
+}  // namespace
+
+int64_t syn_vq_workspace_bytes(int32_t clips, int32_t t_pose, int32_t pose_dim) {
+    if (clips <= 0 || t_pose <= 0 || pose_dim <= 0) return -1;
+    const int64_t n = (int64_t)clips * t_pose * rvq::kDim;
+    const int64_t in_row = ((pose_dim + 31) / 32 * 32) * 2;            // padded bf16 pose row; also holds the quantised rows (256 B per pose frame)
+    return n * 14 + (int64_t)clips * t_pose * (in_row > 256 ? in_row : 256) + 256;
+}
+
+int syn_vq_map2latent(const syn_vq_model* m, const float* pose, int32_t clips, int32_t t_pose, void* workspace, float* latent,
+                      void* stream) {
+    if (!m || !pose || !workspace || !latent || clips <= 0 || t_pose <= 0 || t_pose % 4) return fail_msg("syn_vq_map2latent: bad arguments (frames % 4 == 0)");
+    const int dp = m->enc[0].cin;
+    VqWs w = vq_ws(workspace, clips, t_pose, dp);
+    const long rows = (long)clips * t_pose;
+    hipLaunchKernelGGL(k_vq_pose_in, dim3((unsigned)((rows * dp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pose, w.in, rows, m->pose_dim, dp);
+    int rc, t = t_pose;
+    if ((rc = vq_conv(m->enc[0], 0, 0, 1, w.in, nullptr, w.af, rvq::kDim, w.ab, clips, t, t, stream))) return rc;     // conv + ReLU (encdec.py:23-24)
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = vq_conv(m->enc[1 + 7 * i], 0, 0, 0, w.ab, nullptr, w.bf, rvq::kDim, w.bb, clips, t, t / 2, stream))) return rc;   // k4 s2 (:27-29)
+        t /= 2;
+        { float* f = w.af; w.af = w.bf; w.bf = f; __bf16* b = w.ab; w.ab = w.bb; w.bb = b; }
+        if ((rc = vq_resnet(m->enc + 2 + 7 * i, w, clips, t, stream))) return rc;
+    }
+    return vq_conv(m->enc[15], 0, 0, 0, w.ab, nullptr, latent, rvq::kDim, nullptr, clips, t, t, stream);           // (:33)
+}
+
+namespace {
+int vq_decode(const syn_vq_model* m, VqWs& w, const __bf16* qb, int clips, int t, float* pose_out, void* stream) {
+    int rc;
+    if ((rc = vq_conv(m->dec[0], 0, 0, 1, qb, nullptr, w.af, rvq::kDim, w.ab, clips, t, t, stream))) return rc;        // conv + ReLU (encdec.py:50-51)
+    for (int i = 0; i < 2; ++i) {
+        if ((rc = vq_resnet(m->dec + 1 + 7 * i, w, clips, t, stream))) return rc;
+        if ((rc = vq_conv(m->dec[7 + 7 * i], 1, 0, 0, w.ab, nullptr, w.bf, rvq::kDim, w.bb, clips, t, 2 * t, stream))) return rc;   // Upsample x2 + conv (:55-57)
+        t *= 2;
+        { float* f = w.af; w.af = w.bf; w.bf = f; __bf16* b = w.ab; w.ab = w.bb; w.bb = b; }
+    }
+    if ((rc = vq_conv(m->dec[15], 0, 0, 1, w.ab, nullptr, nullptr, 0, w.hb, clips, t, t, stream))) return rc;          // conv + ReLU (:60-61)
+    return vq_conv(m->dec[16], 0, 0, 0, w.hb, nullptr, pose_out, m->pose_dim, nullptr, clips, t, t, stream);          // (:62), (N, T, D)
+}
+}  // namespace
+
+int syn_vq_latent2origin(const syn_vq_model* m, const float* latent, int32_t clips, int32_t t_lat, void* workspace, float* pose_out,
+                         int32_t* idx, float* sqerr, int32_t* hist, void* stream) {
+    if (!m || !latent || !workspace || !pose_out || !idx || !sqerr || !hist || clips <= 0 || t_lat <= 0) return fail_msg("syn_vq_latent2origin: bad arguments");
+    VqWs w = vq_ws(workspace, clips, 4 * t_lat, m->enc[0].cin);
+    // quantised rows: fp32 into bf (free until the first up-conv), bf16 into the input region (the decoder's operand)
+    int rc = syn_vq_quantize(latent, m->codebooks, m->codebooks_t, m->code_sq, w.bf, w.in, idx, sqerr, hist, clips * t_lat, stream);
+    if (rc) return rc;
+    return vq_decode(m, w, w.in, clips, t_lat, pose_out, stream);
+}
+
+int syn_vq_forward_decoder(const syn_vq_model* m, const int32_t* idx, int32_t n_q, int32_t clips, int32_t t_lat, void* workspace,
+                           float* pose_out, void* stream) {
+    if (!m || !idx || !workspace || !pose_out || clips <= 0 || t_lat <= 0) return fail_msg("syn_vq_forward_decoder: bad arguments");
+    VqWs w = vq_ws(workspace, clips, 4 * t_lat, m->enc[0].cin);
+    int rc = syn_vq_codes(idx, m->codebooks, w.bf, w.in, clips * t_lat, n_q, stream);
+    if (rc) return rc;
+    return vq_decode(m, w, w.in, clips, t_lat, pose_out, stream);
+}
+
+int32_t syn_vq_quantize_groups(int32_t rows) { return (rows + rvq::q_rows(rows) - 1) / rvq::q_rows(rows); }
 
 int syn_vq_quantize(const float* x, const float* codebooks, const float* codebooks_t, const float* code_sq, float* q_f32,
                     void* q_bf16, int32_t* idx, float* sqerr, int32_t* hist, int32_t rows, void* stream) {
@@ -1653,7 +1753,8 @@ int syn_vq_quantize(const float* x, const float* codebooks, const float* codeboo
     rvq::QArgs a;
     a.X = x; a.CB = codebooks; a.CBT = codebooks_t; a.CC = code_sq; a.Qf = q_f32; a.Qb = (__bf16*)q_bf16; a.idx = idx;
     a.sqerr = sqerr; a.hist = hist; a.rows = rows;
-    hipLaunchKernelGGL(rvq::k_quantize, dim3(syn_vq_quantize_groups(rows)), dim3(rvq::kQThreads), 0, (hipStream_t)stream, a);
+    if (rvq::q_rows(rows) == 4) hipLaunchKernelGGL(rvq::k_quantize<4>, dim3(syn_vq_quantize_groups(rows)), dim3(rvq::kQThreads), 0, (hipStream_t)stream, a);
+    else                        hipLaunchKernelGGL(rvq::k_quantize<16>, dim3(syn_vq_quantize_groups(rows)), dim3(rvq::kQThreads), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_quantize launch", e);
 }

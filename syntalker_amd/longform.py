@@ -7,8 +7,9 @@ A long take of n pose frames is generated window by window: windows are `pose_le
 produced - a serial dependency, which is why the reference samples with batch size 1 and why the small-batch step
 kernel exists.  Several independent takes can be advanced together (batch dimension).
 
-Only the diffusion part is here (latents in, latents out): RVQ-VAE decoding and SMPL-X post-processing of the
-reference (`latent2origin`, rotation conversions) are outside the hot path.
+`sample_long` is the diffusion part (latents in, latents out); `decode_take` is what the reference does with those
+latents next (trainer :472-500): split per body part, scale, `latent2origin` of the three RVQ-VAEs (rvqvae.py, SURVEY
+§8 f2), un-normalise, integrate the root velocity.  The SMPL-X / rotation post-processing after that stays outside.
 """
 from __future__ import annotations
 
@@ -67,3 +68,28 @@ def sample_long(diffusion, model, audio, word, seed_latent, n_pose: int | None =
         last = sample[:, :, 0, :].permute(0, 2, 1).contiguous()          # (B, 32, 1536): trainer's squeeze/permute, batched
         pieces.append(last if i == 0 else last[:, pre_frames:])
     return torch.cat(pieces, dim=1)
+
+
+def decode_take(latents, vq_upper, vq_hands, vq_lower, latent_scale: float = 5.0, *, use_trans: bool = True,
+                trans_mean=None, trans_std=None, pose_stats: dict | None = None):
+    """latents (B, T', 1536) from `sample_long` -> dict(upper (B,4T',78), hands (B,4T',180), lower (B,4T',54), trans
+    (B,4T',3) or None).  diffusion_rvqvae_trainer.py:458-500: channel thirds are upper / hands / lower latents, scaled
+    by vqvae_latent_scale before decoding; with use_trans the last 3 lower channels are the root velocity
+    (de-normalised, x and z integrated over time, y kept absolute); pose_norm statistics are applied if given
+    (pose_stats = {"upper": (mean, std), ...})."""
+    parts = {}
+    for k, (name, vq) in enumerate((("upper", vq_upper), ("hands", vq_hands), ("lower", vq_lower))):
+        parts[name] = vq.latent2origin(latents[..., 512 * k:512 * (k + 1)].contiguous() * latent_scale)[0]
+    trans = None
+    if use_trans:
+        v = parts["lower"][..., -3:]
+        if trans_std is not None:
+            v = v * trans_std + trans_mean
+        trans = torch.cumsum(v, dim=-2)
+        trans[..., 1] = v[..., 1]
+        parts["lower"] = parts["lower"][..., :-3]
+    if pose_stats is not None:
+        for name, (mean, std) in pose_stats.items():
+            parts[name] = parts[name] * std + mean
+    parts["trans"] = trans
+    return parts

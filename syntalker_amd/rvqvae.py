@@ -95,110 +95,107 @@ class RVQVAE(nn.Module):
 
     # ---- device-side parameters ----------------------------------------------------------------------------------
     def packed(self):
-        """Fragment-packed conv weights, padded biases, codebook views; rebuilt when a parameter changes."""
-        sd = self.state_dict()
-        ver = tuple((v._version, v.data_ptr()) for v in sd.values())
+        """syn_vq_model of this module: fragment-packed conv weights, padded biases, codebook views.  Rebuilt when a
+        parameter changes (version counters) or moves."""
+        tensors = list(self.parameters()) + list(self.buffers())
+        ver = tuple((v._version, v.data_ptr()) for v in tensors)
         if self._packed is not None and self._packed["ver"] == ver:
             return self._packed
+        sd = self.state_dict()
         dev = sd["decoder.model.0.weight"].device
         if dev.type != "cuda":
             raise _lib.SynHipError("RVQVAE runs on the HIP kernels only: move the module to the GPU (no CPU fallback)")
         _lib.load()
-        convs = {}
-        for key, cin, cout, taps, stride, dil, pad in self._enc + self._dec:
-            cin_p, cout_p = _up(cin, 32), _up(cout, 128)
-            w = pack_conv(sd[key + ".weight"].float(), cin_p, cout_p)
-            b = torch.zeros(cout_p, device=dev)
-            b[:cout] = sd[key + ".bias"].float()
-            cv = _lib.SynVqConv(w.data_ptr(), b.data_ptr(), cin_p, cout_p, cout, taps, stride, dil, pad, 0, 0, 0)
-            convs[key] = (cv, w, b)
+        vm, keep = _lib.SynVqModel(), []
+        vm.pose_dim = self.input_width
+        for arr, specs in ((vm.enc, self._enc), (vm.dec, self._dec)):
+            for i, (key, cin, cout, taps, stride, dil, pad) in enumerate(specs):
+                cin_p, cout_p = _up(cin, 32), _up(cout, 128)
+                w = pack_conv(sd[key + ".weight"].float(), cin_p, cout_p)
+                b = torch.zeros(cout_p, device=dev)
+                b[:cout] = sd[key + ".bias"].float()
+                arr[i] = _lib.SynVqConv(w.data_ptr(), b.data_ptr(), cin_p, cout_p, cout, taps, stride, dil, pad, 0, 0, 0)
+                keep += [w, b]
         cb = torch.stack([sd[f"quantizer.layers.{q}.codebook"].float() for q in range(NUM_Q)]).contiguous()
-        self._packed = {"ver": ver, "convs": convs, "cb": cb, "cbt": cb.transpose(1, 2).contiguous(),
-                        "cc": torch.sum(cb.transpose(1, 2) ** 2, dim=1).contiguous()}       # quantizer.py:66: sum(k_w**2, dim=0)
+        cbt = cb.transpose(1, 2).contiguous()
+        cc = torch.sum(cbt ** 2, dim=1).contiguous()                        # quantizer.py:66: sum(k_w**2, dim=0)
+        vm.codebooks, vm.codebooks_t, vm.code_sq = cb.data_ptr(), cbt.data_ptr(), cc.data_ptr()
+        self._packed = {"ver": ver, "model": vm, "keep": keep, "cb": cb, "cbt": cbt, "cc": cc, "ws": {}}
         return self._packed
 
-    def _conv(self, key, x_b, t_in, t_out, clips, *, resid=None, want_f32=True, want_b16=True, relu_in=False, relu_out=False,
-              up=0, ldy=None):
-        cv, _, _ = self.packed()["convs"][key]
-        cv.up, cv.relu_in, cv.relu_out = up, int(relu_in), int(relu_out)
-        dev = x_b.device
-        ldy = cv.cout if ldy is None else ldy
-        yf = torch.empty(clips, t_out, ldy, device=dev) if want_f32 else None
-        yb = torch.empty(clips, t_out, cv.cout, device=dev, dtype=torch.bfloat16) if want_b16 else None
-        _lib.check(_lib.load().syn_vq_conv1d(C.byref(cv), x_b.data_ptr(), _lib.ptr(resid), _lib.ptr(yf), ldy, _lib.ptr(yb), clips,
-                                             t_in, t_out, torch.cuda.current_stream().cuda_stream), "syn_vq_conv1d")
-        return yf, yb
-
-    def _resnet(self, key, xf, xb, t, n):
-        for j in range(3):
-            _, hb = self._conv(f"{key}.model.{j}.conv1", xb, t, t, n, want_f32=False, relu_in=True)
-            xf, xb = self._conv(f"{key}.model.{j}.conv2", hb, t, t, n, resid=xf, relu_in=True)
-        return xf, xb
-
-    def _encoder(self, pose):
-        n, t, d = pose.shape
-        if t % 4:
-            raise ValueError("RVQVAE: the number of frames must be a multiple of 4 (two stride-2 stages)")
-        cin_p = _up(d, 32)
-        xb = torch.zeros(n, t, cin_p, device=pose.device, dtype=torch.bfloat16)
-        xb[..., :d] = pose
-        xf, xb = self._conv("encoder.model.0", xb, t, t, n, relu_out=True)
-        for i in range(2):
-            xf, xb = self._conv(f"encoder.model.{2 + i}.0", xb, t, t // 2, n)
-            t //= 2
-            xf, xb = self._resnet(f"encoder.model.{2 + i}.1", xf, xb, t, n)
-        yf, _ = self._conv("encoder.model.4", xb, t, t, n, want_b16=False)
-        return yf                                                           # (N, T/4, 512)
-
-    def _decoder(self, qb, n, t):
-        xf, xb = self._conv("decoder.model.0", qb, t, t, n, relu_out=True)
-        for i in range(2):
-            xf, xb = self._resnet(f"decoder.model.{2 + i}.0", xf, xb, t, n)
-            xf, xb = self._conv(f"decoder.model.{2 + i}.2", xb, t, 2 * t, n, up=1)
-            t *= 2
-        _, xb = self._conv("decoder.model.4", xb, t, t, n, want_f32=False, relu_out=True)
-        yf, _ = self._conv("decoder.model.6", xb, t, t, n, want_b16=False, ldy=self.input_width)
-        return yf                                                           # (N, 4 T', D)
+    def _workspace(self, p, clips, t_pose, dev):
+        key = (clips, t_pose)
+        if key not in p["ws"]:
+            if len(p["ws"]) > 4:
+                p["ws"].clear()
+            nbytes = _lib.load().syn_vq_workspace_bytes(clips, t_pose, self.input_width)
+            p["ws"][key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        return p["ws"][key]
 
     def _quantize(self, lat):
-        """lat (N, T', 512) fp32 -> quantised fp32 + bf16 rows, indices (N, T', 6), commit loss, perplexity."""
+        """lat (N, T', 512) fp32 -> quantised fp32 rows, indices (N, T', 6), commit loss, perplexity (quantiser alone)."""
         p = self.packed()
         lib = _lib.load()
         n, t, c = lat.shape
         rows = n * t
         x = lat.contiguous().float()
         qf = torch.empty(rows, c, device=x.device)
-        qb = torch.empty(rows, c, device=x.device, dtype=torch.bfloat16)
         idx = torch.empty(rows, NUM_Q, device=x.device, dtype=torch.int32)
         sq = torch.empty(lib.syn_vq_quantize_groups(rows), NUM_Q, device=x.device)
         hist = torch.zeros(NUM_Q, NB_CODE, device=x.device, dtype=torch.int32)
         _lib.check(lib.syn_vq_quantize(x.data_ptr(), p["cb"].data_ptr(), p["cbt"].data_ptr(), p["cc"].data_ptr(), qf.data_ptr(),
-                                       qb.data_ptr(), idx.data_ptr(), sq.data_ptr(), hist.data_ptr(), rows,
+                                       None, idx.data_ptr(), sq.data_ptr(), hist.data_ptr(), rows,
                                        torch.cuda.current_stream().cuda_stream), "syn_vq_quantize")
-        commit = (sq.sum(0) / (rows * c)).mean()                            # F.mse_loss per layer, mean over layers (:137)
+        commit, perp = self._stats(sq, hist, rows)
+        return qf.view(n, t, c), idx.view(n, t, NUM_Q).long(), commit, perp
+
+    @staticmethod
+    def _stats(sq, hist, rows):
+        commit = (sq.sum(0) / (rows * CODE_DIM)).mean()                     # F.mse_loss per layer, mean over layers (residual_vq.py:137)
         prob = hist.float() / rows
         perp = torch.exp(-(prob * torch.log(prob + 1e-7)).sum(1)).mean()   # quantizer.py:84-90, residual_vq.py:138
-        return qf.view(n, t, c), qb.view(n, t, c), idx.view(n, t, NUM_Q).long(), commit, perp
+        return commit, perp
 
     # ---- the reference's entry points ------------------------------------------------------------------------------
     @torch.no_grad()
     def map2latent(self, x):
-        return self._encoder(x.float())
+        """(N, T, D) -> (N, T/4, 512).  models/vq/model.py:95-100."""
+        p = self.packed()
+        n, t, d = x.shape
+        if d != self.input_width or t % 4:
+            raise ValueError(f"RVQVAE.map2latent: expected (N, T % 4 == 0, {self.input_width}), got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        lat = torch.empty(n, t // 4, CODE_DIM, device=x.device)
+        _lib.check(_lib.load().syn_vq_map2latent(C.byref(p["model"]), x.data_ptr(), n, t, self._workspace(p, n, t, x.device).data_ptr(),
+                                                 lat.data_ptr(), torch.cuda.current_stream().cuda_stream), "syn_vq_map2latent")
+        return lat
 
     @torch.no_grad()
     def latent2origin(self, x):
+        """(N, T', 512) -> ((N, 4 T', D), commit loss, perplexity).  models/vq/model.py:102-109."""
+        p = self.packed()
+        lib = _lib.load()
         n, t, _ = x.shape
-        _, qb, _, commit, perp = self._quantize(x)
-        return self._decoder(qb, n, t), commit, perp
+        x = x.contiguous().float()
+        out = torch.empty(n, 4 * t, self.input_width, device=x.device)
+        idx = torch.empty(n * t, NUM_Q, device=x.device, dtype=torch.int32)
+        sq = torch.empty(lib.syn_vq_quantize_groups(n * t), NUM_Q, device=x.device)
+        hist = torch.zeros(NUM_Q, NB_CODE, device=x.device, dtype=torch.int32)
+        _lib.check(lib.syn_vq_latent2origin(C.byref(p["model"]), x.data_ptr(), n, t, self._workspace(p, n, 4 * t, x.device).data_ptr(),
+                                            out.data_ptr(), idx.data_ptr(), sq.data_ptr(), hist.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "syn_vq_latent2origin")
+        commit, perp = self._stats(sq, hist, n * t)
+        return out, commit, perp
 
     @torch.no_grad()
     def encode(self, x):
-        lat = self._encoder(x.float())
+        """(N, T, D) -> (indices (N, T/4, 6), per-layer codes (6, N, 512, T/4)).  models/vq/model.py:53-65."""
+        lat = self.map2latent(x)
         n, t, c = lat.shape
-        _, _, idx, _, _ = self._quantize(lat)
+        _, idx, _, _ = self._quantize(lat)
         cb = self.packed()["cb"]
         res, codes = lat.reshape(n * t, c), []
-        for q in range(NUM_Q):                                              # the per-layer straight-through outputs (:150-160)
+        for q in range(NUM_Q):                                              # the per-layer straight-through outputs (residual_vq.py:150-160)
             cq = cb[q][idx[..., q].reshape(-1)]
             qd = res + (cq - res)
             res = res - qd
@@ -207,18 +204,20 @@ class RVQVAE(nn.Module):
 
     @torch.no_grad()
     def forward_decoder(self, x):
+        """indices (N, T', Q <= 6) -> (N, 4 T', D).  models/vq/model.py:86-93."""
+        p = self.packed()
         n, t, nq = x.shape
         idx = x.to(torch.int32).contiguous()
-        qf = torch.empty(n * t, CODE_DIM, device=x.device)
-        qb = torch.empty(n * t, CODE_DIM, device=x.device, dtype=torch.bfloat16)
-        _lib.check(_lib.load().syn_vq_codes(idx.data_ptr(), self.packed()["cb"].data_ptr(), qf.data_ptr(), qb.data_ptr(), n * t, nq,
-                                            torch.cuda.current_stream().cuda_stream), "syn_vq_codes")
-        return self._decoder(qb.view(n, t, CODE_DIM), n, t)
+        out = torch.empty(n, 4 * t, self.input_width, device=x.device)
+        _lib.check(_lib.load().syn_vq_forward_decoder(C.byref(p["model"]), idx.data_ptr(), nq, n, t,
+                                                      self._workspace(p, n, 4 * t, x.device).data_ptr(), out.data_ptr(),
+                                                      torch.cuda.current_stream().cuda_stream), "syn_vq_forward_decoder")
+        return out
 
     @torch.no_grad()
     def forward(self, x):
-        lat = self._encoder(x.float())
-        y, commit, perp = self.latent2origin(lat)
+        """models/vq/model.py:67-83 in eval mode."""
+        y, commit, perp = self.latent2origin(self.map2latent(x))
         return {"rec_pose": y, "commit_loss": commit, "perplexity": perp}
 
 

@@ -98,7 +98,7 @@ def test_rvqvae_vs_reference_outputs(vq_golden, part, dim):
     assert e < 2e-2
     # residual quantiser on the golden latent: the reference's indices, fp32 round-off on the rows
     rec = rvqvae.synth_rec_latent(sd, part)
-    qf, _, idx, commit, perp = m._quantize(rec.to(DEV))
+    qf, idx, commit, perp = m._quantize(rec.to(DEV))
     assert np.array_equal(idx.cpu().numpy(), vq_golden[f"{part}.quantizer.idx"])
     assert rel_l2(qf.permute(0, 2, 1), vq_golden[f"{part}.quantizer.out"]) < 1e-6
     y, commit2, perp2 = m.latent2origin(rec.to(DEV))
@@ -144,3 +144,23 @@ def test_rvqvae_batch_independence():
     all6 = m.latent2origin(rec)[0]
     one = m.latent2origin(rec[4:5])[0]
     assert torch.equal(all6[4:5], one)
+
+
+def test_decode_take_vs_oracle():
+    """The step after the sampler (trainer :458-500): 1536-channel latents of a whole take -> three body-part poses + root
+    translation, against the restatement.  The latents are sums of codes at 1/5 scale, as a trained sampler emits them."""
+    from oracle.longform_ref import decode_take_ref
+    from syntalker_amd import longform
+    dims = {"upper": 78, "hands": 180, "lower": 57}
+    sds = {k: rvqvae.synth_state_dict(d, seed=11) for k, d in dims.items()}
+    vqs = {k: _model(d) for k, d in dims.items()}
+    lat = torch.cat([rvqvae.synth_rec_latent(sds[k], k, n=2, t=60) for k in ("upper", "hands", "lower")], dim=-1) / 5.0
+    tm, ts = torch.tensor([0.01, 0.9, -0.02]), torch.tensor([0.5, 0.1, 0.4])
+    got = longform.decode_take(lat.to(DEV), vqs["upper"], vqs["hands"], vqs["lower"], 5.0, trans_mean=tm.to(DEV), trans_std=ts.to(DEV))
+    want = decode_take_ref(sds, lat, 5.0, trans_mean=tm, trans_std=ts)
+    for k in ("upper", "hands", "lower", "trans"):
+        assert got[k].shape == want[k].shape
+        e = rel_l2(got[k], want[k])
+        print(k, e)
+        assert e < 2e-2
+    assert got["lower"].shape[-1] == 54 and got["trans"].shape == (2, 240, 3)
