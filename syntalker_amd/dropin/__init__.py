@@ -24,9 +24,14 @@ _MAP = {
 }
 
 
-def install():
-    """Alias the hot-path modules under the reference's module names."""
-    for ref_name, ours in _MAP.items():
+# opt-in: the sampling / evaluation drivers only run the RVQ-VAEs in eval() (diffusion_rvqvae_trainer.py:28,105-161); the
+# reference's RVQ-VAE *training* script needs the trainable original, so this alias is not installed by default
+_MAP_RVQ = {"models.vq.model": "syntalker_amd.dropin.models.vq.model"}
+
+
+def install(rvqvae: bool = False):
+    """Alias the hot-path modules under the reference's module names (rvqvae=True: also `models.vq.model.RVQVAE`)."""
+    for ref_name, ours in {**_MAP, **(_MAP_RVQ if rvqvae else {})}.items():
         mod = importlib.import_module(ours)
         sys.modules[ref_name] = mod
         parent, _, leaf = ref_name.rpartition(".")

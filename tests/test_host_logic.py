@@ -216,3 +216,6 @@ def test_dropin_aliases_resolve():
     assert create_gaussian_diffusion is process.create_gaussian_diffusion
     assert TwoClassifierFreeSampleModel_Bodypart is guidance.TwoClassifierFreeSampleModel_Bodypart
     assert create_named_schedule_sampler is resample.create_named_schedule_sampler and MDM.__name__ == "MDM"
+    dropin.install(rvqvae=True)
+    from syntalker_amd import rvqvae
+    assert getattr(importlib.import_module("models.vq.model"), "RVQVAE") is rvqvae.RVQVAE
