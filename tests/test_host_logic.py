@@ -219,3 +219,18 @@ def test_dropin_aliases_resolve():
     dropin.install(rvqvae=True)
     from syntalker_amd import rvqvae
     assert getattr(importlib.import_module("models.vq.model"), "RVQVAE") is rvqvae.RVQVAE
+
+
+def test_config_loader_reads_reference_style_yaml(tmp_path):
+    """YAML of the shape of configs/diffusion_rvqvae_128.yaml -> the namespace MDM / the RVQ-VAE builders read."""
+    from syntalker_amd import config
+    from syntalker_amd.denoiser import MDM
+    y = tmp_path / "cfg.yaml"
+    y.write_text("vqvae_type: rvqvae\nvqvae_squeeze_scale: 4\nvqvae_latent_scale: 5\nuse_trans: True\naudio_f: 256\n"
+                 "word_f: 256\npose_length: 128\npre_frames: 4\naudio_rep: onset+amplitude\ntraining_speakers: [2]\n")
+    a = config.load_args(str(y), batch_size=3)
+    assert a.vqvae_latent_scale == 5 and a.use_trans is True and a.batch_size == 3 and a.training_speakers == [2]
+    assert a.t_fix_pre is False                     # default filled in for a key the file omits
+    m = MDM(a)                                      # constructible from it
+    assert m.state_dict()["mytimmblocks.0.attn.qkv.weight"].shape == (1536, 512)
+    assert config.BODY_DIMS == {"upper": 78, "hands": 180, "lower": 54}
