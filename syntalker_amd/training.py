@@ -221,20 +221,55 @@ def _rotary(m, h):
 WAV_CHANNELS_LAST = True     # run the encoder's convolutions as (N, C, 1, L) channels-last conv2d: MIOpen's NHWC kernels without
                              # the NCHW <-> NHWC transposes it otherwise inserts around every convolution
 
+class ConvBf16Fn(torch.autograd.Function):
+    """(N, C, 1, L) convolution of the audio encoder with bf16 operands: forward and data gradient on MIOpen's bf16
+    kernels (fp32 accumulation, the rounding policy of every GEMM on this path); the weight gradient - a reduction over
+    up to 2 M positions - stays on the fp32 kernel (MIOpen's bf16 weight-gradient kernels lose 14 % on the first layer)."""
 
-def _conv_bn(conv, bn, x, training):
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
+        ctx.save_for_backward(xb, wb)
+        ctx.geom = (stride, pad)
+        return F.conv2d(xb, wb, None, stride=(1, stride), padding=(0, pad)).float()
+
+    @staticmethod
+    def backward(ctx, gy):
+        xb, wb = ctx.saved_tensors
+        stride, pad = ctx.geom
+        args = ((1, stride), (0, pad), (1, 1), False, (0, 0), 1)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy.to(torch.bfloat16), xb, wb, None, *args, (True, False, False))[0].float()
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gy, xb.float(), wb.float(), None, *args, (False, True, False))[1]
+        return gx, gw, None, None
+
+
+WAV_BF16_FROM = 0         # first encoder block that uses it
+WAV_BF16 = False          # experiment, off: 15.1 -> 12.3 ms per step at B = 32, but the gradients of the first encoder blocks
+                          # move by up to 14 % (vs 1 % in fp32): the backward chain through the 12 convolutions amplifies every
+                          # bf16 rounding ~1.5x per block (scripts/diag_train_grads.py)
+
+
+def _conv_bn(conv, bn, x, training, bf16=False):
     """Conv1d + BatchNorm1d of the module (batch statistics in training, running statistics in eval) on (N, C, 1, L)."""
-    y = F.conv2d(x, conv.weight.unsqueeze(2), conv.bias, stride=(1, conv.stride[0]), padding=(0, conv.padding[0]))
+    if bf16:
+        y = ConvBf16Fn.apply(x, conv.weight.unsqueeze(2), conv.stride[0], conv.padding[0])
+        if conv.bias is not None:
+            y = y + conv.bias.view(1, -1, 1, 1)
+    else:
+        y = F.conv2d(x, conv.weight.unsqueeze(2), conv.bias, stride=(1, conv.stride[0]), padding=(0, conv.padding[0]))
     return F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
 
 
-def _wav_block(blk, x):
+def _wav_block(blk, x, bf16=False):
     """models/utils/layer.py:171-184 with the module's own Conv1d / BatchNorm1d (train or eval statistics)."""
     if WAV_CHANNELS_LAST and x.dim() == 4:
         tr = blk.training
-        z = F.leaky_relu(_conv_bn(blk.conv1, blk.bn1, x, tr), 0.01)
-        z = _conv_bn(blk.conv2, blk.bn2, z, tr)
-        short = x if blk.downsample is None else _conv_bn(blk.downsample[0], blk.downsample[1], x, tr)
+        z = F.leaky_relu(_conv_bn(blk.conv1, blk.bn1, x, tr, bf16), 0.01)
+        z = _conv_bn(blk.conv2, blk.bn2, z, tr, bf16)
+        short = x if blk.downsample is None else _conv_bn(blk.downsample[0], blk.downsample[1], x, tr, bf16)
         return F.leaky_relu(z + short, 0.01)
     short = x
     z = F.leaky_relu(blk.bn1(blk.conv1(x)), 0.01)
@@ -261,8 +296,8 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     a = audio.unsqueeze(1) if audio.dim() == 2 else audio.transpose(1, 2)
     if WAV_CHANNELS_LAST:
         a = a.unsqueeze(2).contiguous(memory_format=torch.channels_last)       # (B, C, 1, L), channel innermost
-    for blk in m.WavEncoder.feat_extractor:
-        a = _wav_block(blk, a)
+    for i, blk in enumerate(m.WavEncoder.feat_extractor):
+        a = _wav_block(blk, a, WAV_BF16 and i >= WAV_BF16_FROM)
     if a.dim() == 4:
         a = a.squeeze(2)
     a_feat = a.transpose(1, 2).permute(1, 0, 2)                                  # (128, B, 256)
