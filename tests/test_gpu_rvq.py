@@ -164,3 +164,14 @@ def test_decode_take_vs_oracle():
         print(k, e)
         assert e < 2e-2
     assert got["lower"].shape[-1] == 54 and got["trans"].shape == (2, 240, 3)
+
+
+def test_rvqvae_h3d_body_part_widths():
+    """The text-prompt trainer builds the same model on 156 / 360 / 107 pose channels (h3d_diffusion_new_trainer.py:104-146)."""
+    for dim in (156, 360, 107):
+        m = _model(dim)
+        sd = rvqvae.synth_state_dict(dim, seed=11)
+        rec = rvqvae.synth_rec_latent(sd, "h3d", n=2, t=8)
+        pose = rvqvae.synth_pose("h3d", dim, n=2, t=32)
+        assert rel_l2(m.latent2origin(rec.to(DEV))[0], rr.latent2origin(sd, rec)[0]) < 2e-2
+        assert rel_l2(m.map2latent(pose.to(DEV)), rr.map2latent(sd, pose)) < 2e-2
