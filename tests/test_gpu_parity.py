@@ -251,6 +251,28 @@ def test_cpu_tensors_fail_loudly():
         m(synth.synth_latent(1), torch.tensor([3]), synth.synth_clip_inputs(1))
 
 
+def test_bench_size_batch_is_copies_of_its_clips(beatx):
+    """The bench batch (1024 clips = 512 workgroups of the whole-step kernel, two rounds on the chip) built as 128 copies
+    of 8 distinct clips: every copy must carry the bits of the original wherever it sits in the batch, and the 8
+    originals must match the CPU oracle.  Conditioning is computed once for the 8 clips and tiled (see
+    test_batch_rows_are_independent for why)."""
+    from oracle import denoiser_ref as dr
+    from syntalker_amd import engine
+    y8, x8 = synth.synth_clip_inputs(8, seed=21), synth.synth_latent(8, seed=21)
+    t8 = torch.tensor([0, 1, 50, 333, 500, 777, 998, 999])
+    cond8 = beatx.variant_conds(synth.to_device(y8, DEV), [(False, False, None)])[0]
+    B, R = 1024, 128
+    sb = engine.StepBuffers(B, 1, DEV)
+    sb.cond.copy_(cond8.repeat(R, 1, 1).reshape(-1, 512)); sb.load_x(x8.to(DEV).repeat(R, 1, 1, 1))
+    sb.t_model.copy_(t8.int().to(DEV).repeat(R)); sb.t_coef.zero_()
+    engine.run_step(beatx.packed(), sb, engine.identity_coefs(DEV), False)
+    out = sb.read(sb.x)
+    assert torch.equal(out, out[:8].repeat(R, 1, 1, 1))
+    with torch.no_grad():
+        want = dr.mdm_forward(synth_state_dict("beatx"), x8, t8, y8)
+    assert rel_l2(out[:8].cpu(), want) < FWD_TOL
+
+
 def test_full_size_properties(beatx):
     """BASELINE-size batch (256 clips): properties that need no oracle.
        (1) t=0 step adds no noise: result independent of the injected noise;
