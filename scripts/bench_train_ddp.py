@@ -1,0 +1,47 @@
+"""DDP training step, eager vs graph-replayed (one process per GPU over RCCL; also runs with a single rank).
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port 29531 scripts/bench_train_ddp.py [B=32] [steps=20]"""
+import os, sys, time, torch
+os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")       # whole-step capture: no watchdog thread touching the stream
+import torch.distributed as dist
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from syntalker_amd import synth, training
+from syntalker_amd.denoiser import MDM
+from syntalker_amd.process import create_gaussian_diffusion
+from syntalker_amd.resample import create_named_schedule_sampler
+rank, local, world = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+torch.cuda.set_device(local)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+d = create_gaussian_diffusion(); s = create_named_schedule_sampler("uniform", d)
+y = synth.to_device(synth.synth_clip_inputs(B, seed=1 + rank, mask_batch=B), 'cuda')
+y["audio"] = torch.randn(B, 68266, 2, device='cuda')
+x0 = synth.synth_latent(B, seed=1 + rank, name="x0").cuda()
+
+
+def run(capturable):
+    m = synth.synth_fill_(MDM(synth.default_args()).train(), 0).cuda()
+    side = torch.cuda.Stream() if capturable else torch.cuda.current_stream()
+    with torch.cuda.stream(side):                       # DDP built on the stream its iterations run on
+        ddp = training.make_ddp(m, local, capturable=capturable)
+    torch.cuda.current_stream().wait_stream(side)
+    opt = torch.optim.Adam(ddp.parameters(), lr=5e-5, betas=(0.5, 0.999), capturable=capturable)
+    if not capturable:
+        step = lambda: training.train_step(ddp, d, s, opt, x0, {"y": y})
+    else:
+        g = training.GraphedTrainStep(ddp, d, opt, x0, {"y": y}, warmup=11, stream=side)
+        step = lambda: g(x0, s.sample(B, x0.device)[0], {"y": y})
+    for _ in range(3): loss = step()
+    torch.cuda.synchronize(); dist.barrier(); t0 = time.perf_counter()
+    for _ in range(n): loss = step()
+    torch.cuda.synchronize(); dist.barrier(); dt = (time.perf_counter() - t0) / n
+    if rank == 0:
+        print(f"{'graph-replayed' if capturable else 'eager'} DDP step, {world} rank(s) x {B} clips: {dt*1e3:.1f} ms "
+              f"({world*B/dt:.0f} samples/s), loss {float(loss):.4f}", flush=True)
+    if capturable: g.close()
+
+
+run(False)
+run(True)
+dist.barrier(); dist.destroy_process_group()

@@ -336,14 +336,24 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     return out.reshape(T, bs, C, 1).permute(1, 2, 3, 0)
 
 
-def make_ddp(model, local_rank: int | None = None, sync_bn: bool = False):
+UNUSED_IN_FORWARD = ("embed_style", "uncon_audio_embeddings", "uncon_text_embeddings")
+
+
+def make_ddp(model, local_rank: int | None = None, sync_bn: bool = False, capturable: bool = False):
     """One process per GPU, gradients all-reduced over RCCL (backend "nccl"); `embed_style` and the h3d
-    `uncon_audio_embeddings` never receive gradients (unused in forward), hence find_unused_parameters."""
+    `uncon_*_embeddings` never receive gradients (unused in forward), hence find_unused_parameters.
+    capturable=True prepares the wrapper for `GraphedTrainStep`: the unused-parameter search is a host-side walk plus
+    a blocking all-reduce in every backward, which cannot be captured, so those parameters are frozen instead and the
+    search is switched off (same gradients: they are None either way)."""
     from torch.nn.parallel import DistributedDataParallel as DDP
     if sync_bn:
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    if capturable:
+        for n, p in model.named_parameters():
+            if n.split(".")[0] in UNUSED_IN_FORWARD:
+                p.requires_grad_(False)
     dev_ids = None if local_rank is None else [local_rank]
-    return DDP(model, device_ids=dev_ids, broadcast_buffers=False, find_unused_parameters=True,
+    return DDP(model, device_ids=dev_ids, broadcast_buffers=False, find_unused_parameters=not capturable,
                gradient_as_bucket_view=True, bucket_cap_mb=64)
 
 
@@ -363,8 +373,11 @@ def train_step(model, diffusion, sampler, optimizer, x0, model_kwargs, grad_norm
 class GraphedTrainStep:
     """`train_step` captured once in a hipGraph and replayed.  The step is ~1 000 kernel launches long and host-bound
     when issued from Python (device time 15 ms, wall 17-21 ms at 32 clips); a replay costs the device time (15.5 ms).
-    Static shapes: every call must bring tensors of the shapes seen at construction.  Single process (DDP training
-    goes through `train_step`).  The optimizer must be constructed with ``capturable=True``.
+    Static shapes: every call must bring tensors of the shapes seen at construction.  The optimizer must be constructed
+    with ``capturable=True``.  With DDP: wrap with ``make_ddp(..., capturable=True)`` inside ``torch.cuda.stream(s)``,
+    pass ``stream=s`` and ``warmup=11`` (DDP needs that many eager iterations before a capture), and set
+    ``TORCH_NCCL_ASYNC_ERROR_HANDLING=0`` before ``init_process_group`` - the bucketed all-reduces are then nodes of the
+    graph (`scripts/bench_train_ddp.py`; checked with one rank over RCCL: 22.6 ms eager -> 18.0 ms replayed).
 
         step = GraphedTrainStep(model, diffusion, optimizer, x0, {"y": y})
         loss = step(x0, t, {"y": y})          # t from the schedule sampler (host RNG, as in the reference)
@@ -373,21 +386,21 @@ class GraphedTrainStep:
     the HIP runtime (HSA memory-aperture violation, reproduced with PyTorch-ROCm ops only), synchronised ones ran 400
     steps cleanly.  Call `close()` (or let the object die) before interpreter shutdown."""
 
-    def __init__(self, model, diffusion, optimizer, x0, model_kwargs, grad_norm: float = 0.99, warmup: int = 3):
+    def __init__(self, model, diffusion, optimizer, x0, model_kwargs, grad_norm: float = 0.99, warmup: int = 3, stream=None):
         engine._require_cuda(x0, "x0")
         self.model, self.opt, self.grad_norm, self.diffusion = model, optimizer, grad_norm, diffusion
         self.wrapped = diffusion._wrap_model(model)          # its timestep map is uploaded once, outside the capture
         self.x0 = x0.detach().clone()
         self.t = torch.zeros(x0.shape[0], dtype=torch.long, device=x0.device)
         self.y = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in model_kwargs["y"].items()}
-        side = torch.cuda.Stream(device=x0.device)
+        side = stream if stream is not None else torch.cuda.Stream(device=x0.device)   # DDP: the stream the wrapper was built on
         side.wait_stream(torch.cuda.current_stream(x0.device))
         with torch.cuda.stream(side):                         # warm-up: MIOpen solver selection, lazy state, Adam state
             for _ in range(warmup):
                 self._body()
         torch.cuda.current_stream(x0.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=side):
             self.loss = self._body()
 
     def _body(self):

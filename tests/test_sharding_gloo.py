@@ -108,3 +108,47 @@ def test_two_rank_ddp_gradients_equal_full_batch(tmp_path):
     for k, p in net.named_parameters():
         assert torch.allclose(got[k], p.grad, atol=1e-6), k
     assert not any(k.startswith("unused") for k in got)
+
+
+def _ddp_capturable_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from syntalker_amd.training import make_ddp
+
+        class Net(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                torch.manual_seed(0)
+                self.a, self.b = torch.nn.Linear(6, 5), torch.nn.Linear(5, 3)
+                self.embed_style = torch.nn.Linear(6, 4)           # defined, never used (models/denoiser.py)
+
+            def forward(self, x):
+                return self.b(torch.tanh(self.a(x)))
+        data = torch.randn(8, 6, generator=torch.Generator().manual_seed(7))
+        lo, hi = shard_range(8, rank, world)
+        w = make_ddp(Net(), capturable=True)                        # no unused-parameter search: the unused ones are frozen
+        grads = []
+        for _ in range(3):                                          # a second / third iteration would raise if a trainable
+            w.zero_grad()                                           # parameter had been left without a gradient
+            (w(data[lo:hi]) ** 2).mean().backward()
+            grads.append({k: p.grad.clone() for k, p in w.module.named_parameters() if p.grad is not None})
+        if rank == 0:
+            torch.save({"grads": grads[-1], "frozen": [k for k, p in w.module.named_parameters() if not p.requires_grad],
+                        "find_unused": w.find_unused_parameters}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_ddp_prepared_for_graph_capture(tmp_path):
+    out = str(tmp_path / "gc.pt")
+    mp.spawn(_ddp_capturable_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["find_unused"] is False and sorted(got["frozen"]) == ["embed_style.bias", "embed_style.weight"]
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(6, 5), torch.nn.Linear(5, 3)
+    data = torch.randn(8, 6, generator=torch.Generator().manual_seed(7))
+    # rank-mean of the two half-batch means = full-batch mean
+    (b(torch.tanh(a(data))) ** 2).mean().backward()
+    for k, ref in (("a.weight", a.weight.grad), ("b.weight", b.weight.grad), ("b.bias", b.bias.grad)):
+        assert torch.allclose(got["grads"][k], ref, atol=1e-6), k
