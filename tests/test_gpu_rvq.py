@@ -175,3 +175,26 @@ def test_rvqvae_h3d_body_part_widths():
         pose = rvqvae.synth_pose("h3d", dim, n=2, t=32)
         assert rel_l2(m.latent2origin(rec.to(DEV))[0], rr.latent2origin(sd, rec)[0]) < 2e-2
         assert rel_l2(m.map2latent(pose.to(DEV)), rr.map2latent(sd, pose)) < 2e-2
+
+
+def test_rvqvae_round_trip_properties_at_batch_size():
+    """256 clips x 128 frames (the batch the training loader hands over), no oracle needed:
+    (1) forward() = latent2origin(map2latent(.)) and is finite;
+    (2) decoding the indices encode() returns reproduces that reconstruction (the two differ only by the rounding of the
+        straight-through sum vs the plain sum of codes, amplified to the bf16 noise floor by the decoder);
+    (3) the histogram behind the perplexity counts every row once per layer; commit loss = mean squared residual >= 0."""
+    dim = 78
+    m = _model(dim)
+    pose = rvqvae.synth_pose("upper", dim, n=256, t=128).to(DEV)
+    out = m(pose)
+    lat = m.map2latent(pose)
+    y, commit, perp = m.latent2origin(lat)
+    assert torch.equal(out["rec_pose"], y) and torch.isfinite(y).all() and y.shape == (256, 128, dim)
+    idx, codes = m.encode(pose)
+    assert idx.shape == (256, 32, 6) and int(idx.min()) >= 0 and int(idx.max()) < 512
+    y2 = m.forward_decoder(idx)
+    assert rel_l2(y2, y) < 1e-2          # fp32-round-off differences in the decoder input re-roll its bf16 roundings (3.7e-3)
+    assert float(commit) >= 0 and 1.0 <= float(perp) <= 512.0
+    qf, idx2, _, _ = m._quantize(lat)
+    assert torch.equal(idx2, idx)
+    assert rel_l2(codes.sum(0).permute(0, 2, 1), qf) < 1e-6
