@@ -113,6 +113,11 @@ int syn_denoise_step(const syn_model* model, const syn_step* step, void* stream)
  * (this launch + syn_denoise_step) with no host work in between. */
 int syn_step_advance(const int32_t* sched, int32_t* counter, int32_t* t_model, int32_t n_t_model, int32_t* t_coef, int32_t n_t_coef,
                      void* stream);
+/* The same for the next n_steps steps at once: row s of t_model [n_steps][n_t_model] / t_coef [n_steps][n_t_coef] belongs
+ * to step *counter + s; *counter advances by n_steps.  A graph of n_steps captured steps, each pointing at its own row,
+ * needs one of these per replay instead of one per step. */
+int syn_steps_advance(const int32_t* sched, int32_t* counter, int32_t* t_model, int32_t n_t_model, int32_t* t_coef,
+                      int32_t n_t_coef, int32_t n_steps, void* stream);
 
 /* Same step, eagerly, with a hipEvent after every launch: fills ms_out[8] / count_out[8] with the elapsed
  * milliseconds and launch count per stage class {0 input GEMM, 1 qkv GEMM, 2 attention, 3 proj GEMM,

@@ -18,7 +18,7 @@ EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_ste
            "syn_wav_encode", "syn_wav_workspace_bytes", "syn_wav_out_frames",
            "syn_vq_conv1d", "syn_vq_quantize", "syn_vq_quantize_groups", "syn_vq_codes",
            "syn_vq_workspace_bytes", "syn_vq_map2latent", "syn_vq_latent2origin", "syn_vq_forward_decoder",
-           "syn_step_advance", "syn_ln_fwd", "syn_ln_bwd", "syn_gelu_fwd", "syn_gelu_bwd", "syn_attn_fwd", "syn_attn_bwd")
+           "syn_step_advance", "syn_steps_advance", "syn_ln_fwd", "syn_ln_bwd", "syn_gelu_fwd", "syn_gelu_bwd", "syn_attn_fwd", "syn_attn_bwd")
 
 vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
 
@@ -91,6 +91,7 @@ def load():
     lib.syn_test_gemm.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.syn_test_attention.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.syn_step_advance.argtypes = [vp, vp, vp, i32, vp, i32, vp]
+    lib.syn_steps_advance.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp]
     lib.syn_ln_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
     lib.syn_ln_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.syn_gelu_fwd.argtypes = [vp, vp, i64, vp]

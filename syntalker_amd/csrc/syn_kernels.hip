@@ -1395,14 +1395,18 @@ __global__ void k_axpby_rows(const float* __restrict__ x, const float* __restric
 // Sampling loops: the timestep vectors of the next step from a device-resident schedule, so that a loop iteration is
 // one graph replay and nothing else on the host.  sched[i] = {row of the coefficient table, original timestep};
 // *counter is advanced by the kernel (single workgroup).
+// n_steps > 1: the vectors of the next n_steps steps at once, row s of t_model [n_steps][n_tm] / t_coef [n_steps][n_tc]
+// for step i + s (a graph of n_steps captured steps reads one row each: one of these per replay instead of one per step).
 __global__ void k_step_advance(const int* __restrict__ sched, int* __restrict__ counter, int* __restrict__ t_model, int n_tm,
-                               int* __restrict__ t_coef, int n_tc) {
+                               int* __restrict__ t_coef, int n_tc, int n_steps) {
     const int i = *counter;
-    const int tc = sched[2 * i], tm = sched[2 * i + 1];
-    for (int j = threadIdx.x; j < n_tm; j += blockDim.x) t_model[j] = tm;
-    for (int j = threadIdx.x; j < n_tc; j += blockDim.x) t_coef[j] = tc;
+    for (int s = 0; s < n_steps; ++s) {
+        const int tc = sched[2 * (i + s)], tm = sched[2 * (i + s) + 1];
+        for (int j = threadIdx.x; j < n_tm; j += blockDim.x) t_model[(size_t)s * n_tm + j] = tm;
+        for (int j = threadIdx.x; j < n_tc; j += blockDim.x) t_coef[(size_t)s * n_tc + j] = tc;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) *counter = i + 1;
+    if (threadIdx.x == 0) *counter = i + n_steps;
 }
 
 __global__ void k_randn(float* __restrict__ out, long n4, uint64_t seed, uint64_t stream_id, long first4) {
@@ -1766,13 +1770,19 @@ int syn_vq_codes(const int32_t* idx, const float* codebooks, float* q_f32, void*
     return e == hipSuccess ? 0 : fail("k_codes launch", e);
 }
 
-int syn_step_advance(const int32_t* sched, int32_t* counter, int32_t* t_model, int32_t n_t_model, int32_t* t_coef, int32_t n_t_coef,
-                     void* stream) {
-    if (!sched || !counter || !t_model || !t_coef || n_t_model <= 0 || n_t_coef <= 0) return fail_msg("syn_step_advance: bad arguments");
+int syn_steps_advance(const int32_t* sched, int32_t* counter, int32_t* t_model, int32_t n_t_model, int32_t* t_coef, int32_t n_t_coef,
+                      int32_t n_steps, void* stream) {
+    if (!sched || !counter || !t_model || !t_coef || n_t_model <= 0 || n_t_coef <= 0 || n_steps <= 0)
+        return fail_msg("syn_steps_advance: bad arguments");
     hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(256), 0, (hipStream_t)stream, (const int*)sched, (int*)counter, (int*)t_model,
-                       n_t_model, (int*)t_coef, n_t_coef);
+                       n_t_model, (int*)t_coef, n_t_coef, n_steps);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_step_advance launch", e);
+}
+
+int syn_step_advance(const int32_t* sched, int32_t* counter, int32_t* t_model, int32_t n_t_model, int32_t* t_coef, int32_t n_t_coef,
+                     void* stream) {
+    return syn_steps_advance(sched, counter, t_model, n_t_model, t_coef, n_t_coef, 1, stream);
 }
 
 int syn_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t first_index, void* stream) {

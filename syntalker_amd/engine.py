@@ -188,7 +188,21 @@ class StepGraph:
         torch.cuda.current_stream(pm.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            for _ in range(steps):
+            if steps > 1:
+                # one schedule kernel per replay: it fills a row of timestep vectors per captured step, and every captured
+                # launch points at its own row (same-box A/B at B = 1: 160.5 -> 158.3 us per step)
+                self.tm_rows = torch.zeros(steps, sb.t_model.numel(), dtype=torch.int32, device=pm.device)
+                self.tc_rows = torch.zeros(steps, sb.t_coef.numel(), dtype=torch.int32, device=pm.device)
+                _lib.check(_lib.load().syn_steps_advance(self.sched.data_ptr(), self.counter.data_ptr(), self.tm_rows.data_ptr(),
+                                                         sb.t_model.numel(), self.tc_rows.data_ptr(), sb.t_coef.numel(), steps,
+                                                         _lib.current_stream()), "syn_steps_advance")
+                try:
+                    for j in range(steps):
+                        sb.c.t_model, sb.c.t_coef = self.tm_rows[j].data_ptr(), self.tc_rows[j].data_ptr()
+                        run_step(pm, sb, coef, use_noise, fused_rng)
+                finally:
+                    sb.c.t_model, sb.c.t_coef = sb.t_model.data_ptr(), sb.t_coef.data_ptr()
+            else:
                 if scheduled:
                     _lib.check(_lib.load().syn_step_advance(self.sched.data_ptr(), self.counter.data_ptr(), sb.t_model.data_ptr(),
                                                             sb.t_model.numel(), sb.t_coef.data_ptr(), sb.t_coef.numel(),
