@@ -96,6 +96,40 @@ def test_randn_is_standard_normal_and_shard_invariant(lib):
     assert abs(float((a * c).mean())) < 5e-3                 # different step -> independent
 
 
+def _philox4x32_10(idx4, stream_id, seed):
+    """Philox4x32-10 (Salmon et al., SC'11) in numpy: counter = (idx4 lo, idx4 hi, stream lo, stream hi), key = seed."""
+    import numpy as np
+    c = [np.asarray(idx4 & 0xFFFFFFFF, np.uint64), np.asarray(idx4 >> 32, np.uint64),
+         np.full(idx4.shape, stream_id & 0xFFFFFFFF, np.uint64), np.full(idx4.shape, stream_id >> 32, np.uint64)]
+    k0, k1 = seed & 0xFFFFFFFF, seed >> 32
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+        n0 = (p1 >> np.uint64(32)) ^ c[1] ^ np.uint64(k0)
+        n2 = (p0 >> np.uint64(32)) ^ c[3] ^ np.uint64(k1)
+        c = [n0, p1 & np.uint64(0xFFFFFFFF), n2, p0 & np.uint64(0xFFFFFFFF)]
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c
+
+
+def test_randn_is_philox_box_muller(lib):
+    """The generator's definition, pinned from outside: element 4q+j of (seed, stream) is Box-Muller of the Philox4x32-10
+    block with counter (q, stream) - cos/sin of word pairs (0,1) and (2,3).  The device uses the hardware log2 / sqrt /
+    sin / cos and fp32 uniforms, so the comparison is numeric (median error 6e-8), not bitwise."""
+    import numpy as np
+    n, seed, stream, first = 1 << 16, 0x1234567890ABCDEF, 917, 4096
+    a = torch.empty(n, device="cuda")
+    lib.check(lib.load().syn_randn(a.data_ptr(), n, seed, stream, first, lib.current_stream()), "randn")
+    w = _philox4x32_10(np.arange(first // 4, (first + n) // 4, dtype=np.uint64), stream, seed)
+    u = [(x.astype(np.float64) + 0.5) * 2.0 ** -32 for x in w]
+    want = np.empty((n // 4, 4))
+    for p in range(2):
+        rad = np.sqrt(-2.0 * np.log(u[2 * p]))
+        want[:, 2 * p], want[:, 2 * p + 1] = rad * np.cos(2 * np.pi * u[2 * p + 1]), rad * np.sin(2 * np.pi * u[2 * p + 1])
+    got = a.cpu().double().numpy().reshape(-1, 4)
+    d = np.abs(got - want)
+    assert np.median(d) < 1e-6 and d.max() < 1e-4        # worst case: u1 within 1e-6 of 1, where fp32 u1 loses -ln(u1)'s digits
+
+
 @pytest.mark.parametrize("B,L", [(3, 68224), (2, 68266), (1, 20000)])
 def test_wav_encoder_vs_torch(B, L):
     """the HIP WavEncoder (channels-last bf16 implicit-GEMM convs, BN folded) against the fp32 PyTorch
