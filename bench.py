@@ -296,9 +296,9 @@ def main():
                             f"{cond_ms_per_clip / (dt / K * 1e3 / B):.0f} denoising steps' worth",
             "roofline": roofline,
         }
-        if args.layer_mode == 0 and not args.no_small_batch:
+        if args.layer_mode == 0 and not args.no_small_batch and world == 1:
             out["small_batch"] = small_batch_probe(pm, coef, dev)
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:      # the CPU baseline is a 1-GPU-run item: the other ranks would only wait for it
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
