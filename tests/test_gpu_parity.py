@@ -273,6 +273,29 @@ def test_bench_size_batch_is_copies_of_its_clips(beatx):
     assert rel_l2(out[:8].cpu(), want) < FWD_TOL
 
 
+def test_largest_and_empty_batches(beatx):
+    """4096 clips (131 072 token rows, 805 MB of fp32 latents: past any 16-bit / 27-bit index shortcut) as 512 copies of 8
+    clips - every copy bitwise equal to the first, through both tile sizes the library would pick; and the empty batch is
+    refused with an error instead of a launch."""
+    from syntalker_amd import engine
+    from syntalker_amd._lib import SynHipError
+    y8, x8 = synth.synth_clip_inputs(8, seed=22), synth.synth_latent(8, seed=22)
+    t8 = torch.tensor([0, 2, 51, 334, 501, 778, 997, 999])
+    cond8 = beatx.variant_conds(synth.to_device(y8, DEV), [(False, False, None)])[0]
+    B, R = 4096, 512
+    sb = engine.StepBuffers(B, 1, DEV)
+    sb.cond.copy_(cond8.repeat(R, 1, 1).reshape(-1, 512)); sb.load_x(x8.to(DEV).repeat(R, 1, 1, 1))
+    sb.t_model.copy_(t8.int().to(DEV).repeat(R)); sb.t_coef.zero_()
+    engine.run_step(beatx.packed(), sb, engine.identity_coefs(DEV), False)
+    out = sb.read(sb.x)
+    assert torch.isfinite(out).all() and torch.equal(out, out[:8].repeat(R, 1, 1, 1))
+    del sb, out
+    torch.cuda.empty_cache()
+    with pytest.raises((SynHipError, ValueError, RuntimeError)):
+        beatx(torch.zeros(0, 1536, 1, 32, device=DEV), torch.zeros(0, dtype=torch.long, device=DEV),
+              synth.to_device(synth.synth_clip_inputs(1, seed=1), DEV))
+
+
 def test_full_size_properties(beatx):
     """BASELINE-size batch (256 clips): properties that need no oracle.
        (1) t=0 step adds no noise: result independent of the injected noise;
