@@ -3,17 +3,19 @@
 
     python bench.py --gpus N --steps K --warmup W [--batch B]
 
-One "step" = one DDPM denoising step (denoiser evaluation + posterior update, hipGraph replay) over a
-batch of B synthetic 128-frame clips per GPU (latent (B,1536,1,32)); metric = clip-steps/s over ALL
-GPUs (BASELINE.json: "denoising-steps/sec (128-frame clips)").  Workload = configs[1]
+One "step" = one DDPM denoising step (denoiser evaluation + posterior update) over a batch of B synthetic
+128-frame clips per GPU (latent (B,1536,1,32)), issued the way SpacedDiffusion.p_sample_loop issues it:
+device-resident timestep schedule, hipGraph replays of 10 captured steps (single-step graph for the
+remainder); metric = clip-steps/s over ALL GPUs (BASELINE.json: "denoising-steps/sec (128-frame clips)").  Workload = configs[1]
 (diffusion_rvqvae_128 sampling, p_sample_loop, bf16 operands / fp32 accumulate): random-init weights
 of the reference architecture, synthetic audio/word/seed conditioning, computed ONCE per clip before
 the timed region exactly as the fused p_sample_loop does (its cost is reported separately).
 Clips shard across GPUs with no collective (weak scaling: B per GPU is fixed).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel: algorithmic FLOPs per launch / average launch duration (hipEvents around
-                every launch of eager steps run right after the timed region) vs the dense bf16 MFMA peak.
+  roofline      dominant kernel: algorithmic FLOPs per launch / average launch duration (hipEvents on the replay
+                stream around every graph replay of the timed region, divided by the steps it holds; the step is one
+                kernel) vs the dense bf16 MFMA peak; one eager launch afterwards only names the kernel.
   cpu_baseline  the as-written CPU restatement of the reference forward (oracle/) timed on the host cores.
 """
 import argparse
@@ -197,18 +199,32 @@ def main():
     sb.load_x(x_T)
     coef = engine.posterior_coefs(diff.tables(), dev)
     sb.set_rng(1234, first_clip=rank * B)
-    graph = engine.StepGraph(pm, sb, coef, True, fused_rng=True)
+    # The loop exactly as SpacedDiffusion.p_sample_loop runs it (process.py `_fused`): the timestep schedule lives on the
+    # device, hook-free stretches replay a hipGraph of CH = 10 captured steps (one schedule kernel + 10 step kernels),
+    # the remainder a single-step graph.  Noise ~ Philox(seed, step = t, global element index), drawn in the epilogue.
+    CH, MAXS = 10, engine.StepGraph.MAX_STEPS
+    g10 = engine.StepGraph(pm, sb, coef, True, fused_rng=True, scheduled=True, steps=CH)
+    g1 = engine.StepGraph(pm, sb, coef, True, fused_rng=True, scheduled=True)
+    ts = [999 - (i % 1000) for i in range(MAXS)]            # t = 999, 998, ... (wraps: any t is a valid step to time)
+    g10.set_schedule(ts, ts); g1.set_schedule(ts, ts)
+    state = {"pos": 0, "last": None}
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
-
-    def step(i, pair=None):            # exactly the body of the fused p_sample_loop
-        sb.t_coef.fill_(i)
-        sb.t_model.fill_(i)
-        if pair:
-            pair[0].record()           # events on the stream the graph is replayed on: brackets the step kernel(s)
-        graph.replay()                 # noise ~ Philox(seed, step = t, global element index), drawn in the epilogue
-        if pair:
-            pair[1].record()
+    def run_steps(n, events=None):
+        """n consecutive steps; events: list that receives (start, end, steps) hipEvent brackets on the replay stream."""
+        done = 0
+        while done < n:
+            g, k = (g10, CH) if n - done >= CH else (g1, 1)
+            if state["pos"] + k > MAXS:
+                state["pos"], state["last"] = 0, None
+            if state["last"] is not g:                       # hand the schedule position over (one tiny fill per switch)
+                g.counter.fill_(state["pos"]); state["last"] = g
+            if events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); g.replay(); e1.record()
+                events.append((e0, e1, k))
+            else:
+                g.replay()
+            state["pos"] += k; done += k
 
     def barrier():
         torch.cuda.synchronize()
@@ -216,16 +232,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    t_idx = 999
-    for _ in range(W):
-        step(t_idx); t_idx = (t_idx - 1) % 1000
+    run_steps(W)
     barrier()
+    ev = []
     t0 = time.perf_counter()
-    for k in range(K):
-        step(t_idx, ev[k]); t_idx = (t_idx - 1) % 1000
+    run_steps(K, ev)
     barrier()
     dt = time.perf_counter() - t0
-    replay_ms = sum(a.elapsed_time(b) for a, b in ev) / K      # average graph-replay duration inside the timed region
+    assert sum(k for _, _, k in ev) == K
+    replay_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / K   # average per-step duration of the replays inside the timed region
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
