@@ -451,3 +451,21 @@ def test_graph_replayed_train_step(beatx):
     step.close()
     assert all(np.isfinite(losses)) and not torch.equal(before, m.mytimmblocks[0].attn.qkv.weight)
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
+
+
+def test_ddp_wrapper_inside_the_captured_training_step():
+    """One rank over RCCL under torchrun (the GPU boxes have one GPU): `make_ddp(capturable=True)` + `GraphedTrainStep`
+    capture the whole step with the wrapper's bucketed all-reduces inside the graph, and replays keep training
+    (finite, decreasing-ish loss is not asserted: only that eager and replayed steps both run to completion)."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import REPO
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(REPO, "scripts", "bench_train_ddp.py"), "4", "3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "eager DDP step" in r.stdout and "graph-replayed DDP step" in r.stdout, r.stdout[-2000:]
+    loss = float(r.stdout.strip().splitlines()[-1].rsplit("loss", 1)[1])
+    assert loss == loss and abs(loss) < 1e3
