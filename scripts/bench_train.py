@@ -1,5 +1,5 @@
 """Training-step timing (not the contract bench): B clips per GPU, fwd+bwd+Adam, 1 GPU."""
-import sys, time, torch, numpy as np
+import sys, time, torch
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from syntalker_amd import synth, training
 from syntalker_amd.denoiser import MDM

@@ -1,6 +1,6 @@
 """Small-batch path (layer_mode 3) against the whole-step kernel (layer_mode 0): agreement, determinism,
 error flag, and graph-replay step time over batch sizes.  Usage: python scripts/diag_latency.py [reps]"""
-import sys, time, torch
+import sys, torch
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from syntalker_amd import synth, engine
 from syntalker_amd.denoiser import MDM
