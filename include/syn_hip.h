@@ -71,7 +71,8 @@ typedef struct syn_step {
     int32_t m_tile;         /* rows per workgroup: 0 = auto, else 32 / 64 / 128                  */
     int32_t reserved;       /* kernel selection: 0 = auto (small-batch kernel when a group holds <= 4 sequences and
                                ws_sync != NULL, else the whole-step kernel); 4 = whole-step kernel always;
-                               3 = small-batch kernel always; 1 / 2 = five / two kernels per block (A/B)   */
+                               3 = small-batch kernel always; 1 / 2 = five / two kernels per block (A/B);
+                               +8 = never split a tile over several workgroups (see ws_xch)               */
     /* conditioning, row (v*B + b)*32 + frame */
     const float*   cond;    /* [V*B*32][512] per-clip term: cbias + c_frame + seed/style term    */
     const int32_t* t_model; /* [V*B] ORIGINAL timestep -> row of syn_model.te                    */
@@ -102,6 +103,9 @@ typedef struct syn_step {
                           counters; word 256 = sticky error flag: a barrier wait ran out)        */
     float* ws_x0v;     /* [V*B*32][1536] fp32 or NULL; small-batch path with V > 1: lets the variants of a clip run on
                           different XCDs (each writes its x0_hat here, a small second kernel combines them)   */
+    float* ws_xch;     /* [V*B][8][32*512] fp32 or NULL; with it (and ws_sync) batches of 17..128 sequences run the whole-step
+                          kernel with every 32-row tile split over 2 or 4 workgroups of one XCD (heads / MLP slices / output
+                          chunks dealt to the members, partial residual streams exchanged through these slots)      */
 } syn_step;
 
 /* Enqueue one full step on `stream`: one kernel (k_stack, or k_lat for small batches; + k_guided_update when the

@@ -39,7 +39,7 @@ class SynStep(C.Structure):
                 ("x_t", vp), ("x_t_bf16", vp), ("noise", vp), ("rng", vp), ("coef", vp), ("t_coef", vp),
                 ("x_next", vp), ("x_next_bf16", vp), ("pred_x0", vp),
                 ("ws_h", vp), ("ws_xn", vp), ("ws_q", vp), ("ws_k", vp), ("ws_vt", vp), ("ws_o", vp),
-                ("ws_hid", vp), ("ws_hc", vp), ("ws_sync", vp), ("ws_x0v", vp)]
+                ("ws_hid", vp), ("ws_hc", vp), ("ws_sync", vp), ("ws_x0v", vp), ("ws_xch", vp)]
 
 
 class SynWavConv(C.Structure):

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "syn_hip.h"
@@ -834,6 +835,8 @@ __global__ __launch_bounds__(kThreads) void k_mlp_block(const BArgs a) {
 //                 region B 64 KB: { QS 64x256 | KS 64x256 | VTS 2x128x72 } during attention,
 //                                 { HID 2 x 64x512 } during the MLP
 //                 RED 2.5 KB LayerNorm scratch
+#include "syn_latency.inc"
+
 struct SArgs {
     float* H;             // [M][512] fp32 residual stream: read at entry, final value written back
     __bf16* Y;            // [M][512] bf16(h_final): operand of the output GEMM
@@ -841,6 +844,11 @@ struct SArgs {
     int M;
     int write_h;          // also write the final fp32 h (needed only by the guidance combine)
     long long* dbg;
+    // tensor-parallel mode (33..128 sequences, MT = 32): tp = 2 or 4 workgroups of ONE XCD share a tile, each computes
+    // its heads / MLP slices / output chunks, partial residual streams are exchanged through L2 (see k_stack)
+    int tp, tp_tiles;     // members per tile (1 = off), number of tiles
+    unsigned* sync;       // [320]: per XCD at +32x: [0] rank allocation, [1] finished workgroups, [2 + g] barrier of group g
+    float* xch;           // [tiles][2][4][32 * 512] fp32 exchange slots
     // fused input stage (in.X != nullptr): h = rotary(x_t . A^T + cond + te[t]) instead of reading H
     GArgs in;
     // fused output stage (out.Xn != nullptr; single conditioning variant only): x0 = h . Wout^T + b and the
@@ -915,7 +923,7 @@ __device__ __forceinline__ void ln_to_lds(f32x4 (&h)[4][MT / 16], const float* _
     }
 }
 
-template <int MT>
+template <int MT, bool TP = false>
 __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MF = MT / 16;
@@ -927,8 +935,69 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
     char* const Vts = RB + MT * 512;
     float* const red = reinterpret_cast<float*>(RB + MT * 1024);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lr = lane & 15;
-    const int m0 = blockIdx.x * MT;
     constexpr int KS1 = SYN_D / 32, KS2 = SYN_FF / 32;
+    // Tensor-parallel mode: the workgroups of an XCD (hardware XCC id, as in k_lat) take a rank by arrival order; P
+    // consecutive ranks form a group = one tile.  The members hold identical copies of the residual stream; after the
+    // attention and after the MLP each writes the partial sum of ITS heads / hidden slices (member 0's includes the
+    // previous residual) to an L2-resident slot, the group meets at an XCD-local barrier, and everybody adds the P
+    // partials in member order - the same bits in every member.
+    const int P = TP ? a.tp : 1;             // compile-time 1 in the plain instances: their code is unchanged
+    int member = 0, tile = blockIdx.x;
+    unsigned* gctr = nullptr;
+    unsigned* xbase = nullptr;
+    unsigned* const gerr = a.sync ? a.sync + lat::kGroups * 32 : nullptr;
+    unsigned gphase = 0;
+    if constexpr (TP) {
+        __shared__ int s_rank;
+        const int xcd = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u) % lat::kGroups;
+        xbase = a.sync + xcd * 32;
+        if (tid == 0) s_rank = (int)__hip_atomic_fetch_add(xbase, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int rank = s_rank, per_xcd = (int)gridDim.x / lat::kGroups;
+        if (rank >= per_xcd) {                                       // the dispatcher did not deal the workgroups evenly
+            if (tid == 0) __hip_atomic_store(gerr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        member = rank % P;
+        tile = xcd + lat::kGroups * (rank / P);
+        gctr = xbase + 2 + rank / P;
+    }
+    // (tp) leave the counters zeroed for the next launch: the last workgroup of this XCD to finish resets them
+    auto tp_done = [&]() {
+        if (TP && tid == 0) {
+            const unsigned per_xcd = gridDim.x / lat::kGroups;
+            if (__hip_atomic_fetch_add(xbase + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == per_xcd - 1)
+                for (int i = 0; i < 32; ++i) __hip_atomic_store(xbase + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    if (TP && tile >= a.tp_tiles) { tp_done(); return; }           // padding group (tiles are dealt 8 at a time)
+    const int m0 = tile * MT;
+    float* const xch = TP ? a.xch : nullptr;
+    // this member's partial -> sum of all members' partials, in member order (identical bits in every member).  Two slot
+    // sets alternate: a member can be at most one exchange ahead of the slowest reader of the previous one.
+    auto exchange = [&](f32x4 (&hh)[4][MT / 16]) {
+        constexpr int MFX = MT / 16;
+        int et = tid;
+        asm volatile("" : "+v"(et));              // addresses are rebuilt here, not kept live across the blocks
+        float* const set = xch + ((size_t)(tile * 2 + (int)(gphase & 1u)) * 4) * (MT * 512) + et * 4;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < MFX; ++mf)
+                *reinterpret_cast<f32x4*>(set + (size_t)member * (MT * 512) + (nf * MFX + mf) * 2048) = hh[nf][mf];
+        lat::group_release();
+        ++gphase;
+        lat::group_wait(gctr, gphase * (unsigned)P, gerr);
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int mf = 0; mf < MFX; ++mf) {
+                f32x4 sum = *reinterpret_cast<const f32x4*>(set + (nf * MFX + mf) * 2048);
+                for (int j = 1; j < P; ++j)
+                    sum = sum + *reinterpret_cast<const f32x4*>(set + (size_t)j * (MT * 512) + (nf * MFX + mf) * 2048);
+                hh[nf][mf] = sum;
+            }
+    };
     stamp(a.dbg, 0);
 
     f32x4 h[4][MF];
@@ -1063,14 +1132,20 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
         const syn_layer& L = a.layer[HOT(l)];
         // Rings are declared per block so they are dead (not loop-carried registers) outside their phase.
         uint4 rq[DQ][3];                           // qkv ring: primed one phase ahead of its loop
-        kloop_prime<3, 32, KS1, DQ>(rq, wqkv(l, 0), KS1, 0);      // in flight during LayerNorm 1
+        kloop_prime<3, 32, KS1, DQ>(rq, wqkv(l, member), KS1, 0);  // in flight during LayerNorm 1
         const uint4* const wproj = (const uint4*)L.w_proj + ((size_t)(wave * 4) * KS1) * 64 + lane;
         const uint4* const wfc2 = (const uint4*)L.w_fc2 + ((size_t)(wave * 4) * KS2) * 64 + lane;
         // ---- x1 = LN1(h) -> XN;  h += b_proj ------------------------------------------------------------
         ln_to_lds<MT>(h, L.ln1_g, L.ln1_b, L.b_proj, XN, red);
+        if (TP && member != 0) {                 // (tp) only member 0's partial carries the residual and the bias
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) h[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         __syncthreads();
         if (l == 3) stamp(a.dbg, 1);
-        for (int head = 0; head < SYN_HEADS; ++head) {
+        for (int head = member; head < SYN_HEADS; head += P) {
             // ---- q, k, v fragments of this head for all MT rows ------------------------------------------
             f32x4 acc[3][MF];
 #pragma unroll
@@ -1140,7 +1215,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
                 }
             }
             // next qkv ring (next head, or head 0 of the next block) goes in flight before the proj piece
-            if (head + 1 < SYN_HEADS) kloop_prime<3, 32, KS1, DQ>(rq, wqkv(l, head + 1), KS1, 0);
+            if (head + P < SYN_HEADS) kloop_prime<3, 32, KS1, DQ>(rq, wqkv(l, head + P), KS1, 0);
             __syncthreads();
             if (l == 3 && head == 0) stamp(a.dbg, 3);
             // ---- h += o_head . Wproj[:, 128 head .. +128]^T  (K = 128) ---------------------------------------
@@ -1148,15 +1223,23 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
             __syncthreads();
             if (l == 3 && head == 0) stamp(a.dbg, 4);
         }
+        if constexpr (TP) exchange(h);
         if (l == 3) stamp(a.dbg, 5);
         // ---- x2 = LN2(h) -> XN;  h += b_fc2 ------------------------------------------------------------------
         uint4 r1[D1][2];
         auto wfc1 = [&](int c) { return (const uint4*)L.w_fc1 + ((size_t)(HOT(c) * 16 + wave * 2) * KS1) * 64 + lane; };
-        kloop_prime<2, 1, KS1, D1>(r1, wfc1(0), KS1, 0);          // in flight during LayerNorm 2
+        kloop_prime<2, 1, KS1, D1>(r1, wfc1(member), KS1, 0);     // in flight during LayerNorm 2
         ln_to_lds<MT>(h, L.ln2_g, L.ln2_b, L.b_fc2, XN, red);
+        if (TP && member != 0) {
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) h[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         __syncthreads();
         if (l == 3) stamp(a.dbg, 6);
-        for (int c = 0; c < SYN_FF / HC; ++c) {
+        int slice_it = 0;
+        for (int c = member; c < SYN_FF / HC; c += P, ++slice_it) {
             f32x4 a1[2][MF];
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf)
@@ -1165,7 +1248,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
             kloop_run<MF, 2, 1, 0, KS1, 1024, D1>(a1, r1, XN, wfc1(c), KS1, 0);
             uint4 r2[D2][4];
             kloop_prime<4, 1, HC / 32, D2>(r2, wfc2, KS2, HOT(c) * 8);   // in flight during the GELU
-            char* const hb = RB + (c & 1) * (MT * 512);
+            char* const hb = RB + (slice_it & 1) * (MT * 512);
 #pragma unroll
             for (int nf = 0; nf < 2; ++nf) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(L.b_fc1 + c * HC + wave * 32 + nf * 16 + g * 4);
@@ -1177,11 +1260,12 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
                     *reinterpret_cast<bf16x4*>(hb + (mf * 16 + lr) * 512 + ((slot ^ lr) << 4) + (g & 1) * 8) = to_bf16x4(v);
                 }
             }
-            if (c + 1 < SYN_FF / HC) kloop_prime<2, 1, KS1, D1>(r1, wfc1(c + 1), KS1, 0);
+            if (c + P < SYN_FF / HC) kloop_prime<2, 1, KS1, D1>(r1, wfc1(c + P), KS1, 0);
             __syncthreads();
             kloop_run<MF, 4, 1, 0, HC / 32, 512, D2>(h, r2, hb, wfc2, KS2, HOT(c) * 8);
         }
         __syncthreads();        // region B (hidden slices) becomes q/k/v + LayerNorm scratch of the next block
+        if constexpr (TP) exchange(h);
         if (l == 3) stamp(a.dbg, 7);
     }
     if (a.dbg) stamp(a.dbg, 10);
@@ -1196,7 +1280,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
                 *reinterpret_cast<bf16x4*>(XN + (mf * 16 + lr) * 1024 + ((slot ^ lr) << 4) + (g & 1) * 8) = to_bf16x4(h[nf][mf]);
         }
         __syncthreads();
-        for (int c = 0; c < SYN_C / kNT; ++c) {
+        for (int c = member; c < SYN_C / kNT; c += P) {          // (tp) the output chunks are dealt to the members
             f32x4 acc[4][MF];
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
@@ -1273,6 +1357,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
     }
     }
     stamp(a.dbg, 8);
+    if constexpr (TP) tp_done();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1491,6 +1576,18 @@ int launch_stack(const SArgs& a, int mt, hipStream_t s) {
         once = true;
     }
     dim3 grid((a.M + mt - 1) / mt), block(kThreads);
+    if (a.tp > 1) {
+        if (mt != 32 || !a.sync || !a.xch) return fail_msg("stack: the tensor-parallel mode needs 32-row tiles, ws_sync and ws_xch");
+        grid.x = lat::kGroups * a.tp * ((a.tp_tiles + lat::kGroups - 1) / lat::kGroups);    // whole groups on every XCD
+        if (grid.x > 256) return fail_msg("stack: the tensor-parallel mode needs all its workgroups resident (<= 256)");
+    }
+    if (a.tp > 1) {
+        static bool once_tp = false;
+        if (!once_tp) { allow_lds(k_stack<32, true>, 32 * 2048 + 4096); once_tp = true; }
+        hipLaunchKernelGGL((k_stack<32, true>), grid, block, 32 * 2048 + 4096, s, a);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : fail("k_stack launch", e);
+    }
     switch (mt) {
         case 64: hipLaunchKernelGGL(k_stack<64>, grid, block, 64 * 2048 + 4096, s, a); break;
         case 32: hipLaunchKernelGGL(k_stack<32>, grid, block, 32 * 2048 + 4096, s, a); break;
@@ -1500,7 +1597,6 @@ int launch_stack(const SArgs& a, int mt, hipStream_t s) {
     return e == hipSuccess ? 0 : fail("k_stack launch", e);
 }
 
-#include "syn_latency.inc"
 #include "syn_wavenc.inc"
 #include "syn_train.inc"
 #include "syn_rvq.inc"
@@ -1977,7 +2073,14 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     // against layer modes 1 / 2).
     const bool by_seq = V > 1 && st->ws_x0v != nullptr;
     const int per_group = by_seq ? (B * V + lat::kGroups - 1) / lat::kGroups : ((B + lat::kGroups - 1) / lat::kGroups) * V;
-    if (mode == 0 && !(st->reserved & 4) && st->ws_sync && per_group <= 4 && latency_path_ok()) mode = 3;
+    // 17..128 sequences (measured: 280 us per step at 17..64 sequences, 310-345 us at 65..128, against 330-400 us of the
+    // small-batch kernel at 17..32 and 405-413 us of one workgroup per tile above): the whole-step kernel with every
+    // 32-row tile split over 4 (<= 64 sequences) or 2 workgroups of one XCD, see k_stack.  reserved bit 3 (value 8)
+    // switches it off, and so does pinning a kernel (bit 2) or a tile size.
+    const int tiles = V * B;
+    const bool use_tp = mode == 0 && st->m_tile == 0 && !(st->reserved & 12) && st->ws_sync && st->ws_xch &&
+                        tiles >= 17 && tiles <= 128 && latency_path_ok();
+    if (mode == 0 && !use_tp && !(st->reserved & 4) && st->ws_sync && per_group <= 4 && latency_path_ok()) mode = 3;
     if (mode == 3) {
         // small-batch path: one persistent kernel, output features split over the CUs of an XCD
         if (!st->ws_sync) return fail_msg("syn_denoise_step: the latency path needs ws_sync");
@@ -2038,7 +2141,12 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
         for (int l = 0; l < SYN_LAYERS; ++l) sa.layer[l] = md->layer[l];
         sa.in = ain;
         if (fuse_out) sa.out = aout;
-        if ((rc = launch_stack(sa, mt > 64 ? 64 : mt, s))) return rc;
+        int tile_rows = mt > 64 ? 64 : mt;
+        sa.tp = 1;
+        if (use_tp) {
+            sa.tp = tiles <= 64 ? 4 : 2; sa.tp_tiles = tiles; sa.sync = st->ws_sync; sa.xch = st->ws_xch; tile_rows = 32;
+        }
+        if ((rc = launch_stack(sa, tile_rows, s))) return rc;
         mark(ST_FC2);
     } else
     if (fused) {

@@ -201,7 +201,7 @@ def test_c_abi_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.syn_version() == 1
     # struct sizes as the C compiler lays them out (include/syn_hip.h): 4 int32 + 20 pointers; 11 pointers; 760 B
-    assert ctypes.sizeof(_lib.SynStep) == 16 + 8 * 22 and ctypes.sizeof(_lib.SynLayer) == 88
+    assert ctypes.sizeof(_lib.SynStep) == 16 + 8 * 23 and ctypes.sizeof(_lib.SynLayer) == 88
     assert ctypes.sizeof(_lib.SynModel) == 8 * 5 + 88 * 8 + 16
 
 
