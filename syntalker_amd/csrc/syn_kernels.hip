@@ -992,9 +992,11 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
         for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
             for (int mf = 0; mf < MFX; ++mf) {
-                f32x4 sum = *reinterpret_cast<const f32x4*>(set + (nf * MFX + mf) * 2048);
+                // own partial from the register it was stored from (same bits), the others' from L2; member order
+                const f32x4 own = hh[nf][mf];
+                f32x4 sum = member == 0 ? own : *reinterpret_cast<const f32x4*>(set + (nf * MFX + mf) * 2048);
                 for (int j = 1; j < P; ++j)
-                    sum = sum + *reinterpret_cast<const f32x4*>(set + (size_t)j * (MT * 512) + (nf * MFX + mf) * 2048);
+                    sum = sum + (j == member ? own : *reinterpret_cast<const f32x4*>(set + (size_t)j * (MT * 512) + (nf * MFX + mf) * 2048));
                 hh[nf][mf] = sum;
             }
     };
