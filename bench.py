@@ -135,7 +135,7 @@ def small_batch_probe(pm, coef, dev, sizes=(1, 8, 32), reps=300):
         return e0.elapsed_time(e1) * 1e3 / reps
 
     us = {B: timed(B, 0) for B in sizes}
-    return {"kernel": "library's choice: k_lat up to 16 clips (output features split over the 32 CUs of an XCD, L2-local group barriers), k_stack with every tile split over 4 CUs of an XCD at 32",
+    return {"kernel": "library's choice: k_lat up to 8 clips (output features split over the 32 CUs of an XCD, L2-local group barriers), k_stack with every tile split over 4 CUs of an XCD at 32",
             "us_per_step": {str(B): round(t, 1) for B, t in us.items()},
             "clip_steps_per_s": {str(B): round(B / t * 1e6, 0) for B, t in us.items()},
             "whole_step_kernel_us_per_step_B1": round(timed(1, 4), 1)}

@@ -69,8 +69,8 @@ typedef struct syn_step {
     int32_t n_clips;        /* B                                                                 */
     int32_t n_variants;     /* V >= 1                                                            */
     int32_t m_tile;         /* rows per workgroup: 0 = auto, else 32 / 64 / 128                  */
-    int32_t reserved;       /* kernel selection: 0 = auto (small-batch kernel when a group holds <= 4 sequences and
-                               ws_sync != NULL, else the whole-step kernel); 4 = whole-step kernel always;
+    int32_t reserved;       /* kernel selection: 0 = auto (small-batch kernel up to 8 sequences when ws_sync != NULL, the whole-step
+                               kernel with split tiles at 9..128 sequences when ws_xch != NULL, else the whole-step kernel); 4 = whole-step kernel always;
                                3 = small-batch kernel always; 1 / 2 = five / two kernels per block (A/B);
                                +8 = never split a tile over several workgroups (see ws_xch)               */
     /* conditioning, row (v*B + b)*32 + frame */
@@ -103,7 +103,7 @@ typedef struct syn_step {
                           counters; word 256 = sticky error flag: a barrier wait ran out)        */
     float* ws_x0v;     /* [V*B*32][1536] fp32 or NULL; small-batch path with V > 1: lets the variants of a clip run on
                           different XCDs (each writes its x0_hat here, a small second kernel combines them)   */
-    float* ws_xch;     /* [V*B][8][32*512] fp32 or NULL; with it (and ws_sync) batches of 17..128 sequences run the whole-step
+    float* ws_xch;     /* [V*B][8][32*512] fp32 or NULL; with it (and ws_sync) batches of 9..128 sequences run the whole-step
                           kernel with every 32-row tile split over 2 or 4 workgroups of one XCD (heads / MLP slices / output
                           chunks dealt to the members, partial residual streams exchanged through these slots)      */
 } syn_step;

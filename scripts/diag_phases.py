@@ -38,3 +38,7 @@ print("  output stage (3 x 512 cols + posterior)  ", med(t[:, 8] - t[:, 10]))
 print("  total per workgroup                      ", med(t[:, 8] - t[:, 0]))
 print("  output stage detail: to-LDS+gemm0, epi0, gemm1, epi1, gemm2, epi2:", [med(t[:, 11] - t[:, 10]), med(t[:, 12] - t[:, 11]), med(t[:, 13] - t[:, 12]), med(t[:, 14] - t[:, 13]), med(t[:, 15] - t[:, 14]), med(t[:, 16] - t[:, 15])])
 print("  input stage detail: cond/te + first x_t piece in LDS, gemm0, gemm1, gemm2, rotary:", [med(t[:, 17] - t[:, 0]), med(t[:, 18] - t[:, 17]), med(t[:, 19] - t[:, 18]), med(t[:, 20] - t[:, 19]), med(t[:, 9] - t[:, 20])])
+if t[:, 24].max() > 0:
+    print("  tile-split exchange after the attention of block 3: stores + drain, barrier, reads + sums:",
+          [med(t[:, 22] - t[:, 21]), med(t[:, 23] - t[:, 22]), med(t[:, 24] - t[:, 23])], " barrier wait min / max:",
+          int((t[:, 23] - t[:, 22]).min()), int((t[:, 23] - t[:, 22]).max()))

@@ -844,7 +844,7 @@ struct SArgs {
     int M;
     int write_h;          // also write the final fp32 h (needed only by the guidance combine)
     long long* dbg;
-    // tensor-parallel mode (33..128 sequences, MT = 32): tp = 2 or 4 workgroups of ONE XCD share a tile, each computes
+    // tensor-parallel mode (9..128 sequences, MT = 32): tp = 2 or 4 workgroups of ONE XCD share a tile, each computes
     // its heads / MLP slices / output chunks, partial residual streams are exchanged through L2 (see k_stack)
     int tp, tp_tiles;     // members per tile (1 = off), number of tiles
     unsigned* sync;       // [320]: per XCD at +32x: [0] rank allocation, [1] finished workgroups, [2 + g] barrier of group g
@@ -923,7 +923,7 @@ __device__ __forceinline__ void ln_to_lds(f32x4 (&h)[4][MT / 16], const float* _
     }
 }
 
-template <int MT, bool TP = false>
+template <int MT, int TP = 0>       // TP: members per tile in the tile-split mode (0 = off, 2, 4)
 __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MF = MT / 16;
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
     // attention and after the MLP each writes the partial sum of ITS heads / hidden slices (member 0's includes the
     // previous residual) to an L2-resident slot, the group meets at an XCD-local barrier, and everybody adds the P
     // partials in member order - the same bits in every member.
-    const int P = TP ? a.tp : 1;             // compile-time 1 in the plain instances: their code is unchanged
+    constexpr int P = TP ? TP : 1;           // 1 in the plain instances: their code is unchanged
     int member = 0, tile = blockIdx.x;
     unsigned* gctr = nullptr;
     unsigned* xbase = nullptr;
@@ -975,8 +975,9 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
     float* const xch = TP ? a.xch : nullptr;
     // this member's partial -> sum of all members' partials, in member order (identical bits in every member).  Two slot
     // sets alternate: a member can be at most one exchange ahead of the slowest reader of the previous one.
-    auto exchange = [&](f32x4 (&hh)[4][MT / 16]) {
+    auto exchange = [&](f32x4 (&hh)[4][MT / 16], long long* dbg = nullptr) {
         constexpr int MFX = MT / 16;
+        stamp(dbg, 21);
         int et = tid;
         asm volatile("" : "+v"(et));              // addresses are rebuilt here, not kept live across the blocks
         float* const set = xch + ((size_t)(tile * 2 + (int)(gphase & 1u)) * 4) * (MT * 512) + et * 4;
@@ -986,19 +987,37 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
             for (int mf = 0; mf < MFX; ++mf)
                 *reinterpret_cast<f32x4*>(set + (size_t)member * (MT * 512) + (nf * MFX + mf) * 2048) = hh[nf][mf];
         lat::group_release();
+        stamp(dbg, 22);
         ++gphase;
         lat::group_wait(gctr, gphase * (unsigned)P, gerr);
+        stamp(dbg, 23);
+        // the others' partials: all loads of a half (2 x MFX fragments from P - 1 members) are issued before the first add
+        // (a dependent chain of 24 L2 round trips measured 5.7 us here); own partial from the register it was stored
+        // from (same bits); member order
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf)
+        for (int half = 0; half < 2; ++half) {
+            f32x4 v[P][2][MFX];
 #pragma unroll
-            for (int mf = 0; mf < MFX; ++mf) {
-                // own partial from the register it was stored from (same bits), the others' from L2; member order
-                const f32x4 own = hh[nf][mf];
-                f32x4 sum = member == 0 ? own : *reinterpret_cast<const f32x4*>(set + (nf * MFX + mf) * 2048);
-                for (int j = 1; j < P; ++j)
-                    sum = sum + (j == member ? own : *reinterpret_cast<const f32x4*>(set + (size_t)j * (MT * 512) + (nf * MFX + mf) * 2048));
-                hh[nf][mf] = sum;
-            }
+            for (int j = 0; j < P; ++j)
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                    for (int mf = 0; mf < MFX; ++mf)
+                        if (j != member)
+                            v[j][n2][mf] = *reinterpret_cast<const f32x4*>(set + (size_t)j * (MT * 512) + ((half * 2 + n2) * MFX + mf) * 2048);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                for (int mf = 0; mf < MFX; ++mf) {
+                    const f32x4 own = hh[half * 2 + n2][mf];
+                    f32x4 sum = member == 0 ? own : v[0][n2][mf];
+#pragma unroll
+                    for (int j = 1; j < P; ++j) sum = sum + (j == member ? own : v[j][n2][mf]);
+                    hh[half * 2 + n2][mf] = sum;
+                }
+        }
+        if (dbg) { __builtin_amdgcn_s_waitcnt(0); stamp(dbg, 24); }
     };
     stamp(a.dbg, 0);
 
@@ -1225,7 +1244,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
             __syncthreads();
             if (l == 3 && head == 0) stamp(a.dbg, 4);
         }
-        if constexpr (TP) exchange(h);
+        if constexpr (TP) exchange(h, l == 3 ? a.dbg : nullptr);
         if (l == 3) stamp(a.dbg, 5);
         // ---- x2 = LN2(h) -> XN;  h += b_fc2 ------------------------------------------------------------------
         uint4 r1[D1][2];
@@ -1585,8 +1604,10 @@ int launch_stack(const SArgs& a, int mt, hipStream_t s) {
     }
     if (a.tp > 1) {
         static bool once_tp = false;
-        if (!once_tp) { allow_lds(k_stack<32, true>, 32 * 2048 + 4096); once_tp = true; }
-        hipLaunchKernelGGL((k_stack<32, true>), grid, block, 32 * 2048 + 4096, s, a);
+        if (!once_tp) { allow_lds(k_stack<32, 2>, 32 * 2048 + 4096); allow_lds(k_stack<32, 4>, 32 * 2048 + 4096); once_tp = true; }
+        if (a.tp == 4) hipLaunchKernelGGL((k_stack<32, 4>), grid, block, 32 * 2048 + 4096, s, a);
+        else if (a.tp == 2) hipLaunchKernelGGL((k_stack<32, 2>), grid, block, 32 * 2048 + 4096, s, a);
+        else return fail_msg("stack: tile split over 2 or 4 workgroups only");
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : fail("k_stack launch", e);
     }
@@ -2075,13 +2096,13 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     // against layer modes 1 / 2).
     const bool by_seq = V > 1 && st->ws_x0v != nullptr;
     const int per_group = by_seq ? (B * V + lat::kGroups - 1) / lat::kGroups : ((B + lat::kGroups - 1) / lat::kGroups) * V;
-    // 17..128 sequences (measured: 280 us per step at 17..64 sequences, 310-345 us at 65..128, against 330-400 us of the
-    // small-batch kernel at 17..32 and 405-413 us of one workgroup per tile above): the whole-step kernel with every
+    // 9..128 sequences (measured: 216-231 us per step at 9..48 sequences, 270 at 64, 312-337 us at 65..128, against
+    // 235-400 us of the small-batch kernel at 9..32 and 405-413 us of one workgroup per tile above): the whole-step kernel with every
     // 32-row tile split over 4 (<= 64 sequences) or 2 workgroups of one XCD, see k_stack.  reserved bit 3 (value 8)
     // switches it off, and so does pinning a kernel (bit 2) or a tile size.
     const int tiles = V * B;
     const bool use_tp = mode == 0 && st->m_tile == 0 && !(st->reserved & 12) && st->ws_sync && st->ws_xch &&
-                        tiles >= 17 && tiles <= 128 && latency_path_ok();
+                        tiles >= 9 && tiles <= 128 && latency_path_ok();
     if (mode == 0 && !use_tp && !(st->reserved & 4) && st->ws_sync && per_group <= 4 && latency_path_ok()) mode = 3;
     if (mode == 3) {
         // small-batch path: one persistent kernel, output features split over the CUs of an XCD

@@ -115,8 +115,8 @@ class StepBuffers:
         # guided small batches: per-variant x0_hat, so that the variants of a clip can run on different XCDs
         self.x0v = e(R, CH) if (V > 1 and B * V <= 32) else None
         s.ws_x0v = _lib.ptr(self.x0v)
-        # 17..128 sequences: exchange slots for the whole-step kernel's tensor-parallel mode (a tile split over 2 / 4 CUs)
-        self.xch = e(V * B, 8, 32 * D) if 16 < V * B <= 128 else None
+        # 9..128 sequences: exchange slots for the whole-step kernel's tensor-parallel mode (a tile split over 2 / 4 CUs)
+        self.xch = e(V * B, 8, 32 * D) if 8 < V * B <= 128 else None
         s.ws_xch = _lib.ptr(self.xch)
         self.c = s
 
