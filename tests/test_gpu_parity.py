@@ -212,6 +212,25 @@ def test_h3d_guidance_vs_golden(h3d, golden, kernel):
         assert e < FWD_TOL * 4, e
 
 
+def test_h3d_guidance_vs_golden_in_a_split_tile_batch(h3d, golden):
+    """The guided golden case (2 clips) tiled 6 times: 12 clips x 2 / 3 variants = 24 / 36 sequences, the range in which the
+    whole-step kernel splits every tile over 4 workgroups; every copy must reproduce the reference's guided outputs."""
+    from syntalker_amd import guidance as G
+    y2 = synth.synth_clip_inputs(2, seed=7, style_dim=256, style_zero=False)
+    y = synth.to_device({k: (v.repeat(6, *([1] * (v.dim() - 1))) if torch.is_tensor(v) else v) for k, v in y2.items()}, DEV)
+    x = synth.synth_latent(2, seed=7).repeat(6, 1, 1, 1).to(DEV)
+    t = torch.tensor([10, 700], device=DEV).repeat(6)
+    with torch.no_grad():
+        yc = dict(y, scale=torch.ones(1, device=DEV) * 2.5)
+        out = G.ClassifierFreeSampleModel(h3d)(x, t, yc).cpu()
+        for k in range(6):
+            assert rel_l2(out[2 * k:2 * k + 2], golden["h3d.cfg"]) < FWD_TOL * 2, k
+        yc = dict(y, scale_audio=torch.ones(1, device=DEV), scale_prompt=torch.ones(1, device=DEV) * 4.0)
+        out = G.TwoClassifierFreeSampleModel(h3d)(x, t, yc).cpu()
+        for k in range(6):
+            assert rel_l2(out[2 * k:2 * k + 2], golden["h3d.twocfg"]) < FWD_TOL * 4, k
+
+
 def _bodypart_case():
     y = synth.synth_clip_inputs(1, seed=8, style_dim=256, style_zero=False)
     g = synth._gen("part_prompts", 8)
