@@ -278,7 +278,7 @@ class GaussianDiffusion:
             sched = (indices, [int(tmap[i]) for i in indices])              # timesteps advance on the device
             hooks = each is not None or (noisy and step_noise is not None) or progress
             CH = 10                                                         # steps per replay when nothing happens in between
-            n_multi = 0 if hooks or sb.B * sb.V > 64 else len(indices) // CH
+            n_multi = 0 if hooks else len(indices) // CH
             graph = graph_of(1)                                             # (both captured before the loop starts)
             if n_multi:
                 multi = graph_of(CH)
