@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — denoising-steps/sec of the SynTalker hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--batch B]
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--mode sample|train]
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks (one process per GPU,
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`); under an external launcher
+(the driver's torchrun line) it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment as before.
 
 One "step" = one DDPM denoising step (denoiser evaluation + posterior update) over a batch of B synthetic
 128-frame clips per GPU (latent (B,1536,1,32)), issued the way SpacedDiffusion.p_sample_loop issues it:
@@ -11,6 +15,10 @@ remainder); metric = clip-steps/s over ALL GPUs (BASELINE.json: "denoising-steps
 of the reference architecture, synthetic audio/word/seed conditioning, computed ONCE per clip before
 the timed region exactly as the fused p_sample_loop does (its cost is reported separately).
 Clips shard across GPUs with no collective (weak scaling: B per GPU is fixed).
+
+--mode train times BASELINE.json configs[2] instead (training step: 32 clips per GPU, uniform timestep sampler,
+training_losses forward + backward, clip 0.99, Adam 5e-5 / (0.5, 0.999), DDP all-reduce of the 29.6 M gradients over
+RCCL; reference seam train.py:87-94): metric = training samples/s over all GPUs + a forward / backward / optimiser split.
 
 Extra objects on the JSON line:
   roofline      dominant kernel: algorithmic FLOPs per launch / average launch duration (hipEvents on the replay
@@ -100,13 +108,24 @@ def cpu_baseline(budget_s: float):
             dth = time.perf_counter() - t1
             if dth > budget_s / 4 and nh >= 20:
                 break
+        # SURVEY 8d also asks for B = 40 (the reference's own test batch): a bounded sample of whole-batch forwards
+        y40, x40 = synth.synth_clip_inputs(40, seed=2), synth.synth_latent(40, seed=2)
+        dr.mdm_forward(sd, x40, torch.full((40,), 999), y40)
+        n40, t2 = 0, time.perf_counter()
+        while True:
+            dr.mdm_forward(sd, x40, torch.full((40,), 996 - n40), y40)
+            n40 += 1
+            dt40 = time.perf_counter() - t2
+            if dt40 > budget_s / 3 and n40 >= 2:
+                break
     torch.set_num_threads(all_cores)
     return {"value": round(n / dt, 2), "unit": "clip-steps/s", "cores": best, "kind": "port",
-            "hoisted_value": round(nh / dth, 2),
+            "hoisted_value": round(nh / dth, 2), "value_b40": round(40 * n40 / dt40, 2),
             "sample": f"{n} as-written MDM forwards at B=1 (fp32, torch {torch.__version__} CPU, {best} of {all_cores} "
                       f"threads = fastest of a probe {({k: round(v, 1) for k, v in probe.items()})}, conditioning "
                       f"recomputed every step like the reference), {dt:.1f} s; hoisted_value = the same with the conditioning "
-                      f"computed once and the input stage folded ({nh} forwards, {dth:.1f} s)"}
+                      f"computed once and the input stage folded ({nh} forwards, {dth:.1f} s); value_b40 = as-written forwards at B=40 "
+                      f"({n40} forwards, {dt40:.1f} s, same thread count)"}
 
 
 def small_batch_probe(pm, coef, dev, sizes=(1, 8, 32), reps=300):
@@ -140,36 +159,203 @@ def small_batch_probe(pm, coef, dev, sizes=(1, 8, 32), reps=300):
             "clip_steps_per_s": {str(B): round(B / t * 1e6, 0) for B, t in us.items()},
             "whole_step_kernel_us_per_step_B1": round(timed(1, 4), 1)}
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU) through
+    torch.distributed.run on a free local port, stream rank 0's JSON line through, return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on these hosts (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def timed_region(step, K, W, world, dist, sync):
+    """The contract's timing: W untimed steps, then exactly K steps between barrier + device synchronisation on both
+    sides; returns the MAX over ranks of the elapsed seconds."""
+    def barrier():
+        sync()
+        if world > 1:
+            dist.barrier()
+        sync()
+    for _ in range(W):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            tt = tt.cuda()
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt
+
+
+def dry_run(args, rank, world, dist):
+    """Launch-path check on a GPU-less machine: the ranks rendezvous over gloo, run the barrier-bracketed timing loop
+    around a trivial CPU step and rank 0 reports.  Nothing here is a measurement of the hot path."""
+    acc = torch.zeros(1)
+    def step():
+        acc.add_(1.0)
+    K, W = args.steps, args.warmup
+    dt = timed_region(step, K, W, world, dist, lambda: None)
+    assert float(acc) == K + W
+    B = args.batch or (32 if args.mode == "train" else 1024)
+    return {"metric": "dry run (launch path only, no GPU work)", "value": None, "unit": None, "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 4), "dry_run": True, "mode": args.mode, "clips_per_gpu": B} if rank == 0 else None
+
+
+F_TRAIN = 3 * 5.90e9               # algorithmic FLOPs per training sample: fwd + bwd through the as-written model (SURVEY.md 8d)
+
+
+def run_train(args, rank, local, world, dev, dist):
+    """BASELINE configs[2]: one optimiser step over 32 clips per GPU (global batch 32 x N), data-parallel.  The step is the body
+    of the reference's loop (diffusion_rvqvae_trainer.py:339-356, 555-560): sample t, training_losses forward, backward (DDP: bucketed
+    RCCL all-reduce of the gradients overlapped with it), clip_grad_norm 0.99, Adam.  Nothing is skipped inside the timed region."""
+    from syntalker_amd import synth, training
+    from syntalker_amd.denoiser import MDM
+    from syntalker_amd.process import create_gaussian_diffusion
+    from syntalker_amd.resample import create_named_schedule_sampler
+
+    B, K, W = args.batch or 32, args.steps, args.warmup
+    diff = create_gaussian_diffusion()
+    sampler = create_named_schedule_sampler("uniform", diff)
+    y = synth.to_device(synth.synth_clip_inputs(B, seed=1 + rank, mask_batch=B), dev)
+    y["audio"] = torch.randn(B, 68266, 2, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + rank))   # training clip length
+    x0 = synth.synth_latent(B, seed=1 + rank, name="x0").to(dev)
+    model = synth.synth_fill_(MDM(synth.default_args()).train(), 0).to(dev)
+    graph = args.train_graph
+    net = model
+    side = torch.cuda.Stream(device=dev) if graph else torch.cuda.current_stream(dev)
+    if world > 1:
+        with torch.cuda.stream(side):                           # DDP is built on the stream its iterations run on
+            net = training.make_ddp(model, local, capturable=graph)
+        torch.cuda.current_stream(dev).wait_stream(side)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-5, betas=(0.5, 0.999), capturable=graph)
+    if graph:
+        g = training.GraphedTrainStep(net, diff, opt, x0, {"y": y}, warmup=11 if world > 1 else 3, stream=side)
+        last = {}
+        def step():
+            last["loss"] = g(x0, sampler.sample(B, x0.device)[0], {"y": y})
+    else:
+        last = {}
+        def step():
+            last["loss"] = training.train_step(net, diff, sampler, opt, x0, {"y": y})
+    dt = timed_region(step, K, max(W, 3), world, dist, torch.cuda.synchronize)
+    loss = float(last["loss"])
+    assert loss == loss, "non-finite training loss"
+    # forward / backward / clip+Adam split of one eager step (hipEvents on the current stream; rank 0 only reports it)
+    split = None
+    if not graph:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        acc = [0.0, 0.0, 0.0]
+        for _ in range(3):
+            t, _w = sampler.sample(B, x0.device)
+            opt.zero_grad(set_to_none=True)
+            ev[0].record()
+            l = diff.training_losses(net, x0, t, model_kwargs={"y": y})["loss"].mean()
+            ev[1].record()
+            l.backward()
+            ev[2].record()
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 0.99)
+            opt.step()
+            ev[3].record()
+            torch.cuda.synchronize()
+            for i in range(3):
+                acc[i] += ev[i].elapsed_time(ev[i + 1]) / 3
+        split = {"forward_ms": round(acc[0], 3), "backward_ms" + ("_incl_allreduce" if world > 1 else ""): round(acc[1], 3),
+                 "clip_adam_ms": round(acc[2], 3)}
+    if graph:
+        g.close()
+    if rank != 0:
+        return None
+    value = world * B * K / dt
+    return {"metric": "training samples/sec (128-frame clips)", "value": round(value, 1), "unit": "samples/s", "n_gpus": world,
+            "steps": K, "warmup": max(W, 3), "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16 GEMM operands / fp32 accumulate, fp32 convolutions and master weights", "data": "synthetic",
+            "config": {"workload": f"diffusion_rvqvae_128.yaml training step: {B} clips/GPU (global {world * B}), training_losses fwd+bwd, "
+                                   "clip 0.99, Adam 5e-5 (0.5, 0.999), MDM denoiser 8x512 + trained WavEncoder, random-init",
+                       "clips_per_gpu": B, "global_batch": world * B,
+                       "parallelism": f"dp{world}: one process per GPU, DDP bucketed all-reduce of 29.6 M gradients over RCCL" if world > 1 else "single GPU",
+                       "graph_replayed": graph},
+            "loss": round(loss, 5), "step_split": split,
+            "roofline": {"bound": "mfma", "achieved": round(value / world * F_TRAIN / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                         "frac": round(value / world * F_TRAIN / PEAK_BF16, 4), "traffic": None,
+                         "note": "whole step (~1000 launches), F_train = 17.7 GFLOP per sample; no single dominant kernel"}}
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1024, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default 1024 in sample mode, 32 in train mode)")
     ap.add_argument("--m-tile", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the B = 1 / 8 / 32 probe (clean per-kernel profiles)")
+    ap.add_argument("--mode", choices=("sample", "train"), default="sample",
+                    help="sample: BASELINE configs[1] (DDPM p_sample_loop steps); train: configs[2] (DDP training step, 32 clips/GPU)")
+    ap.add_argument("--train-graph", action="store_true", help="train mode: replay the whole step (incl. the all-reduces) from one hipGraph")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: exercises rank start-up, rendezvous (gloo), the barrier / max-over-ranks timing and the JSON line on CPU")
     ap.add_argument("--layer-mode", type=int, default=0, help="0 library's choice (whole-step kernel at the bench batch), 4 / 3 pin the whole-step / small-batch kernel, "
                          "2 two kernels/block, 1 five kernels/block (A/B)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    dist = None
+    if args.dry_run:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            sys.exit("bench.py: no GPU visible (the hot path has no CPU fallback; --dry-run exercises the launch path only)")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        if args.dry_run:
+            dist.init_process_group("gloo")
+        else:
+            if args.mode == "train" and args.train_graph:
+                os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")   # whole-step capture: no watchdog thread on the stream
+            dist.init_process_group("nccl", device_id=dev)          # backend "nccl" = RCCL on ROCm
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    if args.dry_run:
+        out = dry_run(args, rank, world, dist)
+    elif args.mode == "train":
+        out = run_train(args, rank, local, world, dev, dist)
+    else:
+        out = run_sample(args, rank, local, world, dev, dist)
+    if rank == 0:
+        out["rccl_ranks" if not args.dry_run else "gloo_ranks"] = ranks_seen
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()                 # ranks leave together (rank 0 may still have been timing the CPU baseline)
+        dist.destroy_process_group()
 
+
+def run_sample(args, rank, local, world, dev, dist):
     from syntalker_amd import _lib, engine, synth
     from syntalker_amd.denoiser import MDM
     from syntalker_amd.process import create_gaussian_diffusion
 
-    B, K, W = args.batch, args.steps, args.warmup
+    B, K, W = args.batch or 1024, args.steps, args.warmup
     model = synth.synth_fill_(MDM(synth.default_args()).eval(), seed=0).to(dev)
     model.m_tile = args.m_tile
     model.layer_mode = args.layer_mode
@@ -291,6 +477,9 @@ def main():
                     traffic = pj.get("hbm_bytes_per_launch", {}).get(dom)
             except Exception:
                 traffic = None
+        if traffic is not None and traffic / avg_s > 8.0e12:       # more bytes than HBM can move in one launch: a parsing artefact
+            print(f"bench.py: roofline.traffic {traffic} B / {avg_s * 1e6:.0f} us exceeds 8 TB/s - dropped", file=sys.stderr)
+            traffic = None
         roofline = {"bound": "mfma", "kernel": dom.replace("MT", str(args.m_tile or "auto")),
                     "achieved": round(achieved / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16, 4), "traffic": traffic,
@@ -316,10 +505,8 @@ def main():
         if not args.no_cpu and world == 1:      # the CPU baseline is a 1-GPU-run item: the other ranks would only wait for it
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()                 # ranks leave together (rank 0 may still have been timing the CPU baseline)
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == "__main__":

@@ -1,17 +1,27 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/prof_final_* and gpurun_out/pmc_* (scripts/prof_round.sh) into the committed summaries under
 profiles/ (kernel-stats tables, PMC tables, pmc_traffic.json read by bench.py).  Usage: scripts/collect_profiles.py rNN"""
-import json, os, subprocess, sys
+import csv, io, json, os, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 rd = lambda p: open(os.path.join(R, p)).read().strip()
-def val(part, kernel, col):
-    lines = rd(f"gpurun_out/pmc_{part}/summary.txt").splitlines()
-    names = lines[0].split(",")
+def parse_summary(text):
+    """Rows of a pmc summary as dicts.  Kernel names may contain commas (template arguments); summaries written
+    before the writer quoted them are still read correctly: the numeric columns are taken from the right."""
+    lines = [l for l in text.splitlines() if l and not l.startswith("#")]
+    names = next(csv.reader(io.StringIO(lines[0])))
+    rows = []
     for l in lines[1:]:
-        f = l.split(",")
-        if kernel in f[0]:
-            return float(f[names.index(col)])
+        f = next(csv.reader(io.StringIO(l)))
+        extra = len(f) - len(names)
+        if extra > 0:                                    # unquoted commas inside the kernel name
+            f = [",".join(f[:extra + 1])] + f[extra + 1:]
+        rows.append(dict(zip(names, f)))
+    return rows
+def val(part, kernel, col):
+    for r in parse_summary(rd(f"gpurun_out/pmc_{part}/summary.txt")):
+        if kernel in r["kernel"]:
+            return float(r[col])
     raise KeyError((part, kernel, col))
 notes = {"b1024": "bench.py --steps 30 --warmup 5 --no-small-batch, B = 1024 clips: whole-step kernel k_stack<64>",
          "b8": "bench.py --batch 8 --steps 300 --warmup 20 --no-small-batch: persistent small-batch kernel k_lat, one clip per XCD"}

@@ -15,7 +15,9 @@ with open(sys.argv[1]) as f:
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
 names = sorted({c for v in acc.values() for c in v})
-print("kernel,dispatches," + ",".join(names))
+# csv.writer quotes kernel names that contain commas (template arguments: "k_stack<64, false>")
+out = csv.writer(sys.stdout, lineterminator="\n")
+out.writerow(["kernel", "dispatches"] + names)
 for k in sorted(acc):
     n = len(disp[k])
-    print(f"{k},{n}," + ",".join(f"{acc[k].get(c, 0.0) / n:.4g}" for c in names))
+    out.writerow([k, n] + [f"{acc[k].get(c, 0.0) / n:.4g}" for c in names])

@@ -1,0 +1,47 @@
+"""bench.py's launch path on a GPU-less machine: `--gpus N` starts its own N ranks (torch.distributed.run, 127.0.0.1),
+they rendezvous (gloo in --dry-run), run the barrier-bracketed timing loop and rank 0 prints ONE JSON line.
+The hot path itself never runs here (it has no CPU fallback); on hardware the same code path uses RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra, env=None):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--dry-run", "--steps", "4", "--warmup", "1", *extra],
+                       capture_output=True, text=True, timeout=240, env=e)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, lines
+
+
+@pytest.mark.parametrize("mode", ["sample", "train"])
+def test_bench_starts_its_own_ranks(mode):
+    r, lines = _run("--gpus", "2", "--mode", mode)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout                      # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["gloo_ranks"] == 2 and out["steps"] == 4 and out["dry_run"] is True and out["mode"] == mode
+
+
+def test_bench_single_rank_and_launcher_mismatch():
+    r, lines = _run()
+    assert r.returncode == 0 and json.loads(lines[0])["n_gpus"] == 1
+    # under an external launcher that started a different number of ranks the script refuses instead of mis-reporting
+    r, lines = _run("--gpus", "4", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_refuses_to_run_the_hot_path_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    e = dict(os.environ); e.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1"], capture_output=True, text=True, timeout=240, env=e)
+    assert r.returncode != 0 and "no GPU visible" in r.stderr
