@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SYN_ABI_VERSION 1
+#define SYN_ABI_VERSION 2
 #define SYN_D        512   /* hidden width               (models/denoiser.py:19)  */
 #define SYN_T        32    /* latent frames per clip     (128 pose frames / 4)    */
 #define SYN_C        1536  /* latent channels            (models/denoiser.py:37)  */
@@ -61,6 +61,11 @@ typedef struct syn_model {
     syn_layer    layer[SYN_LAYERS];
     const void*  w_out;     /* packed bf16 (1536 x 512): output_process.poseFinal.weight         */
     const float* b_out;     /* (1536)                                                            */
+    /* the same weights as ONE contiguous tape of 1 KB MFMA fragments in consumption order + per-block bias sets, for the
+     * wave-per-sequence step kernel (large batches; host: syntalker_amd/tape.py).  NULL = that kernel is never chosen. */
+    const void*  tape;        /* bf16 [tape_chunks][16 fragments][64 lanes][8]                    */
+    const float* tape_bias;   /* [9][4096]                                                        */
+    int32_t      tape_chunks; /* 2240                                                             */
 } syn_model;
 
 /* One denoising step over n_clips clips, each evaluated under n_variants conditionings
@@ -72,6 +77,7 @@ typedef struct syn_step {
     int32_t reserved;       /* kernel selection: 0 = auto (small-batch kernel up to 8 sequences when ws_sync != NULL, the whole-step
                                kernel with split tiles at 9..128 sequences when ws_xch != NULL, else the whole-step kernel); 4 = whole-step kernel always;
                                3 = small-batch kernel always; 1 / 2 = five / two kernels per block (A/B);
+                               5 = wave-per-sequence kernel always (needs x_fragment_order = 1);
                                +8 = never split a tile over several workgroups (see ws_xch)               */
     /* conditioning, row (v*B + b)*32 + frame */
     const float*   cond;    /* [V*B*32][512] per-clip term: cbias + c_frame + seed/style term    */
@@ -106,7 +112,16 @@ typedef struct syn_step {
     float* ws_xch;     /* [V*B][8][32*512] fp32 or NULL; with it (and ws_sync) batches of 9..128 sequences run the whole-step
                           kernel with every 32-row tile split over 2 or 4 workgroups of one XCD (heads / MLP slices / output
                           chunks dealt to the members, partial residual streams exchanged through these slots)      */
+    int32_t x_fragment_order; /* 0: x_t / x_t_bf16 / noise / x_next / pred_x0 are token-major (above); 1: they are in the
+                          wave-per-sequence kernel's fragment order (syn_x_to_fragment), and that kernel runs the step
+                          (n_variants must be 1, syn_model.tape non-NULL).  syn_prefers_fragment_order() says when the
+                          library would like a caller to keep its latent that way.                                   */
+    int32_t reserved2;
 } syn_step;
+
+/* 1 when a step over n_clips x n_variants is best run by the wave-per-sequence kernel, i.e. the caller should keep the
+ * latent in fragment order for the whole loop (large single-variant batches); 0 otherwise. */
+int32_t syn_prefers_fragment_order(int32_t n_clips, int32_t n_variants);
 
 /* Enqueue one full step on `stream`: one kernel (k_stack, or k_lat for small batches; + k_guided_update when the
  * variants of a small guided batch were dealt to different XCDs), or the 42-kernel A/B path (reserved = 1). */
@@ -173,6 +188,12 @@ int syn_pack_weight(const float* w, int32_t n, int32_t k, void* out_packed, void
 int syn_pack_weight_t(const void* s_kn, int32_t is_bf16, int32_t n, int32_t k, void* out_packed, void* stream);
 
 /* ---- layout at loop entry / exit ----------------------------------------------------------- */
+/* Fragment order of the wave-per-sequence kernel: fp32 [clip][channel/32][q][lane = 32 hi + frame][r] holds channel
+ * 32 nf + 8 q + 4 hi + r (what a lane owns after the output GEMM); bf16 [clip][channel/32][c][lane][e] holds channel
+ * 32 nf + 16 c + 8 (e >> 2) + 4 hi + (e & 3) (the B operand of the input GEMM).  (B,1536,1,32) fp32 -> both (nullable). */
+int syn_x_to_fragment(const float* x_bct, int32_t n_clips, float* out_f32, void* out_bf16, void* stream);
+/* fragment-order fp32 -> (B,1536,1,32) fp32. */
+int syn_x_from_fragment(const float* x_frag, int32_t n_clips, float* out_bct, void* stream);
 /* (B,1536,1,32) fp32 -> token-major fp32 (nullable) and bf16 (nullable). */
 int syn_to_token_major(const float* x_bct, int32_t n_clips, float* out_f32, void* out_bf16, void* stream);
 /* token-major fp32 -> (B,1536,1,32) fp32. */

@@ -18,7 +18,7 @@ EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_ste
            "syn_wav_encode", "syn_wav_workspace_bytes", "syn_wav_out_frames",
            "syn_vq_conv1d", "syn_vq_quantize", "syn_vq_quantize_groups", "syn_vq_codes",
            "syn_vq_workspace_bytes", "syn_vq_map2latent", "syn_vq_latent2origin", "syn_vq_forward_decoder",
-           "syn_step_advance", "syn_steps_advance", "syn_ln_fwd", "syn_ln_bwd", "syn_gelu_fwd", "syn_gelu_bwd", "syn_attn_fwd", "syn_attn_bwd")
+           "syn_step_advance", "syn_steps_advance", "syn_prefers_fragment_order", "syn_x_to_fragment", "syn_x_from_fragment", "syn_ln_fwd", "syn_ln_bwd", "syn_gelu_fwd", "syn_gelu_bwd", "syn_attn_fwd", "syn_attn_bwd")
 
 vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
 
@@ -30,7 +30,8 @@ class SynLayer(C.Structure):
 
 class SynModel(C.Structure):
     _fields_ = [("w_in", vp), ("te", vp), ("n_te", i32), ("rot_cos", vp), ("rot_sin", vp),
-                ("layer", SynLayer * SYN_LAYERS), ("w_out", vp), ("b_out", vp)]
+                ("layer", SynLayer * SYN_LAYERS), ("w_out", vp), ("b_out", vp),
+                ("tape", vp), ("tape_bias", vp), ("tape_chunks", i32)]
 
 
 class SynStep(C.Structure):
@@ -39,7 +40,8 @@ class SynStep(C.Structure):
                 ("x_t", vp), ("x_t_bf16", vp), ("noise", vp), ("rng", vp), ("coef", vp), ("t_coef", vp),
                 ("x_next", vp), ("x_next_bf16", vp), ("pred_x0", vp),
                 ("ws_h", vp), ("ws_xn", vp), ("ws_q", vp), ("ws_k", vp), ("ws_vt", vp), ("ws_o", vp),
-                ("ws_hid", vp), ("ws_hc", vp), ("ws_sync", vp), ("ws_x0v", vp), ("ws_xch", vp)]
+                ("ws_hid", vp), ("ws_hc", vp), ("ws_sync", vp), ("ws_x0v", vp), ("ws_xch", vp),
+                ("x_fragment_order", i32), ("reserved2", i32)]
 
 
 class SynWavConv(C.Structure):
@@ -85,6 +87,9 @@ def load():
     lib.syn_pack_weight_t.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.syn_to_token_major.argtypes = [vp, i32, vp, vp, vp]
     lib.syn_from_token_major.argtypes = [vp, i32, vp, vp]
+    lib.syn_x_to_fragment.argtypes = [vp, i32, vp, vp, vp]
+    lib.syn_x_from_fragment.argtypes = [vp, i32, vp, vp]
+    lib.syn_prefers_fragment_order.argtypes = [i32, i32]
     lib.syn_axpby_rows.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     lib.syn_randn.argtypes = [vp, i64, u64, u64, i64, vp]
     lib.syn_linear.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
@@ -130,6 +135,7 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def current_stream():
+def current_stream(device=None):
+    """Raw hipStream_t of torch's current stream on `device` (a tensor's device; default: the current device)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(device).cuda_stream

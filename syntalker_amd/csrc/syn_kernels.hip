@@ -1620,6 +1620,7 @@ int launch_stack(const SArgs& a, int mt, hipStream_t s) {
     return e == hipSuccess ? 0 : fail("k_stack launch", e);
 }
 
+#include "syn_seq.inc"
 #include "syn_wavenc.inc"
 #include "syn_train.inc"
 #include "syn_rvq.inc"
@@ -1665,6 +1666,14 @@ int launch_latency(const lat::LArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(lat::k_lat, dim3(lat::kGroups * lat::kP), dim3(kThreads), lat::kLds, s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_lat launch", e);
+}
+
+int launch_seq(const seq::QArgs& a, hipStream_t s) {
+    static bool once = false;
+    if (!once) { allow_lds(seq::k_seq, seq::kLds); once = true; }
+    hipLaunchKernelGGL(seq::k_seq, dim3((a.R + 3) / 4), dim3(seq::kThreads), seq::kLds, s, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_seq launch", e);
 }
 
 // k_lat is written for 8 XCDs x 32 CUs (MI355X in SPX mode): one workgroup per CU, all co-resident.
@@ -1724,6 +1733,25 @@ int syn_to_token_major(const float* x_bct, int32_t n_clips, float* out_f32, void
                        (__bf16*)out_bf16);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_to_token_major launch", e);
+}
+
+int32_t syn_prefers_fragment_order(int32_t n_clips, int32_t n_variants) {
+    // one workgroup = 4 sequences; below ~3/4 of the chip's CUs the token-resident kernel's 32/64-row tiles fill more CUs
+    return n_variants == 1 && n_clips >= 768 ? 1 : 0;
+}
+
+int syn_x_to_fragment(const float* x_bct, int32_t n_clips, float* out_f32, void* out_bf16, void* stream) {
+    if (!x_bct || n_clips <= 0) return fail_msg("syn_x_to_fragment: bad arguments");
+    hipLaunchKernelGGL(seq::k_x_to_fragment, dim3(n_clips, SYN_C / 32), dim3(256), 0, (hipStream_t)stream, x_bct, out_f32, (uint4*)out_bf16);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_x_to_fragment launch", e);
+}
+
+int syn_x_from_fragment(const float* x_frag, int32_t n_clips, float* out_bct, void* stream) {
+    if (!x_frag || !out_bct || n_clips <= 0) return fail_msg("syn_x_from_fragment: bad arguments");
+    hipLaunchKernelGGL(seq::k_x_from_fragment, dim3(n_clips, SYN_C / 32), dim3(256), 0, (hipStream_t)stream, x_frag, out_bct);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_x_from_fragment launch", e);
 }
 
 int syn_from_token_major(const float* x_btc, int32_t n_clips, float* out_bct, void* stream) {
@@ -2087,6 +2115,23 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     GArgs a;
     auto mark = [&](int c) { if (tm) tm->mark(c); };
 
+    if (st->x_fragment_order || (st->reserved & 7) == 5) {
+        // large single-variant batches: one wave per sequence, weights streamed once per 128 rows (syn_seq.inc)
+        if (!st->x_fragment_order) return fail_msg("syn_denoise_step: the wave-per-sequence kernel needs the latent in fragment order (x_fragment_order = 1)");
+        if (V != 1) return fail_msg("syn_denoise_step: fragment-order latents are single-variant only (guided batches run token-major)");
+        if (!md->tape || !md->tape_bias || md->tape_chunks <= seq::kLook) return fail_msg("syn_denoise_step: syn_model.tape is not set");
+        seq::QArgs q;
+        memset(&q, 0, sizeof(q));
+        q.tape = (const char*)md->tape; q.tape_chunks = (unsigned)md->tape_chunks; q.bias = md->tape_bias;
+        q.te = md->te; q.rcos = md->rot_cos; q.rsin = md->rot_sin; q.cond = st->cond; q.t_model = st->t_model;
+        q.xt = st->x_t; q.xb = (const uint4*)st->x_t_bf16; q.noise = st->noise; q.rng = (const unsigned long long*)st->rng;
+        q.coef = st->coef; q.t_coef = st->t_coef; q.xn = st->x_next; q.xnb = (uint4*)st->x_next_bf16; q.x0 = st->pred_x0;
+        q.R = B; q.dbg = g_dbg_mlp;
+        if ((rc = launch_seq(q, s))) return rc;
+        mark(ST_FC2);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : fail("syn_denoise_step", e);
+    }
     int mode = st->reserved & 3;
     // Small batches: the persistent feature-split kernel (syn_latency.inc) beats the token-resident one while a
     // group (XCD) holds at most 4 sequences (measured per step: 161 / 239 / 405 us at 1 / 2 / 4 sequences per

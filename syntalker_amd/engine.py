@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import tape as _tape
 from .conditioning import ClipConditioner, fold_input_stage, rotary_tables, time_table
 
 T, CH, D, FF, LAYERS = 32, 1536, 512, 1024, 8
@@ -72,6 +73,9 @@ class PackedModel:
             L.w_fc2, L.b_fc2 = hold(pack_weight(sd[p + "mlp.fc2.weight"])), hold(f32(sd[p + "mlp.fc2.bias"]))
         m.w_out = hold(pack_weight(sd["output_process.poseFinal.weight"]))
         m.b_out = hold(f32(sd["output_process.poseFinal.bias"]))
+        # the same weights as one tape of MFMA fragments in consumption order: the wave-per-sequence kernel (large batches)
+        tp, tb = _tape.build_tape(sd, folded["A"])
+        m.tape, m.tape_bias, m.tape_chunks = hold(tp), hold(tb), tp.shape[0] // _tape.CHUNK_FRAGS
         self.c = m
         self.conditioner = ClipConditioner({k: (v.detach() if torch.is_tensor(v) else v) for k, v in sd.items()},
                                            folded, variant, use_style)
@@ -83,6 +87,10 @@ class StepBuffers:
 
     def __init__(self, B: int, V: int, device, want_x0: bool = False, m_tile: int = 0, layer_mode: int = 0):
         self.B, self.V = B, V
+        # latent layout: fragment order when the wave-per-sequence kernel runs the steps (the library's choice for large
+        # single-variant batches, or pinned with layer_mode 5), token-major otherwise
+        lib = _lib.load()
+        self.fragment = bool(layer_mode == 5 or (layer_mode == 0 and m_tile == 0 and lib.syn_prefers_fragment_order(B, V)))
         R, Mb = V * B * T, B * T
         e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=device)
         bf = torch.bfloat16
@@ -118,19 +126,21 @@ class StepBuffers:
         # 9..128 sequences: exchange slots for the whole-step kernel's tensor-parallel mode (a tile split over 2 / 4 CUs)
         self.xch = e(V * B, 8, 32 * D) if 8 < V * B <= 128 else None
         s.ws_xch = _lib.ptr(self.xch)
+        s.x_fragment_order = int(self.fragment)
         self.c = s
 
     # layout ------------------------------------------------------------------------------------
+    def _import(self, src: torch.Tensor, dst_f32, dst_bf16):
+        lib = _lib.load()
+        fn, name = (lib.syn_x_to_fragment, "syn_x_to_fragment") if self.fragment else (lib.syn_to_token_major, "syn_to_token_major")
+        _lib.check(fn(src.data_ptr(), self.B, dst_f32.data_ptr(), _lib.ptr(dst_bf16), _lib.current_stream(src.device)), name)
+
     def load_x(self, x_bct: torch.Tensor):
-        """(B,1536,1,32) fp32 -> token-major x + bf16 shadow."""
-        x_bct = x_bct.detach().float().contiguous()
-        _lib.check(_lib.load().syn_to_token_major(x_bct.data_ptr(), self.B, self.x.data_ptr(), self.xb.data_ptr(),
-                                                  _lib.current_stream()), "syn_to_token_major")
+        """(B,1536,1,32) fp32 -> x in the step kernel's layout + bf16 shadow."""
+        self._import(x_bct.detach().float().contiguous(), self.x, self.xb)
 
     def load_noise(self, eps_bct: torch.Tensor):
-        eps_bct = eps_bct.detach().float().contiguous()
-        _lib.check(_lib.load().syn_to_token_major(eps_bct.data_ptr(), self.B, self.noise.data_ptr(), None,
-                                                  _lib.current_stream()), "syn_to_token_major")
+        self._import(eps_bct.detach().float().contiguous(), self.noise, None)
 
     def set_rng(self, seed: int, first_clip: int = 0):
         """Key of the in-epilogue generator for the whole loop; the per-step stream id is the clip's t_coef."""
@@ -139,8 +149,11 @@ class StepBuffers:
     def draw_noise(self, seed: int, step: int, first_clip: int = 0):
         """N(0,1) keyed by (seed, step, global element index): identical for any sharding of the batch."""
         n = self.B * T * CH
-        _lib.check(_lib.load().syn_randn(self.noise.data_ptr(), n, seed, step, first_clip * T * CH,
-                                         _lib.current_stream()), "syn_randn")
+        dst = torch.empty_like(self.noise) if self.fragment else self.noise       # the generator's index space is token-major
+        _lib.check(_lib.load().syn_randn(dst.data_ptr(), n, seed, step, first_clip * T * CH,
+                                         _lib.current_stream(dst.device)), "syn_randn")
+        if self.fragment:
+            self.noise.view(-1).copy_(_tape.to_fragment_order(dst.view(self.B, T, CH)).view(-1))
 
     def check_sync(self):
         """The small-batch kernel's group barrier is bounded; a wait that ran out leaves a sticky flag."""
@@ -153,8 +166,9 @@ class StepBuffers:
     def read(self, src: torch.Tensor) -> torch.Tensor:
         self.check_sync()
         out = torch.empty(self.B, CH, 1, T, dtype=torch.float32, device=src.device)
-        _lib.check(_lib.load().syn_from_token_major(src.data_ptr(), self.B, out.data_ptr(), _lib.current_stream()),
-                   "syn_from_token_major")
+        lib = _lib.load()
+        fn, name = (lib.syn_x_from_fragment, "syn_x_from_fragment") if self.fragment else (lib.syn_from_token_major, "syn_from_token_major")
+        _lib.check(fn(src.data_ptr(), self.B, out.data_ptr(), _lib.current_stream(src.device)), name)
         return out
 
 

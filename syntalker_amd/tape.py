@@ -11,26 +11,31 @@ directly as the next B operand: lane (hi, token) holds features {8q + 4hi + r}, 
 kc carries  k = 16 kc + 8 (e >> 2) + 4 hi + (e & 3)  instead of the natural 16 kc + 8 hi + e; the tape applies the
 same permutation to the weights' K index (a contraction does not care in which order k is visited).
 
-Two fragment orders inside a piece (every piece is a multiple of 128 fragments = 8 ring chunks of 16):
-  "wide"  [kc][tile]            all tiles of the piece are live accumulators (the residual stream itself): input, proj, fc2
-  "pair"  [pair][kc][u = 0, 1]  two tiles in flight, each finished tile is consumed at once (q, k, v, fc1, output):
-                                the wave never holds more than 32 accumulator registers for these pieces
+Fragment orders inside a piece (every piece is a multiple of 8 fragments = one 8 KB ring chunk):
+  "wide16" [kc][tile 0..15]       all 16 tiles of the residual stream are live accumulators (input stage)
+  "wide"   [kc][tile 0..11], then tiles 12..15 in pair order: inside the blocks the wave keeps residual tiles 12..15 in
+                                  a private LDS slab (512 registers do not hold the residual stream, the LayerNorm output
+                                  and the working set at once); they are accumulated two at a time after the first twelve
+  "pair"   [pair][kc][u = 0, 1]   two tiles in flight, each finished tile is consumed at once (q, k, v, fc1, output)
 Tape order:
-    input   A (512 x 1536)                                                   wide  96 kc x 16 tiles = 1536
+    input   A (512 x 1536)                                                   wide16  96 kc x 16 = 1536
+    block l           proj bias as a rank-1 MFMA update (K chunk 0 = [hi | lo] bf16 split of the bias)  wide, 1 kc = 16
     block l, head h   q_h, k_h, v_h (128 x 512 each, LayerNorm-1 gain folded in)   pair  3 x 128
-                      proj[:, 128h:128h+128] (512 x 128)                           wide  8 kc x 16 = 128
+                      proj[:, 128h:128h+128] (512 x 128)                           wide  8 kc = 128
+    block l           fc2 bias, rank-1 update                                      wide, 1 kc = 16
     block l, slice s  fc1[128s:128s+128] (128 x 512, LayerNorm-2 gain folded in)  pair  128          (8 slices)
-                      fc2[:, 128s:128s+128] (512 x 128)                           wide  8 kc x 16 = 128
+                      fc2[:, 128s:128s+128] (512 x 128)                           wide  8 kc = 128
     output  Wout (1536 x 512)                                                pair  24 pairs x 32 kc x 2 = 1536
-  = 1536 + 8 * 4096 + 1536 = 35 840 fragments (35 MB).
+  = 1536 + 8 * (4096 + 32) + 1536 = 36 096 fragments (35.25 MB).
 
-Bias sets (fp32, 4096 floats = one 16 KB chunk each, set l for block l, set 8 for the output stage):
+Biases.  Those that start an accumulator (q, fc1, output) are read from LDS-resident sets (fp32, 2048 floats = 8 KB
+each, set l for block l, set 8 for the output stage):
     [0:512)     q bias of the 4 heads = Wq . beta1   (LayerNorm-1 shift folded; the k bias cancels in the softmax and
                 the v bias passes through the attention unchanged, so it is folded into the proj bias)
-    [512:1024)  b_proj + Wproj . (Wv . beta1)
-    [1024:2048) b_fc1 + W1 . beta2
-    [2048:2560) b_fc2
+    [512:1536)  b_fc1 + W1 . beta2
     set 8: [0:1536) b_out
+Those added to the residual stream (proj: b_proj + Wproj . (Wv . beta1); fc2: b_fc2) are applied by the matrix cores as a
+rank-1 update h += bias (x) 1 (the "bias" pieces of the tape): no accumulator round trip through the vector ALU.
 (reference: models/timm_transformer/transformer.py:83-104,145-151,195-198; models/denoiser.py:188-195.)
 """
 from __future__ import annotations
@@ -38,9 +43,9 @@ from __future__ import annotations
 import torch
 
 D, FF, C, HEADS, LAYERS = 512, 1024, 1536, 4, 8
-CHUNK_FRAGS = 16
-TAPE_FRAGS = 1536 + LAYERS * 4096 + 1536
-BIAS_SET = 4096
+CHUNK_FRAGS = 8
+TAPE_FRAGS = 1536 + LAYERS * (4096 + 32) + 1536
+BIAS_SET = 2048
 N_BIAS_SETS = LAYERS + 1
 
 
@@ -55,9 +60,34 @@ def frag_tiles(w: torch.Tensor) -> torch.Tensor:
     return v.reshape(kc, nt, 64, 8).to(torch.bfloat16).contiguous()
 
 
-def wide(w: torch.Tensor) -> torch.Tensor:
+def wide16(w: torch.Tensor) -> torch.Tensor:
     """[kc][tile] order, flattened to [n][64][8]."""
     return frag_tiles(w).reshape(-1, 64, 8)
+
+
+def _split_order(f: torch.Tensor) -> torch.Tensor:
+    """fragments [kc][16 tiles] -> [kc][tiles 0..11] followed by tiles 12..15 in pair order."""
+    kc = f.shape[0]
+    head = f[:, :12].reshape(-1, 64, 8)
+    tail = f[:, 12:].reshape(kc, 2, 2, 64, 8).permute(1, 0, 2, 3, 4).reshape(-1, 64, 8)
+    return torch.cat([head, tail], 0)
+
+
+def wide(w: torch.Tensor) -> torch.Tensor:
+    """512-row weight slice accumulated into the residual stream."""
+    assert w.shape[0] == 512
+    return _split_order(frag_tiles(w))
+
+
+def bias_piece(b: torch.Tensor) -> torch.Tensor:
+    """h += b (x) 1 on the matrix cores: one K chunk whose slots k = 0, 1 (natural order: lane hi = 0, e = 0, 1) carry the
+    bf16 [hi | lo] split of b (16 mantissa bits); the kernel's B operand for it is 1.0 in those two slots."""
+    hi = b.to(torch.bfloat16)
+    lo = (b - hi.double()).to(torch.bfloat16)
+    f = torch.zeros(1, 16, 64, 8, dtype=torch.bfloat16, device=b.device)
+    f[0, :, :32, 0] = hi.reshape(16, 32)
+    f[0, :, :32, 1] = lo.reshape(16, 32)
+    return _split_order(f)
 
 
 def pair(w: torch.Tensor) -> torch.Tensor:
@@ -68,12 +98,12 @@ def pair(w: torch.Tensor) -> torch.Tensor:
 
 
 def build_tape(sd: dict, A: torch.Tensor):
-    """-> (tape bf16 [TAPE_FRAGS][64][8], bias fp32 [9][4096]) on the device of the weights.
+    """-> (tape bf16 [TAPE_FRAGS][64][8], bias fp32 [9][2048]) on the device of the weights.
 
     sd: MDM state_dict view (mytimmblocks.*, output_process.poseFinal.*); A: folded input matrix (512 x 1536)."""
     dev = A.device
     f64 = lambda t: t.detach().to(dev).double()
-    pieces = [wide(f64(A))]
+    pieces = [wide16(f64(A))]
     bias = torch.zeros(N_BIAS_SETS, BIAS_SET, dtype=torch.float64, device=dev)
     for l in range(LAYERS):
         p = f"mytimmblocks.{l}."
@@ -82,16 +112,16 @@ def build_tape(sd: dict, A: torch.Tensor):
         wqkv, wproj = f64(sd[p + "attn.qkv.weight"]), f64(sd[p + "attn.proj.weight"])
         w1, w2 = f64(sd[p + "mlp.fc1.weight"]), f64(sd[p + "mlp.fc2.weight"])
         wq, wk, wv = wqkv[:D], wqkv[D:2 * D], wqkv[2 * D:]
+        pieces.append(bias_piece(f64(sd[p + "attn.proj.bias"]) + wproj @ (wv @ b1n)))
         for h in range(HEADS):
             r = slice(128 * h, 128 * h + 128)
             pieces += [pair(wq[r] * g1[None, :]), pair(wk[r] * g1[None, :]), pair(wv[r] * g1[None, :]), wide(wproj[:, r])]
+        pieces.append(bias_piece(f64(sd[p + "mlp.fc2.bias"])))
         for c in range(FF // 128):
             r = slice(128 * c, 128 * c + 128)
             pieces += [pair(w1[r] * g2[None, :]), wide(w2[:, r])]
         bias[l, 0:512] = wq @ b1n
-        bias[l, 512:1024] = f64(sd[p + "attn.proj.bias"]) + wproj @ (wv @ b1n)
-        bias[l, 1024:2048] = f64(sd[p + "mlp.fc1.bias"]) + w1 @ b2n
-        bias[l, 2048:2560] = f64(sd[p + "mlp.fc2.bias"])
+        bias[l, 512:1536] = f64(sd[p + "mlp.fc1.bias"]) + w1 @ b2n
     wout = f64(sd["output_process.poseFinal.weight"])
     pieces.append(pair(wout))
     bias[LAYERS, 0:C] = f64(sd["output_process.poseFinal.bias"])

@@ -60,12 +60,24 @@ class Wave:
             out[:, v] = self.bias[set_, off + 32 * tile + 8 * (v >> 2) + 4 * self.hi + (v & 3)]
         return out
 
-    def wide(self, acc, bfrag, n_kc):
+    def wide16(self, acc, bfrag, n_kc):
         """acc[t] += W-tile(t, kc) x bfrag(kc) for all 16 tiles; fragments in tape order [kc][tile]."""
         for kc in range(n_kc):
             b = bfrag(kc)
-            for t in range(len(acc)):
+            for t in range(16):
                 acc[t] = mfma32(self.frag(), b, acc[t])
+
+    def wide(self, acc, bfrag, n_kc):
+        """The same inside the blocks: tiles 0..11 [kc][tile], then tiles 12..15 (the LDS-resident ones) two at a time."""
+        for kc in range(n_kc):
+            b = bfrag(kc)
+            for t in range(12):
+                acc[t] = mfma32(self.frag(), b, acc[t])
+        for p in (12, 14):
+            for kc in range(n_kc):
+                b = bfrag(kc)
+                for u in range(2):
+                    acc[p + u] = mfma32(self.frag(), b, acc[p + u])
 
     def pairs(self, init, bfrag, n_pairs, n_kc, done, swap=False):
         """Two tiles in flight, tape order [pair][kc][u]; done(tile index, tile) consumes each finished tile.
@@ -100,7 +112,7 @@ class Wave:
                 f = 32 * t + 8 * (v >> 2) + 4 * self.hi + (v & 3)
                 init[:, v] = cond_tok[self.tok, f] + te_row[f]
             h.append(init)
-        self.wide(h, lambda kc: xb_frag[kc >> 1][kc & 1], 96)
+        self.wide16(h, lambda kc: xb_frag[kc >> 1][kc & 1], 96)
         for g in range(8):                       # 64-wide groups: pairs (j, j + 32) = tiles 2g and 2g + 1, same register
             u, w = h[2 * g], h[2 * g + 1]
             cs, sn = np.zeros_like(u), np.zeros_like(u)
@@ -114,8 +126,9 @@ class Wave:
             # ---- attention: XN = (h - mean) * rstd materialised as bf16 operand fragments (gain / shift are in the tape)
             mean, rstd = self.row_stats(h)
             xn = [d_pair_as_operand((h[kc >> 1] - mean[:, None]) * rstd[:, None], kc & 1) for kc in range(32)]
-            for t in range(16):
-                h[t] = h[t] + self.bias_tile(l, 512, t)                  # proj bias (+ folded v bias)
+            ones = np.zeros((LANES, 8), np.float32)
+            ones[:32, 0:2] = 1.0                                         # slots k = 0, 1 of the rank-1 bias update
+            self.wide(h, lambda kc: ones, 1)                             # h += proj bias (+ folded v bias)
             for head in range(4):
                 qb = {}
                 self.pairs(lambda t: self.bias_tile(l, 128 * head, t), lambda kc: xn[kc], 2, 32,
@@ -146,14 +159,13 @@ class Wave:
             # ---- MLP -------------------------------------------------------------------------------------------
             mean, rstd = self.row_stats(h)
             xn = [d_pair_as_operand((h[kc >> 1] - mean[:, None]) * rstd[:, None], kc & 1) for kc in range(32)]
-            for t in range(16):
-                h[t] = h[t] + self.bias_tile(l, 2048, t)
+            self.wide(h, lambda kc: ones, 1)                             # h += fc2 bias
             for sl in range(8):
                 hb = {}
                 def f_done(t, tile):
                     g = gelu(tile)
                     hb[(t, 0)], hb[(t, 1)] = d_pair_as_operand(g, 0), d_pair_as_operand(g, 1)
-                self.pairs(lambda t: self.bias_tile(l, 1024 + 128 * sl, t), lambda kc: xn[kc], 2, 32, f_done)
+                self.pairs(lambda t: self.bias_tile(l, 512 + 128 * sl, t), lambda kc: xn[kc], 2, 32, f_done)
                 self.wide(h, lambda kc: hb[(kc >> 1, kc & 1)], 8)
         # ---- output stage ---------------------------------------------------------------------------------------
         out = np.zeros((48, 4, LANES, 4), np.float32)

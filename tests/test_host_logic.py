@@ -199,10 +199,17 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.syn_version() == 1
-    # struct sizes as the C compiler lays them out (include/syn_hip.h): 4 int32 + 20 pointers; 11 pointers; 760 B
-    assert ctypes.sizeof(_lib.SynStep) == 16 + 8 * 23 and ctypes.sizeof(_lib.SynLayer) == 88
-    assert ctypes.sizeof(_lib.SynModel) == 8 * 5 + 88 * 8 + 16
+    assert lib.syn_version() == 2
+    # struct sizes exactly as the C compiler lays out include/syn_hip.h (gcc, same ABI as hipcc's host side)
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "sz.c")
+        open(src, "w").write('#include <stdio.h>\n#include "syn_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(syn_step), '
+                             'sizeof(syn_layer), sizeof(syn_model), sizeof(syn_wavenc), sizeof(syn_vq_model));return 0;}\n')
+        subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), src, "-o", os.path.join(td, "sz")], check=True)
+        sizes = [int(v) for v in subprocess.run([os.path.join(td, "sz")], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [ctypes.sizeof(c) for c in (_lib.SynStep, _lib.SynLayer, _lib.SynModel, _lib.SynWavEnc, _lib.SynVqModel)], sizes
+    assert sizes[0] == 16 + 8 * 23 + 8 and sizes[2] == 8 * 5 + 88 * 8 + 16 + 24
 
 
 def test_dropin_aliases_resolve():
