@@ -462,6 +462,8 @@ def run_sample(args, rank, local, world, dev, dist):
             e["ms"] += t; e["launches"] += n_l; e["flops"] += fl * B * n_l
         dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
         d = by_kernel[dom]
+        if getattr(sb, "fragment", False):          # the step ran on the wave-per-sequence kernel (latent in fragment order)
+            dom = "k_seq"
         avg_s = d["ms"] * 1e-3 / d["launches"]
         if args.layer_mode in (0, 3, 4):       # the step IS one kernel: use the hipEvent brackets of the K timed replays
             avg_s = replay_ms * 1e-3
@@ -474,7 +476,7 @@ def run_sample(args, rank, local, world, dev, dist):
             try:
                 pj = json.load(open(tpath))
                 if pj.get("batch") == B and pj.get("layer_mode", 0) == args.layer_mode:
-                    traffic = pj.get("hbm_bytes_per_launch", {}).get(dom)
+                    traffic = pj.get("hbm_bytes_per_launch", {}).get(dom, pj.get("hbm_bytes_per_launch", {}).get(dom + "<MT>"))
             except Exception:
                 traffic = None
         if traffic is not None and traffic / avg_s > 8.0e12:       # more bytes than HBM can move in one launch: a parsing artefact

@@ -1736,8 +1736,16 @@ int syn_to_token_major(const float* x_bct, int32_t n_clips, float* out_f32, void
 }
 
 int32_t syn_prefers_fragment_order(int32_t n_clips, int32_t n_variants) {
-    // one workgroup = 4 sequences; below ~3/4 of the chip's CUs the token-resident kernel's 32/64-row tiles fill more CUs
-    return n_variants == 1 && n_clips >= 768 ? 1 : 0;
+    // k_seq runs 4 sequences per CU and pass, k_stack 2; measured per pass at full occupancy (profiles/r02_diag_seq.txt):
+    // 1.26 ms against 0.66 ms.  Both quantise to whole passes over the 256 CUs, so the choice follows the pass counts:
+    // 1024 / 2048 / 3072 clips -> k_seq, 1280 or 1536 -> k_stack (a second, mostly empty k_seq pass would cost more).
+    if (n_variants != 1 || n_clips < 768) return 0;
+    int dev = 0, cus = 256;
+    hipGetDevice(&dev);
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    const long passes_seq = (n_clips + 4L * cus - 1) / (4L * cus), passes_stack = (n_clips + 2L * cus - 1) / (2L * cus);
+    return passes_seq * 191 < passes_stack * 100 ? 1 : 0;
 }
 
 int syn_x_to_fragment(const float* x_bct, int32_t n_clips, float* out_f32, void* out_bf16, void* stream) {
@@ -2119,7 +2127,7 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
         // large single-variant batches: one wave per sequence, weights streamed once per 128 rows (syn_seq.inc)
         if (!st->x_fragment_order) return fail_msg("syn_denoise_step: the wave-per-sequence kernel needs the latent in fragment order (x_fragment_order = 1)");
         if (V != 1) return fail_msg("syn_denoise_step: fragment-order latents are single-variant only (guided batches run token-major)");
-        if (!md->tape || !md->tape_bias || md->tape_chunks <= seq::kLook) return fail_msg("syn_denoise_step: syn_model.tape is not set");
+        if (!md->tape || !md->tape_bias || md->tape_chunks < 64) return fail_msg("syn_denoise_step: syn_model.tape is not set");
         seq::QArgs q;
         memset(&q, 0, sizeof(q));
         q.tape = (const char*)md->tape; q.tape_chunks = (unsigned)md->tape_chunks; q.bias = md->tape_bias;

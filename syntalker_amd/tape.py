@@ -65,11 +65,14 @@ def wide16(w: torch.Tensor) -> torch.Tensor:
     return frag_tiles(w).reshape(-1, 64, 8)
 
 
+REG_TILES = 12        # residual tiles the kernel keeps in registers; tiles 12..15 live in the wave's LDS slab (syn_seq.inc kRegTiles)
+
+
 def _split_order(f: torch.Tensor) -> torch.Tensor:
-    """fragments [kc][16 tiles] -> [kc][tiles 0..11] followed by tiles 12..15 in pair order."""
+    """fragments [kc][16 tiles] -> [kc][register tiles] followed by the slab tiles in pair order."""
     kc = f.shape[0]
-    head = f[:, :12].reshape(-1, 64, 8)
-    tail = f[:, 12:].reshape(kc, 2, 2, 64, 8).permute(1, 0, 2, 3, 4).reshape(-1, 64, 8)
+    head = f[:, :REG_TILES].reshape(-1, 64, 8)
+    tail = f[:, REG_TILES:].reshape(kc, (16 - REG_TILES) // 2, 2, 64, 8).permute(1, 0, 2, 3, 4).reshape(-1, 64, 8)
     return torch.cat([head, tail], 0)
 
 
