@@ -13,7 +13,11 @@ def load_checkpoints(model, save_path, load_name="model"):
     """Same call signature as the reference's loader.  Accepts prefixed and unprefixed keys."""
     states = torch.load(save_path, map_location="cpu")
     sd = states["model_state"] if isinstance(states, dict) and "model_state" in states else states
-    target = model.module if hasattr(model, "module") and not any(k.startswith("module.") for k in model.state_dict()) else model
+    # the reference's drivers pass an nn.DataParallel / DDP wrapper (test.py:87,208; train.py:94,282): load into the wrapped
+    # module, whose keys carry no "module." prefix
+    target = model
+    while isinstance(target, (torch.nn.DataParallel, torch.nn.parallel.DistributedDataParallel)):
+        target = target.module
     missing, unexpected = target.load_state_dict(strip_module_prefix(sd), strict=False)
     missing = [k for k in missing if not k.endswith("num_batches_tracked")]
     if missing or unexpected:

@@ -122,7 +122,7 @@ class HipWavEncoder:
             if key not in self._ws:         # zeroed once: the halo / tail rows the kernels rely on are never written
                 self._ws[key] = torch.zeros(lib.syn_wav_workspace_bytes(n, L), dtype=torch.uint8, device=wav.device)
             _lib.check(lib.syn_wav_encode(C.byref(self.c), wav[b0:b0 + n].data_ptr(), n, L, self._ws[key].data_ptr(),
-                                          out[b0:b0 + n].data_ptr(), _lib.current_stream()), "syn_wav_encode")
+                                          out[b0:b0 + n].data_ptr(), _lib.current_stream(wav.device)), "syn_wav_encode")
         return out
 
 

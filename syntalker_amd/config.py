@@ -33,6 +33,11 @@ def load_args(path: str | None = None, **overrides) -> SimpleNamespace:
     return SimpleNamespace(**a)
 
 
+def _require(path: str, key: str):
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{key} = {path!r} is configured but does not exist (unset the key to run with random initialisation)")
+
+
 def build_vq_models(args, device="cuda"):
     """The three body-part RVQ-VAEs as diffusion_rvqvae_trainer.py:87-161 builds and loads them."""
     if getattr(args, "vqvae_type", "rvqvae") != "rvqvae":
@@ -45,7 +50,8 @@ def build_vq_models(args, device="cuda"):
         m = rvqvae.build(dim)
         key = "vqvae_lower_trans_path" if (part == "lower" and use_trans) else f"vqvae_{part}_path"
         path = getattr(args, key, None)
-        if path and os.path.exists(path):
+        if path:                                                   # configured: it must exist (the reference raises too);
+            _require(path, key)                                    # only an absent / empty key leaves the random initialisation
             m.load_state_dict(torch.load(path, map_location="cpu")["net"])       # :153-155
         out[part] = m.to(device)
     return out
@@ -55,7 +61,8 @@ def build_sampler(args, device="cuda", model_cls=None):
     from .denoiser import MDM
     model = (model_cls or MDM)(args)
     ckpt = getattr(args, "test_ckpt", None)
-    if ckpt and os.path.exists(ckpt):
+    if ckpt:
+        _require(ckpt, "test_ckpt")
         checkpoint.load_checkpoints(model, ckpt)
     diffusion = create_gaussian_diffusion()
     s = SimpleNamespace(model=model.to(device).eval(), diffusion=diffusion,
@@ -64,6 +71,7 @@ def build_sampler(args, device="cuda", model_cls=None):
                         use_trans=bool(getattr(args, "use_trans", True)), trans_mean=None, trans_std=None)
     for name in ("mean_trans_path", "std_trans_path"):
         p = getattr(args, name, None)
-        if s.use_trans and p and os.path.exists(p):
+        if s.use_trans and p:
+            _require(p, name)
             setattr(s, "trans_mean" if name.startswith("mean") else "trans_std", torch.from_numpy(np.load(p)).float().to(device))
     return s

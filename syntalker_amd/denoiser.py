@@ -206,9 +206,14 @@ class MDM(nn.Module):
     # ---- reference-compatible call --------------------------------------------------------------
     def forward(self, x, timesteps, y=None, uncond_info=False):
         """x (B, 1536, 1, T=32), timesteps (B,) -> predicted x_0, same shape (models/denoiser.py:132-196)."""
-        if torch.is_grad_enabled() and (self.training or self.differentiable_eval):
+        # nn.Module semantics follow self.training, not the autograd mode: train() under no_grad (a validation loss
+        # computed without .eval()) still means batch statistics, DropPath and style dropout, as in the reference.
+        if self.training or (torch.is_grad_enabled() and self.differentiable_eval):
             from . import training                      # differentiable path: HIP GEMMs fwd/dgrad/wgrad (training.py)
             return training.train_forward(self, x, timesteps, y)
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise RuntimeError("MDM.eval() runs the fused inference kernels, which are not differentiable: the output would be "
+                               "detached from x.  Set model.differentiable_eval = True (or call .train()) for gradients.")
         return self.forward_variants(x, timesteps, y, [self.own_variant(y)], None)
 
     def forward_variants(self, x, timesteps, y, variants, weights):

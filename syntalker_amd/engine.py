@@ -37,7 +37,7 @@ def pack_weight(w: torch.Tensor) -> torch.Tensor:
     w = w.detach().float().contiguous()
     n, k = w.shape
     out = torch.empty(n * k * 2, dtype=torch.uint8, device=w.device)
-    _lib.check(_lib.load().syn_pack_weight(w.data_ptr(), n, k, out.data_ptr(), _lib.current_stream()), "syn_pack_weight")
+    _lib.check(_lib.load().syn_pack_weight(w.data_ptr(), n, k, out.data_ptr(), _lib.current_stream(w.device)), "syn_pack_weight")
     return out
 
 
@@ -178,7 +178,7 @@ def run_step(pm: PackedModel, sb: StepBuffers, coef: torch.Tensor, use_noise: bo
     sb.c.coef = coef.data_ptr()
     sb.c.noise = sb.noise.data_ptr() if (use_noise and not fused_rng) else None
     sb.c.rng = sb.rng.data_ptr() if (use_noise and fused_rng) else None
-    _lib.check(_lib.load().syn_denoise_step(C.byref(pm.c), C.byref(sb.c), _lib.current_stream()), "syn_denoise_step")
+    _lib.check(_lib.load().syn_denoise_step(C.byref(pm.c), C.byref(sb.c), _lib.current_stream(pm.device)), "syn_denoise_step")
 
 
 class StepGraph:
@@ -212,7 +212,7 @@ class StepGraph:
                 self.tc_rows = torch.zeros(steps, sb.t_coef.numel(), dtype=torch.int32, device=pm.device)
                 _lib.check(_lib.load().syn_steps_advance(self.sched.data_ptr(), self.counter.data_ptr(), self.tm_rows.data_ptr(),
                                                          sb.t_model.numel(), self.tc_rows.data_ptr(), sb.t_coef.numel(), steps,
-                                                         _lib.current_stream()), "syn_steps_advance")
+                                                         _lib.current_stream(pm.device)), "syn_steps_advance")
                 try:
                     for j in range(steps):
                         sb.c.t_model, sb.c.t_coef = self.tm_rows[j].data_ptr(), self.tc_rows[j].data_ptr()
@@ -223,7 +223,7 @@ class StepGraph:
                 if scheduled:
                     _lib.check(_lib.load().syn_step_advance(self.sched.data_ptr(), self.counter.data_ptr(), sb.t_model.data_ptr(),
                                                             sb.t_model.numel(), sb.t_coef.data_ptr(), sb.t_coef.numel(),
-                                                            _lib.current_stream()), "syn_step_advance")
+                                                            _lib.current_stream(pm.device)), "syn_step_advance")
                 run_step(pm, sb, coef, use_noise, fused_rng)
 
     def set_schedule(self, t_coef_rows, t_model_rows):

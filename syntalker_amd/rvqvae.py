@@ -145,7 +145,7 @@ class RVQVAE(nn.Module):
         hist = torch.zeros(NUM_Q, NB_CODE, device=x.device, dtype=torch.int32)
         _lib.check(lib.syn_vq_quantize(x.data_ptr(), p["cb"].data_ptr(), p["cbt"].data_ptr(), p["cc"].data_ptr(), qf.data_ptr(),
                                        None, idx.data_ptr(), sq.data_ptr(), hist.data_ptr(), rows,
-                                       torch.cuda.current_stream().cuda_stream), "syn_vq_quantize")
+                                       _lib.current_stream(x.device)), "syn_vq_quantize")
         commit, perp = self._stats(sq, hist, rows)
         return qf.view(n, t, c), idx.view(n, t, NUM_Q).long(), commit, perp
 
@@ -167,7 +167,7 @@ class RVQVAE(nn.Module):
         x = x.contiguous().float()
         lat = torch.empty(n, t // 4, CODE_DIM, device=x.device)
         _lib.check(_lib.load().syn_vq_map2latent(C.byref(p["model"]), x.data_ptr(), n, t, self._workspace(p, n, t, x.device).data_ptr(),
-                                                 lat.data_ptr(), torch.cuda.current_stream().cuda_stream), "syn_vq_map2latent")
+                                                 lat.data_ptr(), _lib.current_stream(x.device)), "syn_vq_map2latent")
         return lat
 
     @torch.no_grad()
@@ -183,7 +183,7 @@ class RVQVAE(nn.Module):
         hist = torch.zeros(NUM_Q, NB_CODE, device=x.device, dtype=torch.int32)
         _lib.check(lib.syn_vq_latent2origin(C.byref(p["model"]), x.data_ptr(), n, t, self._workspace(p, n, 4 * t, x.device).data_ptr(),
                                             out.data_ptr(), idx.data_ptr(), sq.data_ptr(), hist.data_ptr(),
-                                            torch.cuda.current_stream().cuda_stream), "syn_vq_latent2origin")
+                                            _lib.current_stream(x.device)), "syn_vq_latent2origin")
         commit, perp = self._stats(sq, hist, n * t)
         return out, commit, perp
 
@@ -211,7 +211,7 @@ class RVQVAE(nn.Module):
         out = torch.empty(n, 4 * t, self.input_width, device=x.device)
         _lib.check(_lib.load().syn_vq_forward_decoder(C.byref(p["model"]), idx.data_ptr(), nq, n, t,
                                                       self._workspace(p, n, 4 * t, x.device).data_ptr(), out.data_ptr(),
-                                                      torch.cuda.current_stream().cuda_stream), "syn_vq_forward_decoder")
+                                                      _lib.current_stream(x.device)), "syn_vq_forward_decoder")
         return out
 
     @torch.no_grad()

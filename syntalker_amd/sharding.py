@@ -49,20 +49,52 @@ def gather_clips(local: torch.Tensor, n_clips: int, group=None) -> torch.Tensor:
     return torch.cat([p[: hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
 
 
-def sample_sharded(diffusion, model, shape, model_kwargs, *, ddim=False, noise=None, seed=0, gather=True, **loop_kw):
+X_T_STREAM = 1 << 20        # stream id of the x_T draw (the per-step noise uses stream ids 0 .. n_steps - 1)
+
+
+def draw_x_T(n_local: int, shape_tail, seed: int, first_clip: int, device) -> torch.Tensor:
+    """x_T ~ N(0, I) for the clips [first_clip, first_clip + n_local) of a global batch, keyed by (seed, GLOBAL element
+    index): the same values whatever the number of ranks.  Counter-based generator of the step kernels (syn_randn) on the
+    GPU; on CPU (host-logic tests) one seeded torch generator per clip."""
+    per = int(torch.tensor(shape_tail).prod())
+    if torch.device(device).type == "cuda":
+        from . import _lib
+        out = torch.empty((n_local,) + tuple(shape_tail), dtype=torch.float32, device=device)
+        _lib.check(_lib.load().syn_randn(out.data_ptr(), out.numel(), seed, X_T_STREAM, first_clip * per, _lib.current_stream(out.device)),
+                   "syn_randn")
+        return out
+    rows = [torch.randn(tuple(shape_tail), generator=torch.Generator().manual_seed((seed * 1000003 + first_clip + i) % (2 ** 63)))
+            for i in range(n_local)]
+    return torch.stack(rows).to(device) if rows else torch.empty((0,) + tuple(shape_tail), device=device)
+
+
+def sample_sharded(diffusion, model, shape, model_kwargs, *, ddim=False, noise=None, seed=None, gather=True, **loop_kw):
     """p_sample_loop / ddim_sample_loop over this rank's slice of a global batch of shape[0] clips.
 
-    `noise` (x_T) and per-clip entries of model_kwargs['y'] are GLOBAL tensors; each rank slices its part.
+    `noise` (x_T) and per-clip entries of model_kwargs['y'] are GLOBAL tensors; each rank slices its part.  Without
+    `noise`, x_T is drawn per clip from (seed, global clip index) (`draw_x_T`), and without `seed` rank 0 draws one and
+    broadcasts it: in every case the result is independent of the number of ranks.
     Returns the full batch on every rank when `gather`, else the local slice."""
     n = shape[0]
-    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    on = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if on else 0
+    world = dist.get_world_size() if on else 1
     lo, hi = shard_range(n, rank, world)
+    if seed is None:
+        dev0 = next(model.parameters()).device
+        t = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+        if on and world > 1:
+            t = t.to(dev0) if dist.get_backend() == "nccl" else t
+            dist.broadcast(t, src=0)
+        seed = int(t.item())
+    if noise is None:
+        noise_local = draw_x_T(hi - lo, shape[1:], seed, lo, next(model.parameters()).device)
+    else:
+        noise_local = noise[lo:hi]
     kw = dict(model_kwargs)
     kw["y"] = shard_kwargs(model_kwargs["y"], lo, hi, n)
     loop = diffusion.ddim_sample_loop if ddim else diffusion.p_sample_loop
     if "step_noise" in loop_kw and loop_kw["step_noise"] is not None:
         loop_kw = dict(loop_kw, step_noise=loop_kw["step_noise"][:, lo:hi])
-    local = loop(model, (hi - lo,) + tuple(shape[1:]), noise=None if noise is None else noise[lo:hi],
-                 model_kwargs=kw, seed=seed, first_clip=lo, **loop_kw)
+    local = loop(model, (hi - lo,) + tuple(shape[1:]), noise=noise_local, model_kwargs=kw, seed=seed, first_clip=lo, **loop_kw)
     return gather_clips(local, n) if gather else local

@@ -53,7 +53,7 @@ def hip_matmul_nt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = 
         b = b.contiguous()
     y = torch.empty(M, Np, dtype=torch.float32, device=x.device)
     _lib.check(_lib.load().syn_linear(xb.data_ptr(), wp.data_ptr(), _lib.ptr(b), M, Np, Kp, y.data_ptr(),
-                                      _lib.current_stream()), "syn_linear")
+                                      _lib.current_stream(y.device)), "syn_linear")
     return y if Np == N else y[:, :N]
 
 
@@ -61,14 +61,14 @@ def _pack_t(src: torch.Tensor, n: int, k: int) -> torch.Tensor:
     """Packed fragments of W = src^T for a row-major src [k][n] (fp32 or bf16), no transposed copy."""
     out = torch.empty(n * k * 2, dtype=torch.uint8, device=src.device)
     _lib.check(_lib.load().syn_pack_weight_t(src.data_ptr(), int(src.dtype is torch.bfloat16), n, k, out.data_ptr(),
-                                             _lib.current_stream()), "syn_pack_weight_t")
+                                             _lib.current_stream(src.device)), "syn_pack_weight_t")
     return out
 
 
 def _gemm_packed(xb: torch.Tensor, wp: torch.Tensor, n: int, k: int) -> torch.Tensor:
     """fp32 y[M][n] = xb[M][k] (bf16, contiguous) . W^T for packed W[n][k]; n % 512 == 0, k % 128 == 0."""
     y = torch.empty(xb.shape[0], n, dtype=torch.float32, device=xb.device)
-    _lib.check(_lib.load().syn_linear(xb.data_ptr(), wp.data_ptr(), None, xb.shape[0], n, k, y.data_ptr(), _lib.current_stream()),
+    _lib.check(_lib.load().syn_linear(xb.data_ptr(), wp.data_ptr(), None, xb.shape[0], n, k, y.data_ptr(), _lib.current_stream(y.device)),
                "syn_linear")
     return y
 
@@ -136,7 +136,7 @@ class HipLayerNormFn(torch.autograd.Function):
         y = torch.empty_like(xc)
         mean, rstd = torch.empty(rows, device=x.device), torch.empty(rows, device=x.device)
         _lib.check(_lib.load().syn_ln_fwd(xc.data_ptr(), gc.data_ptr(), bc.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                          rows, _lib.current_stream()), "syn_ln_fwd")
+                                          rows, _lib.current_stream(y.device)), "syn_ln_fwd")
         ctx.save_for_backward(xc, gc, mean, rstd)
         return y.view(x.shape)
 
@@ -149,7 +149,7 @@ class HipLayerNormFn(torch.autograd.Function):
         dg, db = torch.empty(512, device=dy.device), torch.empty(512, device=dy.device)
         scratch = torch.empty((rows + 63) // 64 * 1024, device=dy.device)
         _lib.check(_lib.load().syn_ln_bwd(dyc.data_ptr(), xc.data_ptr(), gc.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-                                          dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), rows, _lib.current_stream()), "syn_ln_bwd")
+                                          dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), rows, _lib.current_stream(dx.device)), "syn_ln_bwd")
         return dx.view(dy.shape), dg, db
 
 
@@ -161,7 +161,7 @@ class HipGeluFn(torch.autograd.Function):
         engine._require_cuda(x, "GELU input")
         xc = _f32c(x)
         y = torch.empty_like(xc)
-        _lib.check(_lib.load().syn_gelu_fwd(xc.data_ptr(), y.data_ptr(), xc.numel(), _lib.current_stream()), "syn_gelu_fwd")
+        _lib.check(_lib.load().syn_gelu_fwd(xc.data_ptr(), y.data_ptr(), xc.numel(), _lib.current_stream(y.device)), "syn_gelu_fwd")
         ctx.save_for_backward(xc)
         return y
 
@@ -170,7 +170,7 @@ class HipGeluFn(torch.autograd.Function):
         xc, = ctx.saved_tensors
         dyc = _f32c(dy)
         dx = torch.empty_like(xc)
-        _lib.check(_lib.load().syn_gelu_bwd(xc.data_ptr(), dyc.data_ptr(), dx.data_ptr(), xc.numel(), _lib.current_stream()), "syn_gelu_bwd")
+        _lib.check(_lib.load().syn_gelu_bwd(xc.data_ptr(), dyc.data_ptr(), dx.data_ptr(), xc.numel(), _lib.current_stream(dx.device)), "syn_gelu_bwd")
         return dx
 
 
@@ -185,7 +185,7 @@ class HipAttentionFn(torch.autograd.Function):
         bs, T, _ = q.shape
         assert T == 32 and q.shape[2] == 1536, q.shape
         o = torch.empty(bs, T, 512, device=q.device)
-        _lib.check(_lib.load().syn_attn_fwd(q.data_ptr(), o.data_ptr(), bs, _lib.current_stream()), "syn_attn_fwd")
+        _lib.check(_lib.load().syn_attn_fwd(q.data_ptr(), o.data_ptr(), bs, _lib.current_stream(o.device)), "syn_attn_fwd")
         ctx.save_for_backward(q)
         return o
 
@@ -194,7 +194,7 @@ class HipAttentionFn(torch.autograd.Function):
         q, = ctx.saved_tensors
         doc = _f32c(do)
         dqkv = torch.empty_like(q)
-        _lib.check(_lib.load().syn_attn_bwd(q.data_ptr(), doc.data_ptr(), dqkv.data_ptr(), q.shape[0], _lib.current_stream()), "syn_attn_bwd")
+        _lib.check(_lib.load().syn_attn_bwd(q.data_ptr(), doc.data_ptr(), dqkv.data_ptr(), q.shape[0], _lib.current_stream(dqkv.device)), "syn_attn_bwd")
         return dqkv
 
 

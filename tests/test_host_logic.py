@@ -241,3 +241,31 @@ def test_config_loader_reads_reference_style_yaml(tmp_path):
     m = MDM(a)                                      # constructible from it
     assert m.state_dict()["mytimmblocks.0.attn.qkv.weight"].shape == (1536, 512)
     assert config.BODY_DIMS == {"upper": 78, "hands": 180, "lower": 54}
+
+
+def test_checkpoint_loads_into_data_parallel_wrapper(tmp_path):
+    """The reference's drivers hand `load_checkpoints` an nn.DataParallel-wrapped model and a checkpoint whose keys carry the
+    "module." prefix (test.py:87,208; utils/other_tools.py:757-790)."""
+    import torch
+    from syntalker_amd import checkpoint
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+    src = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+    for prefixed in (True, False):
+        sd = {("module." + k if prefixed else k): v for k, v in src.state_dict().items()}
+        path = tmp_path / f"ck{int(prefixed)}.bin"
+        torch.save({"model_state": sd}, path)
+        for target in (torch.nn.DataParallel(net), net):
+            with torch.no_grad():
+                net[0].weight.zero_()
+            assert checkpoint.load_checkpoints(target, str(path)) is target
+            assert torch.equal(net[0].weight, src[0].weight)
+    torch.save({"model_state": {"module.0.weight": src[0].weight}}, tmp_path / "bad.bin")
+    with pytest.raises(KeyError):
+        checkpoint.load_checkpoints(torch.nn.DataParallel(net), str(tmp_path / "bad.bin"))
+
+
+def test_configured_but_missing_checkpoint_paths_raise(tmp_path):
+    from syntalker_amd import config
+    a = config.load_args(None, vqvae_upper_path=str(tmp_path / "nope.bin"))
+    with pytest.raises(FileNotFoundError, match="vqvae_upper_path"):
+        config.build_vq_models(a, device="cpu")

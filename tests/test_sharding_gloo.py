@@ -42,8 +42,13 @@ def _worker(rank, world, port, out):
         full = sample_sharded(d, Toy(), shape, {"y": y}, noise=xT, clip_denoised=False, skip_timesteps=992, step_noise=sn)
         lo, hi = shard_range(shape[0], rank, world)
         ragged = gather_clips(torch.full((hi - lo, 2), float(rank)), shape[0])
+        # no x_T given: every rank draws its clips' x_T from (seed, GLOBAL clip index); with seed=None rank 0's draw is broadcast
+        drawn = sample_sharded(d, Toy(), shape, {"y": y}, noise=None, seed=11, clip_denoised=False, skip_timesteps=992, step_noise=sn)
+        torch.manual_seed(100 + rank)                      # ranks whose own RNGs disagree must still agree on the broadcast seed
+        auto = sample_sharded(d, Toy(), shape, {"y": y}, noise=None, clip_denoised=False, skip_timesteps=992, step_noise=sn, gather=False)
+        auto_all = gather_clips(auto, shape[0])
         if rank == 0:
-            torch.save({"full": full, "ragged": ragged}, out)
+            torch.save({"full": full, "ragged": ragged, "drawn": drawn, "auto": auto_all}, out)
     finally:
         dist.destroy_process_group()
 
@@ -65,6 +70,13 @@ def test_two_rank_sharded_sampling_equals_single_process(tmp_path):
     want = d.p_sample_loop(Toy(), shape, noise=xT, clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=992, step_noise=sn)
     assert torch.equal(got["full"], want)
     assert got["ragged"].shape == (5, 2) and got["ragged"][:3].eq(0).all() and got["ragged"][3:].eq(1).all()
+    # x_T drawn inside: identical to one process drawing all five clips from the same seed (rank-count independence) ...
+    assert torch.equal(got["drawn"], sample_sharded(d, Toy(), shape, {"y": y}, noise=None, seed=11, clip_denoised=False,
+                                                    skip_timesteps=992, step_noise=sn))
+    assert not torch.equal(got["drawn"], want)
+    # ... and distinct clips got distinct x_T although both ranks' torch RNGs were seeded alike
+    assert (got["drawn"][0] - got["drawn"][3]).abs().max() > 1e-3
+    assert torch.isfinite(got["auto"]).all() and got["auto"].shape == want.shape
 
 
 # ---- data-parallel training wiring: torch DDP as configured by training.make_ddp, gloo on CPU ----
