@@ -3,10 +3,10 @@ pose frames, HIP kernels vs the same network on PyTorch-ROCm (the restatement's 
 reference's nn.Modules launch)."""
 import sys, time, torch
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
-from syntalker_amd import rvqvae
+from syntalker_amd import rvqvae, synth
 from oracle import rvq_ref as rr
 DIMS = {"upper": 78, "hands": 180, "lower": 57}
-sds = {k: rvqvae.synth_state_dict(d) for k, d in DIMS.items()}
+sds = {k: synth.synth_vq_state_dict(d) for k, d in DIMS.items()}
 vqs = {}
 for k, d in DIMS.items():
     m = rvqvae.build(d); m.load_state_dict(sds[k]); vqs[k] = m.cuda()
@@ -21,8 +21,8 @@ def timeit(fn, reps):
 
 
 for n in [int(a) for a in sys.argv[1:]] or [1, 8, 64, 256]:
-    lat = {k: rvqvae.synth_rec_latent(sds[k], k, n=n, t=32).cuda() for k in DIMS}
-    pose = {k: rvqvae.synth_pose(k, d, n=n, t=128).cuda() for k, d in DIMS.items()}
+    lat = {k: synth.synth_vq_rec_latent(sds[k], k, n=n, t=32).cuda() for k in DIMS}
+    pose = {k: synth.synth_vq_pose(k, d, n=n, t=128).cuda() for k, d in DIMS.items()}
     reps = 20 if n <= 64 else 5
     with torch.no_grad():
         d_hip = timeit(lambda: [vqs[k].latent2origin(lat[k]) for k in DIMS], reps)

@@ -10,7 +10,7 @@ n = int(secs * 30)
 s = config.build_sampler(config.load_args())                      # random-init: no checkpoint paths in the default args
 synth.synth_fill_(s.model, 0)
 for part, m in s.vq.items():
-    m.load_state_dict(rvqvae.synth_state_dict(m.input_width, seed=11))
+    m.load_state_dict(synth.synth_vq_state_dict(m.input_width, seed=11))
 g = torch.Generator().manual_seed(0)
 audio = torch.randn(B, n * 533, 2, generator=g).cuda()
 word = torch.randint(0, synth.VOCAB, (B, n), generator=g).cuda()

@@ -150,9 +150,24 @@ class GaussianDiffusion:
 
     # ---- forward process --------------------------------------------------------------------------
     def q_sample(self, x_start, t, noise=None):
+        """gaussian_diffusion.py:235-253.  On the GPU (fp32, no autograd through it: the training step's case) one fused
+        kernel through the C ABI, `syn_axpby_rows`, with the two coefficient tables resident on the device."""
         if noise is None:
             noise = torch.randn_like(x_start)
         assert noise.shape == x_start.shape
+        if (x_start.is_cuda and x_start.dtype is torch.float32 and noise.dtype is torch.float32
+                and not (torch.is_grad_enabled() and (x_start.requires_grad or noise.requires_grad))
+                and x_start.dim() > 1 and (x_start.numel() // x_start.shape[0]) % 4 == 0):
+            from . import _lib
+            dev = x_start.device
+            ab = self._cached(("q_ab", dev), lambda: torch.tensor(
+                np.stack([self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod], 1), dtype=torch.float32, device=dev))
+            xs, nz = x_start.contiguous(), noise.contiguous()
+            out = torch.empty_like(xs)
+            _lib.check(_lib.load().syn_axpby_rows(xs.data_ptr(), nz.data_ptr(), ab.data_ptr(), t.to(torch.int32).contiguous().data_ptr(),
+                                                  xs.shape[0], xs.numel() // xs.shape[0], out.data_ptr(), _lib.current_stream(dev)),
+                       "syn_axpby_rows")
+            return out
         return self._tab("sqrt_alphas_cumprod", t, x_start) * x_start + \
             self._tab("sqrt_one_minus_alphas_cumprod", t, x_start) * noise
 

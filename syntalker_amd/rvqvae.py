@@ -221,7 +221,7 @@ class RVQVAE(nn.Module):
         return {"rec_pose": y, "commit_loss": commit, "perplexity": perp}
 
 
-# ---- deterministic synthetic weights / inputs (tests, goldens, benches) ------------------------------------------------
+# ---- construction as the trainer does it (synthetic weights / poses for tests and benches live in synth.py) ----
 def vq_args():
     from types import SimpleNamespace
     return SimpleNamespace(num_quantizers=NUM_Q, shared_codebook=False, quantize_dropout_prob=0.2, mu=0.99)   # trainer :89-92
@@ -230,23 +230,3 @@ def vq_args():
 def build(dim: int) -> "RVQVAE":
     """The constructor call of diffusion_rvqvae_trainer.py:107-150 for a body part of `dim` pose channels."""
     return RVQVAE(vq_args(), dim, NB_CODE, CODE_DIM, CODE_DIM, 2, 2, 512, 3, 3, "relu", None)
-
-
-def synth_state_dict(dim: int, seed: int = 11) -> dict:
-    sd = {k: torch.zeros_like(v) for k, v in build(dim).state_dict().items()}
-    return synth.synth_fill_(sd, seed)
-
-
-def synth_pose(part: str, dim: int, n: int = 2, t: int = 64, seed: int = 3) -> torch.Tensor:
-    return synth.synth_tensor(f"vq.pose.{part}", (n, t, dim), seed=seed) * dim ** 0.5           # N(0,1) entries
-
-
-def synth_rec_latent(sd: dict, part: str, n: int = 2, t: int = 16) -> torch.Tensor:
-    """A latent the residual quantiser has something to say about: a sum of one code per layer (indices from a seeded
-    generator) plus noise at 30 % of the last layer's scale -- what the sampler's output looks like after training."""
-    g = synth._gen(f"vq.rec.idx.{part}", 4)
-    rec = 0.3 * 0.06 * 0.6 ** 5 * synth.synth_tensor(f"vq.rec.{part}", (n, t, 512), seed=4) * (n * t * 512) ** 0.5
-    for q in range(NUM_Q):
-        idx = torch.randint(0, NB_CODE, (n, t), generator=g)
-        rec = rec + sd[f"quantizer.layers.{q}.codebook"].cpu()[idx]
-    return rec

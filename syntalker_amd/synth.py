@@ -112,3 +112,26 @@ def synth_step_noise(steps: int, batch: int, seed: int = 0) -> torch.Tensor:
 
 def to_device(y: dict, device):
     return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in y.items()}
+
+
+# ---- RVQ-VAE (the models either side of the sampling loop): synthetic weights / poses / latents ----------------------
+def synth_vq_state_dict(dim: int, seed: int = 11) -> dict:
+    from . import rvqvae
+    sd = {k: torch.zeros_like(v) for k, v in rvqvae.build(dim).state_dict().items()}
+    return synth_fill_(sd, seed)
+
+
+def synth_vq_pose(part: str, dim: int, n: int = 2, t: int = 64, seed: int = 3) -> torch.Tensor:
+    return synth_tensor(f"vq.pose.{part}", (n, t, dim), seed=seed) * dim ** 0.5           # N(0,1) entries
+
+
+def synth_vq_rec_latent(sd: dict, part: str, n: int = 2, t: int = 16) -> torch.Tensor:
+    """A latent the residual quantiser has something to say about: a sum of one code per layer (indices from a seeded
+    generator) plus noise at 30 % of the last layer's scale -- what the sampler's output looks like after training."""
+    from .rvqvae import NB_CODE, NUM_Q
+    g = _gen(f"vq.rec.idx.{part}", 4)
+    rec = 0.3 * 0.06 * 0.6 ** 5 * synth_tensor(f"vq.rec.{part}", (n, t, 512), seed=4) * (n * t * 512) ** 0.5
+    for q in range(NUM_Q):
+        idx = torch.randint(0, NB_CODE, (n, t), generator=g)
+        rec = rec + sd[f"quantizer.layers.{q}.codebook"].cpu()[idx]
+    return rec

@@ -36,13 +36,13 @@ def main():
     for part, dim in PARTS:
         m = RVQVAE(vq_args(), dim, 512, 512, 512, 2, 2, 512, 3, 3, "relu", None).eval()
         synth.synth_fill_(m, seed=11)
-        pose = rvqvae.synth_pose(part, dim)                                                        # (2, 64, dim)
+        pose = synth.synth_vq_pose(part, dim)                                                        # (2, 64, dim)
         lat = m.map2latent(pose)                                                                   # (2, 16, 512)
         out[f"{part}.map2latent"] = lat.numpy()
         idx, all_codes = m.encode(pose)                                                            # (2,16,6), (6,2,512,16)
         out[f"{part}.encode.idx"] = idx.numpy()
         out[f"{part}.forward_decoder"] = m.forward_decoder(idx).numpy()                            # (2, 64, dim)
-        rec = rvqvae.synth_rec_latent(m.state_dict(), part)
+        rec = synth.synth_vq_rec_latent(m.state_dict(), part)
         xq, qidx, _, _ = m.quantizer(rec.clone().permute(0, 2, 1), sample_codebook_temp=0.5)
         out[f"{part}.quantizer.idx"] = qidx.numpy()
         out[f"{part}.quantizer.out"] = xq.numpy()                                                  # (2, 512, 16)

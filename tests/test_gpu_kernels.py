@@ -150,6 +150,13 @@ def test_wav_encoder_vs_torch(B, L):
     print(f"wav encoder B={B} L={L}: out {tuple(got.shape)} rel-L2 {e:.3e}")
     assert e < 2e-2
     assert torch.equal(enc(wav.to("cuda")).cpu(), got)          # deterministic, workspace halos intact on reuse
+    # ... and against the ORACLE's encoder (un-folded convolutions + eval BatchNorm as the reference writes them,
+    # oracle/denoiser_ref.py:wav_encoder, pinned to the imported reference by tests/test_oracle_golden.py)
+    from oracle import denoiser_ref as dr
+    with torch.no_grad():
+        ref = dr.wav_encoder(sd, wav)
+    assert rel_l2(want, ref) < 1e-5                              # the BatchNorm fold itself
+    assert rel_l2(got, ref) < 2e-2
 
 
 def test_training_block_ops_vs_torch_autograd():
@@ -205,3 +212,22 @@ def test_wav_encoder_single_channel():
     want = conditioning.wav_features(blocks, wav)
     got = conditioning.HipWavEncoder(blocks, torch.device("cuda"))(wav.to("cuda")).cpu()
     assert got.shape == want.shape and rel_l2(got, want) < 2e-2
+
+
+def test_q_sample_on_the_device_vs_oracle():
+    """q_sample (gaussian_diffusion.py:235-253) as the training step issues it - one syn_axpby_rows launch with
+    device-resident coefficient tables - against the oracle's fp64-table restatement."""
+    from oracle.process_ref import RefProcess
+    from syntalker_amd import synth
+    from syntalker_amd.process import create_gaussian_diffusion
+    from tests.conftest import rel_l2
+    d = create_gaussian_diffusion()
+    B = 7
+    x0, eps = synth.synth_latent(B, seed=3, name="x0"), synth.synth_latent(B, seed=4, name="eps")
+    t = torch.tensor([0, 1, 17, 250, 500, 998, 999])
+    got = d.q_sample(x0.cuda(), t.cuda(), noise=eps.cuda())
+    want = RefProcess(False).q_sample(x0, t, eps)
+    assert got.is_cuda and rel_l2(got.cpu(), want) < 1e-6
+    # the autograd-visible form (a tensor that requires grad) takes the torch expression and agrees with the kernel
+    xg = x0.cuda().requires_grad_(True)
+    assert rel_l2(d.q_sample(xg, t.cuda(), noise=eps.cuda()).detach().cpu(), got.cpu()) < 1e-6

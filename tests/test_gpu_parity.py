@@ -538,3 +538,73 @@ def test_ddp_wrapper_inside_the_captured_training_step():
     assert "eager DDP step" in r.stdout and "graph-replayed DDP step" in r.stdout, r.stdout[-2000:]
     loss = float(r.stdout.strip().splitlines()[-1].rsplit("loss", 1)[1])
     assert loss == loss and abs(loss) < 1e3
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the path bench.py times: DDPM, noise drawn in the kernel's epilogue, 10-step graph replays - against the oracle fed the
+# identical noise, regenerated with syn_randn(seed, stream = t, first_clip) (gaussian_diffusion.py:607-739)
+class _RegeneratedStepNoise:
+    """step_noise[k] for the oracle's loop = what the step kernel drew at its k-th step: syn_randn(seed, stream id = timestep,
+    first element = first_clip * 32 * 1536), regenerated on demand (1000 steps x 8 clips would be 1.5 GB if materialised)."""
+
+    def __init__(self, B, ts, seed, first_clip=0):
+        self.B, self.ts, self.seed, self.first = B, list(ts), seed, first_clip
+
+    def __getitem__(self, k):
+        from syntalker_amd import _lib
+        buf = torch.empty(self.B, 32, 1536, device=DEV)
+        _lib.check(_lib.load().syn_randn(buf.data_ptr(), buf.numel(), self.seed, int(self.ts[k]), self.first * 32 * 1536,
+                                         _lib.current_stream()), "syn_randn")
+        return buf.transpose(1, 2).reshape(self.B, 1536, 1, 32).cpu()
+
+
+def _regenerated_step_noise(B, ts, seed, first_clip=0):
+    return _RegeneratedStepNoise(B, ts, seed, first_clip)
+
+
+@pytest.mark.parametrize("mode,B", [(4, 4), (3, 4), (0, 24)], ids=["whole-step-kernel", "small-batch-kernel", "library-choice-split-tiles"])
+def test_seeded_20_step_ddpm_vs_oracle(beatx, mode, B):
+    from oracle import denoiser_ref as dr
+    from oracle.process_ref import RefProcess
+    from syntalker_amd.process import create_gaussian_diffusion
+    K, seed = 20, 123
+    y, xT = synth.synth_clip_inputs(B, seed=51), synth.synth_latent(B, seed=51)
+    beatx.layer_mode = mode
+    try:
+        got = create_gaussian_diffusion().p_sample_loop(beatx, (B, 1536, 1, 32), noise=xT.to(DEV), clip_denoised=False,
+                                                        model_kwargs={"y": synth.to_device(y, DEV)}, skip_timesteps=1000 - K,
+                                                        seed=seed).cpu()
+    finally:
+        beatx.layer_mode = 0
+    sd = synth_state_dict("beatx")
+    fw = dr.fold_weights(sd)
+    with torch.no_grad():
+        cond, te = dr.clip_conditioning(sd, y, fw), dr.time_table(sd, fw)
+        model_fn = lambda a, b, c: dr.mdm_forward_folded(sd, fw, cond, te, a, b)      # pinned to the as-written forward on the CPU
+        want = RefProcess(False).p_sample_loop(model_fn, (B, 1536, 1, 32), y, noise=xT.clone(),
+                                               step_noise=_regenerated_step_noise(B, range(K - 1, -1, -1), seed), skip_timesteps=1000 - K)
+    e = rel_l2(got, want)
+    print(f"seeded {K}-step DDPM (mode {mode}, B={B}) rel-L2 vs oracle {e:.3e}")
+    assert e < LOOP_TOL
+
+
+def test_full_1000_step_p_sample_loop_vs_oracle(beatx):
+    """One whole p_sample_loop as the reference's sampler runs it (1000 DDPM steps, noise drawn in the step kernel, 10-step
+    graph replays, the library's own kernel choice at B = 8) against the oracle over the same 1000 regenerated noise tensors."""
+    from oracle import denoiser_ref as dr
+    from oracle.process_ref import RefProcess
+    from syntalker_amd.process import create_gaussian_diffusion
+    B, seed = 8, 2024
+    y, xT = synth.synth_clip_inputs(B, seed=61), synth.synth_latent(B, seed=61)
+    got = create_gaussian_diffusion().p_sample_loop(beatx, (B, 1536, 1, 32), noise=xT.to(DEV), clip_denoised=False,
+                                                    model_kwargs={"y": synth.to_device(y, DEV)}, seed=seed).cpu()
+    sd = synth_state_dict("beatx")
+    fw = dr.fold_weights(sd)
+    with torch.no_grad():
+        cond, te = dr.clip_conditioning(sd, y, fw), dr.time_table(sd, fw)
+        model_fn = lambda a, b, c: dr.mdm_forward_folded(sd, fw, cond, te, a, b)
+        want = RefProcess(False).p_sample_loop(model_fn, (B, 1536, 1, 32), y, noise=xT.clone(),
+                                               step_noise=_regenerated_step_noise(B, range(999, -1, -1), seed))
+    e = rel_l2(got, want)
+    print(f"1000-step p_sample_loop rel-L2 vs oracle {e:.3e}")
+    assert torch.isfinite(got).all() and e < LOOP_TOL

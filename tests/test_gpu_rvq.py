@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import rvq_ref as rr            # noqa: E402
-from syntalker_amd import _lib, rvqvae       # noqa: E402
+from syntalker_amd import _lib, rvqvae, synth       # noqa: E402
 
 pytestmark = pytest.mark.gpu
 PARTS = (("upper", 78), ("hands", 180), ("lower", 57))
@@ -34,7 +34,7 @@ def rel_l2(a, b):
 
 def _model(dim):
     m = rvqvae.build(dim)
-    m.load_state_dict(rvqvae.synth_state_dict(dim, seed=11))
+    m.load_state_dict(synth.synth_vq_state_dict(dim, seed=11))
     return m.to(DEV)
 
 
@@ -89,15 +89,15 @@ def test_conv1d_kernel_vs_torch(cfg):
 @pytest.mark.parametrize("part,dim", PARTS)
 def test_rvqvae_vs_reference_outputs(vq_golden, part, dim):
     m = _model(dim)
-    sd = rvqvae.synth_state_dict(dim, seed=11)
-    pose = rvqvae.synth_pose(part, dim)
+    sd = synth.synth_vq_state_dict(dim, seed=11)
+    pose = synth.synth_vq_pose(part, dim)
     lat = m.map2latent(pose.to(DEV))
     assert lat.shape == (2, 16, 512)
     e = rel_l2(lat, vq_golden[f"{part}.map2latent"])
     print(part, "map2latent rel-L2 vs reference", e)
     assert e < 2e-2
     # residual quantiser on the golden latent: the reference's indices, fp32 round-off on the rows
-    rec = rvqvae.synth_rec_latent(sd, part)
+    rec = synth.synth_vq_rec_latent(sd, part)
     qf, idx, commit, perp = m._quantize(rec.to(DEV))
     assert np.array_equal(idx.cpu().numpy(), vq_golden[f"{part}.quantizer.idx"])
     assert rel_l2(qf.permute(0, 2, 1), vq_golden[f"{part}.quantizer.out"]) < 1e-6
@@ -123,15 +123,15 @@ def test_rvqvae_ragged_batch_and_lengths():
     """3 clips of 20 / 36 latent rows (not multiples of the 16-row quantiser groups or of the 32/64-position conv tiles)."""
     dim = 57
     m = _model(dim)
-    sd = rvqvae.synth_state_dict(dim, seed=11)
+    sd = synth.synth_vq_state_dict(dim, seed=11)
     for n, t in ((3, 5), (1, 9), (5, 32)):
-        rec = rvqvae.synth_rec_latent(sd, "lower", n=n, t=t)
+        rec = synth.synth_vq_rec_latent(sd, "lower", n=n, t=t)
         y, commit, perp = m.latent2origin(rec.to(DEV))
         want, wc, wp = rr.latent2origin(sd, rec)
         assert y.shape == want.shape == (n, 4 * t, dim)
         assert rel_l2(y, want) < 2e-2
         assert abs(float(commit) - float(wc)) < 1e-4 * float(wc) + 1e-9 and abs(float(perp) - float(wp)) < 1e-3 * float(wp)
-        pose = rvqvae.synth_pose("lower", dim, n=n, t=4 * t)
+        pose = synth.synth_vq_pose("lower", dim, n=n, t=4 * t)
         assert rel_l2(m.map2latent(pose.to(DEV)), rr.map2latent(sd, pose)) < 2e-2
 
 
@@ -139,8 +139,8 @@ def test_rvqvae_batch_independence():
     """A clip's output does not depend on what else is in the batch (tiles never span clips)."""
     dim = 78
     m = _model(dim)
-    sd = rvqvae.synth_state_dict(dim, seed=11)
-    rec = rvqvae.synth_rec_latent(sd, "upper", n=6, t=32).to(DEV)
+    sd = synth.synth_vq_state_dict(dim, seed=11)
+    rec = synth.synth_vq_rec_latent(sd, "upper", n=6, t=32).to(DEV)
     all6 = m.latent2origin(rec)[0]
     one = m.latent2origin(rec[4:5])[0]
     assert torch.equal(all6[4:5], one)
@@ -152,9 +152,9 @@ def test_decode_take_vs_oracle():
     from oracle.longform_ref import decode_take_ref
     from syntalker_amd import longform
     dims = {"upper": 78, "hands": 180, "lower": 57}
-    sds = {k: rvqvae.synth_state_dict(d, seed=11) for k, d in dims.items()}
+    sds = {k: synth.synth_vq_state_dict(d, seed=11) for k, d in dims.items()}
     vqs = {k: _model(d) for k, d in dims.items()}
-    lat = torch.cat([rvqvae.synth_rec_latent(sds[k], k, n=2, t=60) for k in ("upper", "hands", "lower")], dim=-1) / 5.0
+    lat = torch.cat([synth.synth_vq_rec_latent(sds[k], k, n=2, t=60) for k in ("upper", "hands", "lower")], dim=-1) / 5.0
     tm, ts = torch.tensor([0.01, 0.9, -0.02]), torch.tensor([0.5, 0.1, 0.4])
     got = longform.decode_take(lat.to(DEV), vqs["upper"], vqs["hands"], vqs["lower"], 5.0, trans_mean=tm.to(DEV), trans_std=ts.to(DEV))
     want = decode_take_ref(sds, lat, 5.0, trans_mean=tm, trans_std=ts)
@@ -170,9 +170,9 @@ def test_rvqvae_h3d_body_part_widths():
     """The text-prompt trainer builds the same model on 156 / 360 / 107 pose channels (h3d_diffusion_new_trainer.py:104-146)."""
     for dim in (156, 360, 107):
         m = _model(dim)
-        sd = rvqvae.synth_state_dict(dim, seed=11)
-        rec = rvqvae.synth_rec_latent(sd, "h3d", n=2, t=8)
-        pose = rvqvae.synth_pose("h3d", dim, n=2, t=32)
+        sd = synth.synth_vq_state_dict(dim, seed=11)
+        rec = synth.synth_vq_rec_latent(sd, "h3d", n=2, t=8)
+        pose = synth.synth_vq_pose("h3d", dim, n=2, t=32)
         assert rel_l2(m.latent2origin(rec.to(DEV))[0], rr.latent2origin(sd, rec)[0]) < 2e-2
         assert rel_l2(m.map2latent(pose.to(DEV)), rr.map2latent(sd, pose)) < 2e-2
 
@@ -185,7 +185,7 @@ def test_rvqvae_round_trip_properties_at_batch_size():
     (3) the histogram behind the perplexity counts every row once per layer; commit loss = mean squared residual >= 0."""
     dim = 78
     m = _model(dim)
-    pose = rvqvae.synth_pose("upper", dim, n=256, t=128).to(DEV)
+    pose = synth.synth_vq_pose("upper", dim, n=256, t=128).to(DEV)
     out = m(pose)
     lat = m.map2latent(pose)
     y, commit, perp = m.latent2origin(lat)

@@ -26,13 +26,13 @@ def rel_l2(a, b):
 
 @pytest.mark.parametrize("part,dim", PARTS)
 def test_oracle_matches_reference_outputs(vq_golden, part, dim):
-    sd = rvqvae.synth_state_dict(dim, seed=11)
-    pose = rvqvae.synth_pose(part, dim)
+    sd = synth.synth_vq_state_dict(dim, seed=11)
+    pose = synth.synth_vq_pose(part, dim)
     assert rel_l2(rr.map2latent(sd, pose), vq_golden[f"{part}.map2latent"]) < 1e-5
     idx = rr.encode(sd, pose)
     assert np.array_equal(idx.numpy(), vq_golden[f"{part}.encode.idx"])
     assert rel_l2(rr.forward_decoder(sd, idx), vq_golden[f"{part}.forward_decoder"]) < 1e-5
-    rec = rvqvae.synth_rec_latent(sd, part)
+    rec = synth.synth_vq_rec_latent(sd, part)
     xq, qidx, commit, perp = rr.residual_vq(sd, rec.permute(0, 2, 1))
     assert np.array_equal(qidx.numpy(), vq_golden[f"{part}.quantizer.idx"])
     assert rel_l2(xq, vq_golden[f"{part}.quantizer.out"]) < 1e-6
