@@ -272,6 +272,13 @@ int syn_linear(const void* x_bf16, const void* w_packed, const float* bias, int3
 /* Y[m][n] = sum_k X[m][k] * W[n][k] (+ bias[n]); X bf16 [m_rows][k], W packed, Y fp32 [m_rows][n]. n % 512 == 0. */
 int syn_test_gemm(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k,
                   int32_t m_tile, float* y, void* stream);
+/* Adversarial check of the XCD-group barrier's acquire (syn_latency.inc): on every XCD one workgroup republishes `words`
+ * (<= 4096) 32-bit words `rounds` times with a new payload each round, a second workgroup of the same XCD re-reads them
+ * (L1-warm) after the flag, under mode 0: no invalidate, 1: `buffer_inv sc0` (what the barrier uses), 2: `buffer_inv sc1`,
+ * while the other 30 workgroups of the XCD stream from `stream` (NULL: idle).  stale[xcd] (+= ) counts words read with an
+ * old value.  sync [320] and stale [9] zeroed by the caller; buf [8][4096]. */
+int syn_test_handoff(uint32_t* sync_320_zeroed, uint32_t* buf_8x4096, const float* stream, int64_t stream_n, uint32_t* stale_9_zeroed,
+                     int32_t words, int32_t rounds, int32_t mode, void* stream_h);
 /* attention over ws_q/ws_k/ws_vt -> ws_o for n_seq sequences of 32 tokens, 4 heads x 128. */
 int syn_test_attention(const void* q, const void* k, const void* vt, int32_t n_seq, void* o, void* stream);
 

@@ -3,7 +3,7 @@
 profiles/ (kernel-stats tables, PMC tables, pmc_traffic.json read by bench.py).  Usage: scripts/collect_profiles.py rNN"""
 import csv, io, json, os, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 rd = lambda p: open(os.path.join(R, p)).read().strip()
 def parse_summary(text):
     """Rows of a pmc summary as dicts.  Kernel names may contain commas (template arguments); summaries written
@@ -23,7 +23,7 @@ def val(part, kernel, col):
         if kernel in r["kernel"]:
             return float(r[col])
     raise KeyError((part, kernel, col))
-notes = {"b1024": "bench.py --steps 30 --warmup 5 --no-small-batch, B = 1024 clips: whole-step kernel k_stack<64>",
+notes = {"b1024": "bench.py --steps 30 --warmup 5 --no-small-batch, B = 1024 clips: wave-per-sequence whole-step kernel k_seq",
          "b8": "bench.py --batch 8 --steps 300 --warmup 20 --no-small-batch: persistent small-batch kernel k_lat, one clip per XCD"}
 for b, note in notes.items():
     subprocess.run([sys.executable, os.path.join(R, "scripts/summarize_stats.py"), os.path.join(R, f"gpurun_out/prof_final_{b}/kernel_stats.csv"),
@@ -40,8 +40,8 @@ for b, note in notes.items():
 traffic = lambda b, k: int((2 * val(f"{b}_fetch", k, "FETCH_SIZE") + val(f"{b}_write", k, "WRITE_SIZE")) * 1024)
 json.dump({"batch": 1024, "layer_mode": 0, "source": f"profiles/{tag}_final_pmc_b1024.txt",
            "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 (gfx950 FETCH_SIZE correction); fabric-side traffic, "
-                   "includes weight re-reads served by the Infinity Cache",
-           "hbm_bytes_per_launch": {"k_stack<MT>": traffic("b1024", "k_stack")},
+                   "includes the weight tape pulled by each of the 8 XCD L2s (served by the Infinity Cache)",
+           "hbm_bytes_per_launch": {"k_seq": traffic("b1024", "k_seq")},
            "small_batch": {"batch": 8, "source": f"profiles/{tag}_final_pmc_b8.txt", "k_lat": traffic("b8", "k_lat"),
                            "note": "each of the 8 XCD L2s pulls the 38 MB weight set once per step (304 MB) + activations"}},
           open(os.path.join(R, "profiles/pmc_traffic.json"), "w"), indent=1)

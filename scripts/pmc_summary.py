@@ -9,7 +9,7 @@ disp = defaultdict(set)
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         k = r["Kernel_Name"]
-        if not any(t in k for t in ("k_gemm", "k_attn", "k_mlp", "k_stack", "k_lat", "k_randn", "k_combine", "k_to_token", "k_from_token", "k_conv", "k_block0", "k_guided")):
+        if not any(t in k for t in ("k_gemm", "k_attn", "k_mlp", "k_stack", "k_seq", "k_x_to", "k_x_from", "k_lat", "k_randn", "k_combine", "k_to_token", "k_from_token", "k_conv", "k_block0", "k_guided")):
             continue
         k = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SYN_HIP_LIB") or os.path.join(_HERE, "csrc", "libsyn_
 
 SYN_LAYERS = 8
 EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_step_profile", "syn_pack_weight", "syn_pack_weight_t", "syn_to_token_major",
-           "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_test_gemm", "syn_test_attention",
+           "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_test_gemm", "syn_test_attention", "syn_test_handoff",
            "syn_wav_encode", "syn_wav_workspace_bytes", "syn_wav_out_frames",
            "syn_vq_conv1d", "syn_vq_quantize", "syn_vq_quantize_groups", "syn_vq_codes",
            "syn_vq_workspace_bytes", "syn_vq_map2latent", "syn_vq_latent2origin", "syn_vq_forward_decoder",
@@ -95,6 +95,7 @@ def load():
     lib.syn_linear.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     lib.syn_test_gemm.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.syn_test_attention.argtypes = [vp, vp, vp, i32, vp, vp]
+    lib.syn_test_handoff.argtypes = [vp, vp, vp, i64, vp, i32, i32, i32, vp]
     lib.syn_step_advance.argtypes = [vp, vp, vp, i32, vp, i32, vp]
     lib.syn_steps_advance.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp]
     lib.syn_ln_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]

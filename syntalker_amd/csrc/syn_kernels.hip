@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
 #pragma unroll
                     for (int mf = 0; mf < MFX; ++mf)
                         if (j != member)
-                            v[j][n2][mf] = *reinterpret_cast<const f32x4*>(set + (size_t)j * (MT * 512) + ((half * 2 + n2) * MFX + mf) * 2048);
+                            v[j][n2][mf] = lat::ld_xcd(reinterpret_cast<const f32x4*>(set + (size_t)j * (MT * 512) + ((half * 2 + n2) * MFX + mf) * 2048));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int n2 = 0; n2 < 2; ++n2)
@@ -1971,6 +1971,21 @@ int syn_linear(const void* x_bf16, const void* w_packed, const float* bias, int3
     a.X = (const __bf16*)x_bf16; a.ldx = k; a.x_rows = m_rows; a.W = (const uint4*)w_packed; a.K = k; a.M = m_rows;
     a.bias = bias; a.Yf = y; a.ldyf = n;
     return launch_gemm<EPI_PLAIN>(a, pick_tile(m_rows), n / kNT, (hipStream_t)stream);
+}
+
+int syn_test_handoff(uint32_t* sync_320_zeroed, uint32_t* buf_8x4096, const float* stream, int64_t stream_n, uint32_t* stale_9_zeroed,
+                     int32_t words, int32_t rounds, int32_t mode, void* stream_h) {
+    if (!sync_320_zeroed || !buf_8x4096 || !stale_9_zeroed || words <= 0 || words > 4096 || rounds <= 0 || mode < 0 || mode > 4)
+        return fail_msg("syn_test_handoff: bad arguments");
+    if (!latency_path_ok()) return fail_msg("syn_test_handoff: needs a 256-CU (8 XCD x 32) device");
+    static bool once = false;
+    if (!once) { allow_lds(lat::k_handoff_stress, 96 * 1024); once = true; }
+    lat::HArgs a;
+    a.sync = sync_320_zeroed; a.buf = buf_8x4096; a.stream = stream; a.stream_n = stream_n; a.stale = stale_9_zeroed;
+    a.words = words; a.rounds = rounds; a.mode = mode;
+    hipLaunchKernelGGL(lat::k_handoff_stress, dim3(256), dim3(512), 96 * 1024, (hipStream_t)stream_h, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_handoff_stress launch", e);
 }
 
 int syn_test_attention(const void* q, const void* k, const void* vt, int32_t n_seq, void* o, void* stream) {

@@ -231,3 +231,34 @@ def test_q_sample_on_the_device_vs_oracle():
     # the autograd-visible form (a tensor that requires grad) takes the torch expression and agrees with the kernel
     xg = x0.cuda().requires_grad_(True)
     assert rel_l2(d.q_sample(xg, t.cuda(), noise=eps.cuda()).detach().cpu(), got.cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("words,loaded", [(64, False), (1024, True), (4096, True)])
+def test_group_barrier_acquire_under_adversarial_reuse(lib, words, loaded):
+    """What the members of an XCD group (small-batch kernel k_lat, tile-split mode of k_stack) must do to read each other's
+    data, in the most hostile form: a consumer CU that keeps the exchanged words L1-resident (the same <= 16 KB re-read every
+    round), a new payload every round, every word checked, the rest of the XCD streaming from HBM.
+      * plain loads are stale on this chip - and `buffer_inv sc0`, which round 1's barrier used, changes nothing (the check is
+        sharp: it would catch a broken acquire);
+      * the agent-scope `buffer_inv sc1` works but costs ~14 us per barrier in k_lat;
+      * loads that bypass the L1 (non-temporal: `ld_xcd` in syn_latency.inc; or sc1 through a buffer descriptor) never read a
+        stale word and need no cache maintenance at all: that is what the kernels do."""
+    from syntalker_amd import _lib
+    dev = "cuda"
+    stream = torch.randn(64 << 20, device=dev) if loaded else None
+    rounds = 20000
+
+    def run(mode):
+        sync = torch.zeros(320, dtype=torch.int32, device=dev)
+        buf = torch.zeros(8, 4096, dtype=torch.int32, device=dev)
+        stale = torch.zeros(9, dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().syn_test_handoff(sync.data_ptr(), buf.data_ptr(), _lib.ptr(stream), 0 if stream is None else stream.numel(),
+                                                stale.data_ptr(), words, rounds, mode, _lib.current_stream()), "syn_test_handoff")
+        torch.cuda.synchronize()
+        assert int(sync.view(10, 32)[:8, 2].min()) == rounds, "a producer / consumer pair did not finish (spin limit)"
+        return int(stale[:8].sum())
+
+    res = {name: run(mode) for mode, name in enumerate(("plain loads", "buffer_inv sc0", "buffer_inv sc1", "non-temporal loads", "sc1 buffer loads"))}
+    print(f"stale words over {rounds} rounds x 8 XCDs x {words} words: {res}")
+    assert res["non-temporal loads"] == 0 and res["sc1 buffer loads"] == 0 and res["buffer_inv sc1"] == 0
+    assert res["plain loads"] > 0, "no staleness with plain loads: this test would not catch a broken hand-off"
