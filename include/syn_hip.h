@@ -179,6 +179,22 @@ int64_t syn_wav_workspace_bytes(int32_t n_clips, int32_t n_samples);
 int syn_wav_encode(const syn_wavenc* enc, const float* wav, int32_t n_clips, int32_t n_samples, void* workspace, float* out,
                    void* stream);
 
+/* ---- per-clip conditioning behind the audio encoder --------------------------------
+ * models/denoiser.py:147-157,160-174: word embedding -> Linear 300->256, cat with the audio features -> mix_audio_text
+ * (512->256) -> avg_pool1d(4) -> . W2c^T, plus embed_text(seed) . W2a^T [+ style . W3s^T] and every bias: the additive
+ * tensor `cond` of syn_step.  All of it is affine, so the caller folds it once per weight set (syntalker_amd/conditioning.py
+ * CondWeights, fp64) into
+ *   gt [256][512] = (W2c Wm_a)^T        tw [vocab][512] = word_embedding (W2c Wm_w Wt)^T      (the word path is a lookup)
+ *   st [seed_dim + style_dim][512] = [W2a W_embed_text | W3s]^T        c0 [512] = all constant terms
+ * audio_feat [n_clips][128][256] fp32 (syn_wav_encode), word [n_clips][128] int64, seed [n_clips][seed_dim], style
+ * [n_clips][style_dim] or NULL, d_scratch [n_clips][512] -> cond [n_clips][32][512].  Two launches, fp32 arithmetic. */
+typedef struct syn_cond_weights {
+    const float* gt; const float* tw; const float* st; const float* c0;
+    int32_t vocab, seed_dim, style_dim, reserved;
+} syn_cond_weights;
+int syn_cond_encode(const syn_cond_weights* w, const float* audio_feat, const int64_t* word, const float* seed, const float* style,
+                    int32_t n_clips, float* d_scratch, float* cond, void* stream);
+
 /* ---- load-time helpers -------------------------------------------------------------------- */
 /* fp32 row-major W[n][k] (nn.Linear.weight layout) -> packed bf16 fragments (n*k*2 bytes).
  * n % 16 == 0, k % 32 == 0. */

@@ -154,41 +154,70 @@ def rotary_tables(inv_freq, n_pos: int = 32):
     return fr.cos().contiguous(), fr.sin().contiguous()
 
 
+class CondWeights:
+    """Everything between the audio features and `cond` folded into four tables (fp64 fold, fp32 tables):
+         cond[b][f] = pool4(audio_feat)[b][f] . GT + 1/4 sum_{i<4} TW[word[b][4f+i]] + d[b]
+         d[b]       = [seed[b] | style[b]] . ST + c0
+       GT = (W2c Wm_a)^T, TW = word_embedding (W2c Wm_w Wt)^T (the whole word path becomes a table lookup),
+       ST = [W2a W_embed_text | W3s]^T, c0 = W2c (Wm_w bt + bm) + W2a b_embed_text + cbias   (models/denoiser.py:147-157,160-174)."""
+
+    def __init__(self, sd, folded, use_style: bool, device):
+        f64 = lambda t: t.detach().double().cpu()
+        W2c, W2a = f64(folded["W2c"]), f64(folded["W2a"])
+        Wm, bm = f64(sd["mix_audio_text.weight"]), f64(sd["mix_audio_text.bias"])
+        Wt, bt = f64(sd["text_encoder_body.weight"]), f64(sd["text_encoder_body.bias"])
+        emb = f64(sd["text_pre_encoder_body.weight"])
+        Wet, bet = f64(sd["embed_text.weight"]), f64(sd["embed_text.bias"])
+        na = Wm.shape[1] - Wt.shape[0]                       # audio feature width (256)
+        Wm_a, Wm_w = Wm[:, :na], Wm[:, na:]
+        self.audio_f = na
+        gt = (W2c @ Wm_a).T                                   # (256, 512)
+        tw = emb @ (W2c @ Wm_w @ Wt).T                        # (vocab, 512)
+        st = (W2a @ Wet).T                                    # (6144, 512)
+        c0 = W2c @ (Wm_w @ bt + bm) + W2a @ bet + f64(folded["cbias"])
+        self.seed_dim, self.style_dim = Wet.shape[1], 0
+        if use_style:
+            W3s = f64(folded["W3s"])
+            st = torch.cat([st, W3s.T], 0)
+            self.style_dim = W3s.shape[1]
+        to = lambda t: t.float().contiguous().to(device)
+        self.gt, self.tw, self.st, self.c0 = to(gt), to(tw), to(st), to(c0)
+        self.vocab = emb.shape[0]
+        self._c = None
+
+    def c_struct(self):
+        from . import _lib
+        if self._c is None:
+            c = _lib.SynCondWeights()
+            c.gt, c.tw, c.st, c.c0 = self.gt.data_ptr(), self.tw.data_ptr(), self.st.data_ptr(), self.c0.data_ptr()
+            c.vocab, c.seed_dim, c.style_dim = self.vocab, self.seed_dim, self.style_dim
+            self._c = c
+        return self._c
+
+    def host_eval(self, audio_feat, word, seed, style):
+        """The formula above in plain torch: the CPU tests check the FOLD against the oracle with it.  Not a code path of
+        `ClipConditioner.cond`, which runs on the HIP kernels only."""
+        bs = seed.shape[0]
+        x = seed.reshape(bs, -1).float()
+        if self.style_dim:
+            x = torch.cat([x, style.float()], 1)
+        d = x @ self.st + self.c0
+        ap = audio_feat.float().reshape(bs, -1, 4, self.audio_f).mean(2)
+        tw = self.tw[word.clamp(0, self.vocab - 1)].reshape(bs, -1, 4, D).mean(2)
+        return ap @ self.gt + tw + d.unsqueeze(1)
+
+
 class ClipConditioner:
-    """Computes ``cond`` for a batch of clips; caches the expensive audio/word branch per masking state."""
+    """Computes ``cond`` for a batch of clips on the HIP kernels (audio encoder `syn_wav_encode`, everything behind it
+    `syn_cond_encode`); caches the audio features per masking state so that guidance variants pay for the encoder once."""
 
     def __init__(self, sd, folded, variant: str, use_style: bool, pool: int = 4):
         self.sd, self.fw, self.variant, self.use_style, self.pool = sd, folded, variant, use_style, pool
         self.wav_blocks = fold_wav_encoder(sd)
         self._hip_wav = None
-        self.W2c_f = folded["W2c"].float()
-        self.W2a_f = folded["W2a"].float()
-        self.W3s_f = folded["W3s"].float() if folded["W3s"] is not None else None
-        self.cbias_f = folded["cbias"].float()
-
-    def frame_term(self, audio, word):
-        """(B, 32, 512): pool(mix([wav | word])) W2c^T."""
-        sd = self.sd
-        if audio.is_cuda:               # the HIP encoder (SURVEY 8 f1); CPU tensors only occur in host-logic tests
-            if self._hip_wav is None:
-                self._hip_wav = HipWavEncoder(self.wav_blocks, audio.device)
-            a = self._hip_wav(audio)
-        else:
-            a = wav_features(self.wav_blocks, audio)
-        w = F.linear(F.embedding(word, sd["text_pre_encoder_body.weight"]),
-                     sd["text_encoder_body.weight"], sd["text_encoder_body.bias"])
-        at = F.linear(torch.cat([a, w], dim=2), sd["mix_audio_text.weight"], sd["mix_audio_text.bias"])
-        at = F.avg_pool1d(at.transpose(1, 2), self.pool).transpose(1, 2)
-        return at @ self.W2c_f.T
-
-    def clip_term(self, seed, style):
-        """(B, 512): embed_text(seed) W2a^T [+ style W3s^T] + cbias."""
-        bs = seed.shape[0]
-        e = F.linear(seed.reshape(bs, -1), self.sd["embed_text.weight"], self.sd["embed_text.bias"])
-        d = e @ self.W2a_f.T + self.cbias_f
-        if style is not None:
-            d = d + style @ self.W3s_f.T
-        return d
+        if pool != 4:
+            raise NotImplementedError("the conditioning kernel pools 4 audio frames per latent frame (vqvae_squeeze_scale = 4)")
+        self.weights = CondWeights(sd, folded, use_style, sd["mix_audio_text.weight"].device)
 
     def style_of(self, y, uncond: bool, bs: int):
         """mask_cond at eval time (models/denoiser.py:110-119, models/denoiser_h3d.py:116-124)."""
@@ -212,13 +241,36 @@ class ClipConditioner:
 
     @torch.no_grad()
     def cond(self, y, uncond: bool = False, uncond_audio: bool = False, frame_cache: dict | None = None):
+        """-> (B, 32, 512) fp32.  frame_cache: dict shared by the variants of one batch (audio features per audio-masking state)."""
+        import ctypes as C
+        from . import _lib
         bs = y["seed"].shape[0]
+        audio, word = self.audio_word_of(y, uncond_audio)
+        if not audio.is_cuda:
+            raise _lib.SynHipError(f"conditioning inputs are on {audio.device}: the per-clip encoders run only on the MI355X HIP "
+                                   "kernels (no CPU fallback). Move the model and model_kwargs['y'] to a cuda device.")
+        dev = audio.device
         key = bool(uncond_audio and self.variant == "h3d")
         if frame_cache is not None and key in frame_cache:
-            c_frame = frame_cache[key]
+            feat = frame_cache[key]
         else:
-            c_frame = self.frame_term(*self.audio_word_of(y, uncond_audio))
+            if self._hip_wav is None:
+                self._hip_wav = HipWavEncoder(self.wav_blocks, dev)
+            feat = self._hip_wav(audio)
             if frame_cache is not None:
-                frame_cache[key] = c_frame
-        d = self.clip_term(y["seed"], self.style_of(y, uncond, bs))
-        return (c_frame + d.unsqueeze(1)).contiguous()
+                frame_cache[key] = feat
+        if feat.shape[1] != 128:
+            raise _lib.SynHipError(f"audio of {audio.shape[1]} samples gives {feat.shape[1]} feature frames; the step kernels need 128 "
+                                   "(68224 .. 68266 samples per 128-pose-frame clip)")
+        w = self.weights
+        if w.gt.device != dev:
+            raise _lib.SynHipError(f"conditioning weights are on {w.gt.device}, inputs on {dev}")
+        style = self.style_of(y, uncond, bs)
+        style = None if style is None else style.detach().float().contiguous()
+        seed = y["seed"].detach().reshape(bs, -1).float().contiguous()
+        word = word.detach().to(torch.int64).contiguous()
+        out = torch.empty(bs, 32, D, dtype=torch.float32, device=dev)
+        d = torch.empty(bs, D, dtype=torch.float32, device=dev)
+        _lib.check(_lib.load().syn_cond_encode(C.byref(w.c_struct()), feat.data_ptr(), word.data_ptr(), seed.data_ptr(), _lib.ptr(style),
+                                               bs, d.data_ptr(), out.data_ptr(), _lib.current_stream(dev)), "syn_cond_encode")
+        return out

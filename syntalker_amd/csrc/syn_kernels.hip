@@ -1621,6 +1621,7 @@ int launch_stack(const SArgs& a, int mt, hipStream_t s) {
 }
 
 #include "syn_seq.inc"
+#include "syn_cond.inc"
 #include "syn_wavenc.inc"
 #include "syn_train.inc"
 #include "syn_rvq.inc"
@@ -2043,6 +2044,21 @@ int syn_attn_bwd(const float* qkv, const float* d_o, float* dqkv, int32_t n_seq,
     hipLaunchKernelGGL(trn::k_attn_bwd, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnBwdLds, (hipStream_t)stream, qkv, d_o, dqkv);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_attn_bwd launch", e);
+}
+
+int syn_cond_encode(const syn_cond_weights* w, const float* audio_feat, const int64_t* word, const float* seed, const float* style,
+                    int32_t n_clips, float* d_scratch, float* cond, void* stream) {
+    if (!w || !w->gt || !w->tw || !w->st || !w->c0 || !audio_feat || !word || !seed || !d_scratch || !cond || n_clips <= 0)
+        return fail_msg("syn_cond_encode: null argument");
+    if (w->seed_dim <= 0 || w->style_dim < 0 || w->vocab <= 0 || (w->style_dim > 0 && !style))
+        return fail_msg("syn_cond_encode: bad dimensions (a model with a style projection needs the style vectors)");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(cnd::k_cond_clip, dim3(SYN_D / 64, (n_clips + 15) / 16), dim3(256), 0, s, seed, w->seed_dim, style, w->style_dim,
+                       w->st, w->c0, n_clips, d_scratch);
+    hipLaunchKernelGGL(cnd::k_cond_frames, dim3(SYN_D / 128, n_clips), dim3(256), 0, s, audio_feat, (const long long*)word, w->gt, w->tw,
+                       w->vocab, d_scratch, cond);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_cond_encode", e);
 }
 
 int32_t syn_wav_out_frames(int32_t n_samples) { return n_samples >= 15 ? wav_plan(n_samples).L4 : 0; }

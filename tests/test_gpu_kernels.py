@@ -262,3 +262,43 @@ def test_group_barrier_acquire_under_adversarial_reuse(lib, words, loaded):
     print(f"stale words over {rounds} rounds x 8 XCDs x {words} words: {res}")
     assert res["non-temporal loads"] == 0 and res["sc1 buffer loads"] == 0 and res["buffer_inv sc1"] == 0
     assert res["plain loads"] > 0, "no staleness with plain loads: this test would not catch a broken hand-off"
+
+
+@pytest.mark.parametrize("variant", ["beatx", "h3d"])
+def test_conditioning_kernels_vs_oracle(variant):
+    """everything behind the audio encoder (word embedding gather, 300->256, concat, mix 512->256, avg-pool 4,
+    . W2c^T, seed / style terms, all biases; models/denoiser.py:147-157,160-174) as two fp32 HIP launches (`syn_cond_encode`),
+    (a) fed the oracle's fp32 audio features: <= 1e-5 vs oracle/denoiser_ref.clip_conditioning;
+    (b) the whole per-clip conditioning (HIP bf16 audio encoder in front): <= 6e-3, and nothing but HIP launches."""
+    import ctypes as C
+    from oracle import denoiser_ref as dr
+    from syntalker_amd import _lib, conditioning, synth
+    from tests.refmodel import synth_state_dict
+    sd = synth_state_dict(variant)
+    style = variant == "h3d"
+    B = 19                                                       # ragged: clip tiles of 16 in the seed GEMM
+    y = synth.synth_clip_inputs(B, seed=8, style_dim=256 if style else 512, style_zero=not style)
+    fo = dr.fold_weights(sd, variant)
+    sd_dev = {k: v.cuda() for k, v in sd.items()}
+    fw = conditioning.fold_input_stage(sd_dev, style)
+    cc = conditioning.ClipConditioner(sd_dev, fw, variant, style)
+    yd = synth.to_device(y, "cuda")
+    for flags in ((False, False), (True, True)):
+        yy = dict(y, uncond=flags[0], uncond_audio=flags[1])
+        with torch.no_grad():
+            want = dr.clip_conditioning(sd, yy, fo, variant)
+            audio, word = cc.audio_word_of(y, flags[1])
+            feat = dr.wav_encoder(sd, audio).contiguous().cuda()
+        st = cc.style_of(yd, flags[0], B)
+        st = None if st is None else st.float().contiguous()     # (operands stay referenced until the launch is enqueued)
+        word_d, seed_d = word.cuda().contiguous(), yd["seed"].reshape(B, -1).contiguous()
+        out, d = torch.empty(B, 32, 512, device="cuda"), torch.empty(B, 512, device="cuda")
+        _lib.check(_lib.load().syn_cond_encode(C.byref(cc.weights.c_struct()), feat.data_ptr(), word_d.data_ptr(), seed_d.data_ptr(),
+                                               _lib.ptr(st), B, d.data_ptr(), out.data_ptr(), _lib.current_stream()), "syn_cond_encode")
+        e = rel_l2(out.cpu(), want)
+        print(f"{variant} {flags}: syn_cond_encode on fp32 features rel-L2 {e:.2e}")
+        assert e < 1e-5
+        full = cc.cond(yd, *flags).cpu()
+        e = rel_l2(full, want)
+        print(f"{variant} {flags}: whole per-clip conditioning rel-L2 {e:.2e}")
+        assert e < 6e-3

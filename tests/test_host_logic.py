@@ -13,6 +13,7 @@ from oracle import denoiser_ref as dr
 from oracle import guidance_ref as gr
 from oracle.process_ref import RefProcess
 from syntalker_amd import checkpoint, conditioning, engine, guidance, process, resample, synth
+from syntalker_amd._lib import SynHipError
 from tests.conftest import REPO, rel_l2
 from tests.refmodel import state_spec, synth_state_dict
 
@@ -139,7 +140,13 @@ def test_folding_and_conditioning_equal_oracle(variant):
     for flags in ((False, False), (True, True)):
         yy = dict(y, uncond=flags[0], uncond_audio=flags[1])
         want = dr.clip_conditioning(sd, yy, {k: (v.float() if v is not None else None) for k, v in fo.items()}, variant)
-        assert rel_l2(cc.cond(y, *flags), want) < 5e-6, flags
+        # the fold behind the conditioning kernels (word path as a table, everything affine collapsed), evaluated on the host:
+        # BN-folded convolutions -> folded tables -> cond
+        audio, word = cc.audio_word_of(y, flags[1])
+        got = cc.weights.host_eval(conditioning.wav_features(cc.wav_blocks, audio), word, y["seed"], cc.style_of(y, flags[0], 2))
+        assert rel_l2(got, want) < 5e-6, flags
+        with pytest.raises(SynHipError):                # the product path itself has no CPU fallback
+            cc.cond(y, *flags)
     te = conditioning.time_table(sd, fw["W2a"], 1000)
     assert rel_l2(te, dr.time_table(sd, {k: (v.float() if v is not None else None) for k, v in fo.items()})) < 5e-6
     rc, rs = conditioning.rotary_tables(sd["rel_pos.inv_freq"])
