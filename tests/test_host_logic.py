@@ -276,3 +276,16 @@ def test_configured_but_missing_checkpoint_paths_raise(tmp_path):
     a = config.load_args(None, vqvae_upper_path=str(tmp_path / "nope.bin"))
     with pytest.raises(FileNotFoundError, match="vqvae_upper_path"):
         config.build_vq_models(a, device="cpu")
+
+
+def test_frechet_metric_equals_oracle_restatement():
+    """syntalker_amd/metrics.py (product, host side) vs oracle/frechet_ref.py (restatement of data_tools.py:1615-1685)."""
+    from oracle.frechet_ref import embed_latents, frechet_distance
+    from syntalker_amd import metrics
+    rng = np.random.default_rng(0)
+    a, b = rng.standard_normal((300, 24)), rng.standard_normal((300, 24)) * 1.2 + 0.3
+    assert abs(metrics.frechet_distance(a, b) - frechet_distance(a, b)) < 1e-9
+    assert metrics.frechet_distance(a, a) < 1e-6
+    lat = rng.standard_normal((5, 32, 1536))
+    want = embed_latents(np.transpose(lat, (0, 2, 1))[:, :, None, :], dim=12)        # the oracle takes (N, 1536, 1, 32)
+    assert np.allclose(metrics.latent_embedding(lat, dim=12), want)

@@ -1,6 +1,10 @@
 """Chunked long-sequence driver: window arithmetic on CPU, end-to-end parity on the GPU."""
+import os
+
 import pytest
 import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from syntalker_amd import longform, synth
 
@@ -94,3 +98,56 @@ def test_sample_long_vs_oracle(use_ddim):
     e = rel_l2(got, want)
     print(f"long-form ({'ddim' if use_ddim else 'ddpm'}) rel-L2 vs oracle: {e:.3e}")
     assert e < 3e-2
+
+
+@pytest.mark.gpu
+def test_sample_from_config_driver(tmp_path):
+    """the `test.py -c <yaml>` scenario end to end - reference-style YAML -> config.load_args -> build_sampler ->
+    sample_long -> decode_take -> Fréchet statistic - through scripts/sample_from_config.py.  48 one-window takes, DDIM-50; the
+    statistic against the oracle's samples (same weights and conditioning, its own noise) must sit at the oracle-vs-oracle
+    noise floor."""
+    import importlib.util
+    import numpy as np
+    from oracle import denoiser_ref as dr
+    from oracle.process_ref import RefProcess
+    from syntalker_amd import longform, metrics, synth
+    from tests.refmodel import synth_state_dict
+    spec = importlib.util.spec_from_file_location("sample_from_config", os.path.join(REPO, "scripts", "sample_from_config.py"))
+    drv = importlib.util.module_from_spec(spec); spec.loader.exec_module(drv)
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text("vqvae_type: rvqvae\nvqvae_squeeze_scale: 4\nvqvae_latent_scale: 5\nuse_trans: True\naudio_f: 256\nword_f: 256\n"
+                   "pose_length: 128\npre_frames: 4\npose_fps: 30\naudio_rep: onset+amplitude\n"
+                   "test_ckpt: ./ckpt/beatx2_cospeech_diffusion/last_500.bin\nvqvae_upper_path: ./ckpt/beatx2_rvqvae/RVQVAE_upper/net_300000.pth\n")
+    with pytest.raises(FileNotFoundError):                       # configured checkpoints must exist unless --random-init
+        drv.main([str(cfg), "--takes", "1"])
+    B, n, dim = 48, 128, 16
+    g = torch.Generator().manual_seed(5)
+    audio, word = torch.randn(B, n * longform.AUDIO_PER_POSE, 2, generator=g), torch.randint(0, synth.VOCAB, (B, n), generator=g)
+    seed_lat = torch.randn(B, n // 4, 1536, generator=g)
+    inp = tmp_path / "in.npz"
+    np.savez(inp, audio=audio.numpy(), word=word.numpy(), seed=seed_lat.numpy())
+    # reference side: the oracle's DDIM-50 samples for the same windows, two independent noise draws
+    sd = synth_state_dict("beatx")
+    fw = dr.fold_weights(sd)
+    y = longform.window_inputs(0, audio, word, seed_lat, None, 112)
+    with torch.no_grad():
+        cond, te = dr.clip_conditioning(sd, y, fw), dr.time_table(sd, fw)
+        fn = lambda a, b, c: dr.mdm_forward_folded(sd, fw, cond, te, a, b)
+        refs = []
+        for s in (11, 12):
+            gg = torch.Generator().manual_seed(s)
+            x = RefProcess(True).ddim_sample_loop(fn, (B, 1536, 1, 32), y, noise=torch.randn(B, 1536, 1, 32, generator=gg),
+                                                  step_noise=torch.zeros(50, B, 1536, 1, 32))
+            refs.append(metrics.latent_embedding(x[:, :, 0, :].permute(0, 2, 1).numpy(), dim=dim))
+    floor = metrics.frechet_distance(refs[0], refs[1])
+    mu, sigma = metrics.gaussian_stats(refs[0])
+    np.savez(tmp_path / "ref.npz", mu=mu, sigma=sigma)
+    rep = drv.main([str(cfg), "--random-init", "--ddim", "--inputs", str(inp), "--ref-stats", str(tmp_path / "ref.npz"),
+                    "--out", str(tmp_path / "out.npz")])
+    assert rep["finite"] and rep["windows"] == 1 and rep["latents"] == [B, 32, 1536]
+    assert rep["poses"]["upper"] == [B, 128, 78] and rep["poses"]["hands"] == [B, 128, 180] and rep["poses"]["lower"] == [B, 128, 54]
+    assert rep["poses"]["trans"] == [B, 128, 3]
+    print(f"Frechet (dim {dim}, N {B}): HIP vs oracle {rep['frechet_vs_ref']:.4f}, oracle vs oracle {floor:.4f}")
+    assert rep["frechet_vs_ref"] < 2.0 * floor + 1e-3
+    z = np.load(tmp_path / "out.npz")
+    assert z["upper"].shape == (B, 128, 78) and np.isfinite(z["trans"]).all()
