@@ -14,4 +14,4 @@ $T scripts/prof_pmc.sh b8_sq "$SQ" --batch 8 --steps 20 --warmup 5 --no-cpu --no
 $T scripts/prof_pmc.sh b8_fetch "FETCH_SIZE" --batch 8 --steps 20 --warmup 5 --no-cpu --no-small-batch > /dev/null 2>&1
 $T scripts/prof_pmc.sh b8_write "TCC_HIT_sum TCC_MISS_sum WRITE_SIZE" --batch 8 --steps 20 --warmup 5 --no-cpu --no-small-batch > /dev/null 2>&1
 for d in gpurun_out/prof_final_b1024 gpurun_out/prof_final_b8; do echo "== $d"; cat $d/bench.json | cut -c1-300; head -4 $d/kernel_stats.csv | cut -c1-200; done
-for d in gpurun_out/pmc_*; do echo "== $d"; cat $d/summary.txt | grep -E "kernel|k_stack|k_lat"; done
+for d in gpurun_out/pmc_*; do echo "== $d"; cat $d/summary.txt | grep -E "kernel|k_stack|k_seq|k_lat"; done
