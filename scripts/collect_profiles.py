@@ -35,7 +35,7 @@ for b, note in notes.items():
             f.write(rd(f"gpurun_out/pmc_{b}_{part}/summary.txt") + "\n")
         f.write("# FETCH_SIZE / WRITE_SIZE in KiB as reported; gfx950 FETCH_SIZE under-reports wide streaming reads by 2x (MI355X_MICROARCH.md, HBM section): "
                 "corrected bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024.\n"
-                "# SQ_WAVE_CYCLES / SQ_WAIT* / SQ_ACTIVE* in quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over 1024 SIMDs (= 16 x number of 16x16x32 bf16 MFMAs); "
+                "# SQ_WAVE_CYCLES / SQ_WAIT* / SQ_ACTIVE* in quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over 1024 SIMDs (= 32 x number of 32x32x16 bf16 MFMAs for k_seq, 16 x number of 16x16x32 ones for k_stack / k_lat); "
                 "GRBM_GUI_ACTIVE summed over the 8 XCDs.\n")
 traffic = lambda b, k: int((2 * val(f"{b}_fetch", k, "FETCH_SIZE") + val(f"{b}_write", k, "WRITE_SIZE")) * 1024)
 json.dump({"batch": 1024, "layer_mode": 0, "source": f"profiles/{tag}_final_pmc_b1024.txt",
