@@ -63,9 +63,9 @@ typedef struct syn_model {
     const float* b_out;     /* (1536)                                                            */
     /* the same weights as ONE contiguous tape of 1 KB MFMA fragments in consumption order + per-block bias sets, for the
      * wave-per-sequence step kernel (large batches; host: syntalker_amd/tape.py).  NULL = that kernel is never chosen. */
-    const void*  tape;        /* bf16 [tape_chunks][16 fragments][64 lanes][8]                    */
+    const void*  tape;        /* bf16 [tape_chunks][16 fragments][64 lanes][8] (1 KB fragments)    */
     const float* tape_bias;   /* [9][4096]                                                        */
-    int32_t      tape_chunks; /* 2240                                                             */
+    int32_t      tape_chunks; /* 2256 chunks of 16 fragments (36 096 fragments, 35.25 MB)           */
 } syn_model;
 
 /* One denoising step over n_clips clips, each evaluated under n_variants conditionings

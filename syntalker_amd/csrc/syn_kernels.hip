@@ -2158,7 +2158,8 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
         // large single-variant batches: one wave per sequence, weights streamed once per 128 rows (syn_seq.inc)
         if (!st->x_fragment_order) return fail_msg("syn_denoise_step: the wave-per-sequence kernel needs the latent in fragment order (x_fragment_order = 1)");
         if (V != 1) return fail_msg("syn_denoise_step: fragment-order latents are single-variant only (guided batches run token-major)");
-        if (!md->tape || !md->tape_bias || md->tape_chunks < 64) return fail_msg("syn_denoise_step: syn_model.tape is not set");
+        if (!md->tape || !md->tape_bias) return fail_msg("syn_denoise_step: syn_model.tape is not set");
+        if (md->tape_chunks * seq::kChunkFrags != 36096) return fail_msg("syn_denoise_step: syn_model.tape_chunks must count 16-fragment chunks of the 36096-fragment tape (2256)");
         seq::QArgs q;
         memset(&q, 0, sizeof(q));
         q.tape = (const char*)md->tape; q.tape_chunks = (unsigned)md->tape_chunks; q.bias = md->tape_bias;

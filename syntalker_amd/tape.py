@@ -11,7 +11,7 @@ directly as the next B operand: lane (hi, token) holds features {8q + 4hi + r}, 
 kc carries  k = 16 kc + 8 (e >> 2) + 4 hi + (e & 3)  instead of the natural 16 kc + 8 hi + e; the tape applies the
 same permutation to the weights' K index (a contraction does not care in which order k is visited).
 
-Fragment orders inside a piece (every piece is a multiple of 8 fragments = one 8 KB ring chunk):
+Fragment orders inside a piece (every piece is a multiple of 16 fragments = one 16 KB ring chunk):
   "wide16" [kc][tile 0..15]       all 16 tiles of the residual stream are live accumulators (input stage)
   "wide"   [kc][tile 0..11], then tiles 12..15 in pair order: inside the blocks the wave keeps residual tiles 12..15 in
                                   a private LDS slab (512 registers do not hold the residual stream, the LayerNorm output
@@ -43,7 +43,7 @@ from __future__ import annotations
 import torch
 
 D, FF, C, HEADS, LAYERS = 512, 1024, 1536, 4, 8
-CHUNK_FRAGS = 8
+CHUNK_FRAGS = 16       # fragments per ring chunk of the kernel (syn_seq.inc SEQ_CHUNK); syn_model.tape_chunks counts these
 TAPE_FRAGS = 1536 + LAYERS * (4096 + 32) + 1536
 BIAS_SET = 2048
 N_BIAS_SETS = LAYERS + 1

@@ -357,16 +357,18 @@ def test_tile_split_over_workgroups_equals_one_workgroup_per_tile(beatx, B, V):
         assert rel_l2(outs[0][:n], want) < FWD_TOL
 
 
-def test_full_size_properties(beatx):
-    """BASELINE-size batch (256 clips): properties that need no oracle.
+@pytest.mark.parametrize("B", [256, 1024], ids=["256-token-resident-kernel", "1024-wave-per-sequence-kernel"])
+def test_full_size_properties(beatx, B):
+    """BASELINE-size batches (256 clips: k_stack; 1024 clips, the bench's batch: the library keeps the latent in fragment
+    order and runs k_seq): properties that need no oracle.
        (1) t=0 step adds no noise: result independent of the injected noise;
        (2) the posterior update is the stated linear form of (x0_hat, x_t, eps): checked by running the
            same step with pred_x0 captured and recombining in fp64;
        (3) seeded in-library noise is reproducible and differs across seeds."""
     from syntalker_amd import engine
     from syntalker_amd.process import create_gaussian_diffusion
-    B = 256
     d = create_gaussian_diffusion()
+    assert beatx.buffers(B, 1).fragment == (B == 1024)
     y1 = synth.synth_clip_inputs(4, seed=31)
     y = {k: (v.repeat(B // 4, *([1] * (v.dim() - 1))) if torch.is_tensor(v) else v) for k, v in y1.items()}
     y = synth.to_device(y, DEV)

@@ -41,6 +41,7 @@ def test_tape_through_the_lane_level_model_reproduces_the_oracle():
     fw = dr.fold_weights(sd)
     t_tape, bias = tape.build_tape(sd, fw["A"])
     assert t_tape.shape == (tape.TAPE_FRAGS, 64, 8) and bias.shape == (9, 2048)
+    assert tape.TAPE_FRAGS == 36096 and tape.TAPE_FRAGS % tape.CHUNK_FRAGS == 0 and tape.TAPE_FRAGS // tape.CHUNK_FRAGS == 2256
     y, x = synth.synth_clip_inputs(1, seed=5), synth.synth_latent(1, seed=5)
     cond, te = dr.clip_conditioning(sd, y, fw), dr.time_table(sd, fw)
     t = torch.tensor([417])
