@@ -231,6 +231,7 @@ class ConvBf16Fn(torch.autograd.Function):
         xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
         ctx.save_for_backward(xb, wb)
         ctx.geom = (stride, pad)
+        ctx.bf16_dgrad = WAV_BF16 == 2
         return F.conv2d(xb, wb, None, stride=(1, stride), padding=(0, pad)).float()
 
     @staticmethod
@@ -240,14 +241,18 @@ class ConvBf16Fn(torch.autograd.Function):
         args = ((1, stride), (0, pad), (1, 1), False, (0, 0), 1)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = torch.ops.aten.convolution_backward(gy.to(torch.bfloat16), xb, wb, None, *args, (True, False, False))[0].float()
+            if ctx.bf16_dgrad:
+                gx = torch.ops.aten.convolution_backward(gy.to(torch.bfloat16), xb, wb, None, *args, (True, False, False))[0].float()
+            else:       # fp32 data gradient: rounding the activations' gradients to bf16 layer after layer is what loses the early blocks
+                gx = torch.ops.aten.convolution_backward(gy, xb.float(), wb.float(), None, *args, (True, False, False))[0]
         if ctx.needs_input_grad[1]:
             gw = torch.ops.aten.convolution_backward(gy, xb.float(), wb.float(), None, *args, (False, True, False))[1]
         return gx, gw, None, None
 
 
 WAV_BF16_FROM = 0         # first encoder block that uses it
-WAV_BF16 = False          # experiment, off: 15.1 -> 12.3 ms per step at B = 32, but the gradients of the first encoder blocks
+WAV_BF16 = False          # False | 1: bf16 forward only (data and weight gradients fp32) | 2: bf16 forward + data gradient.
+                          # 2 measured 15.1 -> 12.3 ms per step at B = 32, but the gradients of the first encoder blocks
                           # move by up to 14 % (vs 1 % in fp32): the backward chain through the 12 convolutions amplifies every
                           # bf16 rounding ~1.5x per block (scripts/diag_train_grads.py)
 
