@@ -3,7 +3,22 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+LOG=$(mktemp)
 # -pragma-unroll-threshold: k_seq's GEMM pieces are straight-line code by design (every weight fragment's position in the
 # LDS ring is a compile-time constant); the default limit of 16 k instructions per unrolled loop refuses the larger ones.
-$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -mllvm -pragma-unroll-threshold=262144 -Wno-unused-result -Wno-unused-value -I../../include -shared -fPIC "$@" syn_kernels.hip -o libsyn_hip.so
+if ! $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -mllvm -pragma-unroll-threshold=262144 -Wno-unused-result -Wno-unused-value \
+        -I../../include -shared -fPIC "$@" syn_kernels.hip -o libsyn_hip.so -Rpass-analysis=kernel-resource-usage > "$LOG" 2>&1; then
+    grep -v "remark:" "$LOG" >&2 || true
+    rm -f "$LOG"
+    exit 1
+fi
+grep -v "remark:" "$LOG" >&2 || true
+# k_seq lives within a few registers of the 512 a wave has: an edit that tips hipcc's allocator over shows up
+# as hundreds of spilled registers and a 20-30 % slower step, not as an error.  Say so at build time.
+spills=$(grep -A12 "Function Name: .*k_seq" "$LOG" | grep "VGPRs Spill" | head -1 | sed 's/.*VGPRs Spill: \([0-9]*\).*/\1/' || true)
+rm -f "$LOG"
+echo "k_seq: ${spills:-?} spilled VGPRs"
+if [ -n "${spills}" ] && [ "${spills}" -gt 48 ]; then
+    echo "WARNING: k_seq spills ${spills} VGPRs (expected <= 16): the register allocation tipped over, expect a much slower step" >&2
+fi
 echo "built $(pwd)/libsyn_hip.so"
