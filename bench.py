@@ -386,13 +386,17 @@ def run_sample(args, rank, local, world, dev, dist):
     coef = engine.posterior_coefs(diff.tables(), dev)
     sb.set_rng(1234, first_clip=rank * B)
     # The loop exactly as SpacedDiffusion.p_sample_loop runs it (process.py `_fused`): the timestep schedule lives on the
-    # device, hook-free stretches replay a hipGraph of CH = 10 captured steps (one schedule kernel + 10 step kernels),
+    # device, hook-free stretches replay a hipGraph of CH = 10 steps (one schedule kernel + syn_denoise_steps: 10 step kernels, or ONE
+    # persistent 10-step launch of k_seq when the latent is in fragment order),
     # the remainder a single-step graph.  Noise ~ Philox(seed, step = t, global element index), drawn in the epilogue.
     CH, MAXS = 10, engine.StepGraph.MAX_STEPS
-    g10 = engine.StepGraph(pm, sb, coef, True, fused_rng=True, scheduled=True, steps=CH)
-    g1 = engine.StepGraph(pm, sb, coef, True, fused_rng=True, scheduled=True)
     ts = [999 - (i % 1000) for i in range(MAXS)]            # t = 999, 998, ... (wraps: any t is a valid step to time)
-    g10.set_schedule(ts, ts); g1.set_schedule(ts, ts)
+    g10 = engine.StepGraph(pm, sb, coef, True, fused_rng=True, scheduled=True, steps=CH)
+    g10.set_schedule(ts, ts)
+    g1 = None                                               # captured only when K or W is not a multiple of CH
+    if K % CH or W % CH:
+        g1 = engine.StepGraph(pm, sb, coef, True, fused_rng=True, scheduled=True)
+        g1.set_schedule(ts, ts)
     state = {"pos": 0, "last": None}
 
     def run_steps(n, events=None):
@@ -427,6 +431,8 @@ def run_sample(args, rank, local, world, dev, dist):
     dt = time.perf_counter() - t0
     assert sum(k for _, _, k in ev) == K
     replay_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / K   # average per-step duration of the replays inside the timed region
+    big = [(a, b) for a, b, k in ev if k == CH]
+    launch_ms = sum(a.elapsed_time(b) for a, b in big) / len(big) if big else replay_ms   # average duration of a CH-step replay
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -441,6 +447,9 @@ def run_sample(args, rank, local, world, dev, dist):
         tot, launches = [0.0] * 8, [0] * 8
         reps = 5 if args.layer_mode in (1, 2) else 1     # single-kernel steps are timed by the replay brackets; one eager launch
                                                          # only names the kernel (keeps the rocprofv3 average = the replay average)
+        frag = bool(getattr(sb, "fragment", False))   # the step runs on the wave-per-sequence kernel (latent in fragment order):
+        if frag:                                      # every k_seq launch of this command is one CH-step replay (no eager launch
+            reps = 0                                  # here: the rocprofv3 average of the kernel stays the replay average)
         for r in range(reps):
             sb.t_coef.fill_(500); sb.t_model.fill_(500)
             sb.c.coef = coef.data_ptr(); sb.c.noise = None; sb.c.rng = sb.rng.data_ptr()
@@ -450,7 +459,7 @@ def run_sample(args, rank, local, world, dev, dist):
                 tot[c] += ms[c]; launches[c] += cnt[c]
         rename = {0: {"fc2_gemm": "step_kernel"}, 4: {"fc2_gemm": "step_kernel"}, 3: {"fc2_gemm": "step_kernel"}, 1: {},
                   2: {"qkv_gemm": "attn_block", "fc2_gemm": "mlp_block"}}[args.layer_mode]
-        stage_ms = {STAGES[c]: tot[c] / reps for c in range(8) if launches[c]}
+        stage_ms = {STAGES[c]: tot[c] / max(reps, 1) for c in range(8) if launches[c]}
         # group by kernel symbol (proj and fc2 share one)
         by_kernel = {}
         for name, t in stage_ms.items():
@@ -460,13 +469,18 @@ def run_sample(args, rank, local, world, dev, dist):
             n_l = launches[STAGES.index(name)] // reps
             e = by_kernel.setdefault(sym, {"ms": 0.0, "launches": 0, "flops": 0.0})
             e["ms"] += t; e["launches"] += n_l; e["flops"] += fl * B * n_l
-        dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
-        d = by_kernel[dom]
-        if getattr(sb, "fragment", False):          # the step ran on the wave-per-sequence kernel (latent in fragment order)
-            dom = "k_seq"
-        avg_s = d["ms"] * 1e-3 / d["launches"]
-        if args.layer_mode in (0, 3, 4):       # the step IS one kernel: use the hipEvent brackets of the K timed replays
-            avg_s = replay_ms * 1e-3
+        spl = 1                                     # steps per launch of the dominant kernel
+        if frag:
+            # one persistent launch per CH-step replay (syn_denoise_steps): flops and duration per LAUNCH cover CH steps
+            dom, spl = "k_seq", (CH if K >= CH else 1)
+            d = {"ms": 0.0, "launches": 1, "flops": F_STEP * B * spl}
+            avg_s = launch_ms * 1e-3
+        else:
+            dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
+            d = by_kernel[dom]
+            avg_s = d["ms"] * 1e-3 / d["launches"]
+            if args.layer_mode in (0, 3, 4):       # the step IS one kernel: use the hipEvent brackets of the K timed replays
+                avg_s = replay_ms * 1e-3
         achieved = d["flops"] / d["launches"] / avg_s
         # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this
         # same command, summarised and committed under profiles/; null when no summary matches this batch size.
@@ -475,7 +489,7 @@ def run_sample(args, rank, local, world, dev, dist):
         if os.path.exists(tpath):
             try:
                 pj = json.load(open(tpath))
-                if pj.get("batch") == B and pj.get("layer_mode", 0) == args.layer_mode:
+                if pj.get("batch") == B and pj.get("layer_mode", 0) == args.layer_mode and pj.get("steps_per_launch", 1) == spl:
                     traffic = pj.get("hbm_bytes_per_launch", {}).get(dom, pj.get("hbm_bytes_per_launch", {}).get(dom + "<MT>"))
             except Exception:
                 traffic = None
@@ -485,7 +499,7 @@ def run_sample(args, rank, local, world, dev, dist):
         roofline = {"bound": "mfma", "kernel": dom.replace("MT", str(args.m_tile or "auto")),
                     "achieved": round(achieved / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16, 4), "traffic": traffic,
-                    "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": d["launches"],
+                    "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": d["launches"] / spl, "steps_per_launch": spl,
                     "whole_step_frac": round(value / world * F_STEP / PEAK_BF16, 4),
                     "timed_region_replay_ms": round(replay_ms, 4),
                     "eager_stage_ms_per_step": {rename.get(k, k): round(v, 4) for k, v in stage_ms.items()}}
@@ -497,8 +511,8 @@ def run_sample(args, rank, local, world, dev, dist):
                                    f"{B} clips/GPU x (1536,1,32) latents, MDM denoiser 8x512, random-init",
                        "clips_per_gpu": B, "global_clips": world * B, "parallelism": f"clip-sharded x{world}, no collective",
                        "m_tile": args.m_tile or "auto"},
-            "latency_note": "one step advances every clip of the batch; per-clip conditioning (audio encoder: HIP implicit-GEMM convs; "
-                            f"word/seed projections: PyTorch-ROCm; once per clip, outside the timed region): {cond_ms_per_clip:.3f} ms/clip = "
+            "latency_note": "one step advances every clip of the batch; per-clip conditioning (audio encoder: HIP implicit-GEMM convs; word / seed / pooling: two fp32 HIP launches; "
+                            f"once per clip, outside the timed region): {cond_ms_per_clip:.3f} ms/clip = "
                             f"{cond_ms_per_clip / (dt / K * 1e3 / B):.0f} denoising steps' worth",
             "roofline": roofline,
         }

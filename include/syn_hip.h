@@ -138,6 +138,15 @@ int syn_step_advance(const int32_t* sched, int32_t* counter, int32_t* t_model, i
 int syn_steps_advance(const int32_t* sched, int32_t* counter, int32_t* t_model, int32_t n_t_model, int32_t* t_coef,
                       int32_t n_t_coef, int32_t n_steps, void* stream);
 
+/* n_steps consecutive steps of a hook-free stretch of p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:714-739,
+ * 905-931), in place (x_next = x_t): step j takes its timesteps from t_model + j * t_model_stride and
+ * t_coef + j * t_coef_stride (the rows syn_steps_advance fills), its noise from rng (noise must be NULL when n_steps > 1).
+ * Fragment-order latents: ONE persistent launch - every workgroup carries its four sequences through all the steps, so the
+ * workgroups drift out of phase and the HBM traffic of the input / output stages of some overlaps the matrix work of the
+ * others.  Token-major latents: the launches of syn_denoise_step, n_steps times. */
+int syn_denoise_steps(const syn_model* model, const syn_step* step, int32_t n_steps, int32_t t_model_stride,
+                      int32_t t_coef_stride, void* stream);
+
 /* Same step, eagerly, with a hipEvent after every launch: fills ms_out[8] / count_out[8] with the elapsed
  * milliseconds and launch count per stage class {0 input GEMM, 1 qkv GEMM, 2 attention, 3 proj GEMM,
  * 4 fc1 GEMM, 5 fc2 GEMM, 6 guidance combine, 7 output GEMM}.  Synchronises `stream`; not graph-capturable. */

@@ -23,7 +23,7 @@ def val(part, kernel, col):
         if kernel in r["kernel"]:
             return float(r[col])
     raise KeyError((part, kernel, col))
-notes = {"b1024": "bench.py --steps 30 --warmup 5 --no-small-batch, B = 1024 clips: wave-per-sequence whole-step kernel k_seq",
+notes = {"b1024": "bench.py --steps 100 --warmup 10 --no-small-batch, B = 1024 clips: wave-per-sequence whole-step kernel k_seq, every launch = one persistent 10-step replay (syn_denoise_steps)",
          "b8": "bench.py --batch 8 --steps 300 --warmup 20 --no-small-batch: persistent small-batch kernel k_lat, one clip per XCD"}
 for b, note in notes.items():
     subprocess.run([sys.executable, os.path.join(R, "scripts/summarize_stats.py"), os.path.join(R, f"gpurun_out/prof_final_{b}/kernel_stats.csv"),
@@ -38,8 +38,8 @@ for b, note in notes.items():
                 "# SQ_WAVE_CYCLES / SQ_WAIT* / SQ_ACTIVE* in quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over 1024 SIMDs (= 32 x number of 32x32x16 bf16 MFMAs for k_seq, 16 x number of 16x16x32 ones for k_stack / k_lat); "
                 "GRBM_GUI_ACTIVE summed over the 8 XCDs.\n")
 traffic = lambda b, k: int((2 * val(f"{b}_fetch", k, "FETCH_SIZE") + val(f"{b}_write", k, "WRITE_SIZE")) * 1024)
-json.dump({"batch": 1024, "layer_mode": 0, "source": f"profiles/{tag}_final_pmc_b1024.txt",
-           "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 (gfx950 FETCH_SIZE correction); fabric-side traffic, "
+json.dump({"batch": 1024, "layer_mode": 0, "steps_per_launch": 10, "source": f"profiles/{tag}_final_pmc_b1024.txt",
+           "note": "bytes per launch (a k_seq launch = 10 steps) = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024 (gfx950 FETCH_SIZE correction); fabric-side traffic, "
                    "includes the weight tape pulled by each of the 8 XCD L2s (served by the Infinity Cache)",
            "hbm_bytes_per_launch": {"k_seq": traffic("b1024", "k_seq")},
            "small_batch": {"batch": 8, "source": f"profiles/{tag}_final_pmc_b8.txt", "k_lat": traffic("b8", "k_lat"),

@@ -4,12 +4,12 @@
 set -u
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 T="timeout 240"
-$T scripts/prof_stats.sh final_b1024 --steps 30 --warmup 5 --cpu-seconds 6 --no-small-batch > /dev/null 2>&1
+$T scripts/prof_stats.sh final_b1024 --steps 100 --warmup 10 --cpu-seconds 6 --no-small-batch > /dev/null 2>&1
 $T scripts/prof_stats.sh final_b8 --batch 8 --steps 300 --warmup 20 --no-cpu --no-small-batch > /dev/null 2>&1
 SQ="GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"
-$T scripts/prof_pmc.sh b1024_sq "$SQ" --steps 6 --warmup 2 --no-cpu --no-small-batch > /dev/null 2>&1
-$T scripts/prof_pmc.sh b1024_fetch "FETCH_SIZE" --steps 6 --warmup 2 --no-cpu --no-small-batch > /dev/null 2>&1
-$T scripts/prof_pmc.sh b1024_write "TCC_HIT_sum TCC_MISS_sum WRITE_SIZE" --steps 6 --warmup 2 --no-cpu --no-small-batch > /dev/null 2>&1
+$T scripts/prof_pmc.sh b1024_sq "$SQ" --steps 10 --warmup 10 --no-cpu --no-small-batch > /dev/null 2>&1
+$T scripts/prof_pmc.sh b1024_fetch "FETCH_SIZE" --steps 10 --warmup 10 --no-cpu --no-small-batch > /dev/null 2>&1
+$T scripts/prof_pmc.sh b1024_write "TCC_HIT_sum TCC_MISS_sum WRITE_SIZE" --steps 10 --warmup 10 --no-cpu --no-small-batch > /dev/null 2>&1
 $T scripts/prof_pmc.sh b8_sq "$SQ" --batch 8 --steps 20 --warmup 5 --no-cpu --no-small-batch > /dev/null 2>&1
 $T scripts/prof_pmc.sh b8_fetch "FETCH_SIZE" --batch 8 --steps 20 --warmup 5 --no-cpu --no-small-batch > /dev/null 2>&1
 $T scripts/prof_pmc.sh b8_write "TCC_HIT_sum TCC_MISS_sum WRITE_SIZE" --batch 8 --steps 20 --warmup 5 --no-cpu --no-small-batch > /dev/null 2>&1

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SYN_HIP_LIB") or os.path.join(_HERE, "csrc", "libsyn_hip.so")   # env override: kernel A/B builds
 
 SYN_LAYERS = 8
-EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_step_profile", "syn_pack_weight", "syn_pack_weight_t", "syn_to_token_major",
+EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_steps", "syn_denoise_step_profile", "syn_pack_weight", "syn_pack_weight_t", "syn_to_token_major",
            "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_test_gemm", "syn_test_attention", "syn_test_handoff",
            "syn_wav_encode", "syn_wav_workspace_bytes", "syn_wav_out_frames", "syn_cond_encode",
            "syn_vq_conv1d", "syn_vq_quantize", "syn_vq_quantize_groups", "syn_vq_codes",
@@ -86,6 +86,7 @@ def load():
     lib.syn_version.restype = C.c_int
     lib.syn_last_error.restype = C.c_char_p
     lib.syn_denoise_step.argtypes = [C.POINTER(SynModel), C.POINTER(SynStep), vp]
+    lib.syn_denoise_steps.argtypes = [C.POINTER(SynModel), C.POINTER(SynStep), C.c_int32, C.c_int32, C.c_int32, vp]
     lib.syn_denoise_step_profile.argtypes = [C.POINTER(SynModel), C.POINTER(SynStep), vp, vp, vp]
     lib.syn_pack_weight.argtypes = [vp, i32, i32, vp, vp]
     lib.syn_pack_weight_t.argtypes = [vp, i32, i32, i32, vp, vp]

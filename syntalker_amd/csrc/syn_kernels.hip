@@ -2140,7 +2140,11 @@ struct StageTimer {          // optional hipEvent after every launch
     }
 };
 
-static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, StageTimer* tm) {
+// Start-delay spread of a multi-step k_seq launch, in units of 64 cycles across the grid (syn_seq.inc); diagnostics only.
+static int g_seq_skew = -1, g_seq_dbg_step = 0;
+
+static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, StageTimer* tm, int n_steps = 1, int tm_stride = 0,
+                     int tc_stride = 0) {
     if (!md || !st) return fail_msg("syn_denoise_step: null model/step");
     const int B = st->n_clips, V = st->n_variants;
     if (B <= 0 || V <= 0) return fail_msg("syn_denoise_step: n_clips and n_variants must be positive");
@@ -2167,6 +2171,9 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
         q.xt = st->x_t; q.xb = (const uint4*)st->x_t_bf16; q.noise = st->noise; q.rng = (const unsigned long long*)st->rng;
         q.coef = st->coef; q.t_coef = st->t_coef; q.xn = st->x_next; q.xnb = (uint4*)st->x_next_bf16; q.x0 = st->pred_x0;
         q.R = B; q.dbg = g_dbg_mlp;
+        q.n_steps = n_steps; q.tm_stride = tm_stride; q.tc_stride = tc_stride; q.dbg_step = g_seq_dbg_step;
+        q.skew = n_steps > 1 && g_seq_skew > 0 ? (unsigned)g_seq_skew : 0u;      // (diagnostics: imposed start delays, see k_seq)
+        if (n_steps > 1 && st->noise) return fail_msg("syn_denoise_steps: injected noise is per step - run such steps one by one");
         if ((rc = launch_seq(q, s))) return rc;
         mark(ST_FC2);
         hipError_t e = hipGetLastError();
@@ -2331,6 +2338,27 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
 
 int syn_denoise_step(const syn_model* md, const syn_step* st, void* stream) {
     return step_impl(md, st, (hipStream_t)stream, nullptr);
+}
+
+void syn_debug_seq_skew(int units_of_64_cycles) { g_seq_skew = units_of_64_cycles; }
+void syn_debug_seq_step(int step) { g_seq_dbg_step = step; }
+
+int syn_denoise_steps(const syn_model* md, const syn_step* st, int32_t n_steps, int32_t t_model_stride, int32_t t_coef_stride,
+                      void* stream) {
+    if (!md || !st) return fail_msg("syn_denoise_steps: null model/step");
+    if (n_steps <= 0 || t_model_stride < 0 || t_coef_stride < 0) return fail_msg("syn_denoise_steps: n_steps must be positive, strides non-negative");
+    if (n_steps > 1 && (st->x_next != st->x_t || st->x_next_bf16 != st->x_t_bf16))
+        return fail_msg("syn_denoise_steps: consecutive steps run in place (x_next = x_t, x_next_bf16 = x_t_bf16)");
+    if (st->x_fragment_order) return step_impl(md, st, (hipStream_t)stream, nullptr, n_steps, t_model_stride, t_coef_stride);
+    // token-major latents: one launch (set) per step, the same kernels syn_denoise_step picks
+    syn_step one = *st;
+    for (int j = 0; j < n_steps; ++j) {
+        one.t_model = st->t_model + (size_t)j * t_model_stride;
+        one.t_coef = st->t_coef + (size_t)j * t_coef_stride;
+        const int rc = step_impl(md, &one, (hipStream_t)stream, nullptr);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int syn_denoise_step_profile(const syn_model* md, const syn_step* st, void* stream, float* ms_out, int32_t* count_out) {

@@ -172,12 +172,18 @@ class StepBuffers:
         return out
 
 
-def run_step(pm: PackedModel, sb: StepBuffers, coef: torch.Tensor, use_noise: bool = True, fused_rng: bool = False):
+def run_step(pm: PackedModel, sb: StepBuffers, coef: torch.Tensor, use_noise: bool = True, fused_rng: bool = False, steps: int = 1):
     """use_noise + fused_rng: the output GEMM's epilogue draws the noise, keyed by sb.rng = {seed, first_clip} and t_coef;
     use_noise only: the noise is read from sb.noise (injected or drawn by draw_noise)."""
     sb.c.coef = coef.data_ptr()
     sb.c.noise = sb.noise.data_ptr() if (use_noise and not fused_rng) else None
     sb.c.rng = sb.rng.data_ptr() if (use_noise and fused_rng) else None
+    if steps > 1:        # sb.c.t_model / t_coef point at [steps][n] rows (syn_steps_advance fills them)
+        if use_noise and not fused_rng:
+            raise ValueError("injected noise is per step: multi-step launches draw theirs (fused_rng) or run without")
+        _lib.check(_lib.load().syn_denoise_steps(C.byref(pm.c), C.byref(sb.c), steps, sb.t_model.numel(), sb.t_coef.numel(),
+                                                 _lib.current_stream(pm.device)), "syn_denoise_steps")
+        return
     _lib.check(_lib.load().syn_denoise_step(C.byref(pm.c), C.byref(sb.c), _lib.current_stream(pm.device)), "syn_denoise_step")
 
 
@@ -196,11 +202,21 @@ class StepGraph:
         if scheduled:
             self.sched = torch.zeros(self.MAX_STEPS, 2, dtype=torch.int32, device=pm.device)
             self.counter = torch.zeros(1, dtype=torch.int32, device=pm.device)
+        if steps > 1:
+            self.tm_rows = torch.zeros(steps, sb.t_model.numel(), dtype=torch.int32, device=pm.device)
+            self.tc_rows = torch.zeros(steps, sb.t_coef.numel(), dtype=torch.int32, device=pm.device)
         side = torch.cuda.Stream(device=pm.device)
         side.wait_stream(torch.cuda.current_stream(pm.device))
-        with torch.cuda.stream(side):          # warm-up launch outside capture (module load, etc.)
+        with torch.cuda.stream(side):          # warm-up launch outside capture (module load, etc.), the same launch(es) as captured
             x_save, xb_save = sb.x.clone(), sb.xb.clone()
-            run_step(pm, sb, coef, use_noise, fused_rng)
+            if steps > 1:
+                try:
+                    sb.c.t_model, sb.c.t_coef = self.tm_rows.data_ptr(), self.tc_rows.data_ptr()
+                    run_step(pm, sb, coef, use_noise, fused_rng, steps=steps)
+                finally:
+                    sb.c.t_model, sb.c.t_coef = sb.t_model.data_ptr(), sb.t_coef.data_ptr()
+            else:
+                run_step(pm, sb, coef, use_noise, fused_rng)
             sb.x.copy_(x_save); sb.xb.copy_(xb_save)
         torch.cuda.current_stream(pm.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
@@ -208,15 +224,14 @@ class StepGraph:
             if steps > 1:
                 # one schedule kernel per replay: it fills a row of timestep vectors per captured step, and every captured
                 # launch points at its own row (same-box A/B at B = 1: 160.5 -> 158.3 us per step)
-                self.tm_rows = torch.zeros(steps, sb.t_model.numel(), dtype=torch.int32, device=pm.device)
-                self.tc_rows = torch.zeros(steps, sb.t_coef.numel(), dtype=torch.int32, device=pm.device)
                 _lib.check(_lib.load().syn_steps_advance(self.sched.data_ptr(), self.counter.data_ptr(), self.tm_rows.data_ptr(),
                                                          sb.t_model.numel(), self.tc_rows.data_ptr(), sb.t_coef.numel(), steps,
                                                          _lib.current_stream(pm.device)), "syn_steps_advance")
+                # syn_denoise_steps: `steps` launches for token-major latents; ONE persistent launch for fragment-order latents
+                # (every workgroup takes its sequences through all the steps, the workgroups drift out of phase)
                 try:
-                    for j in range(steps):
-                        sb.c.t_model, sb.c.t_coef = self.tm_rows[j].data_ptr(), self.tc_rows[j].data_ptr()
-                        run_step(pm, sb, coef, use_noise, fused_rng)
+                    sb.c.t_model, sb.c.t_coef = self.tm_rows.data_ptr(), self.tc_rows.data_ptr()
+                    run_step(pm, sb, coef, use_noise, fused_rng, steps=steps)
                 finally:
                     sb.c.t_model, sb.c.t_coef = sb.t_model.data_ptr(), sb.t_coef.data_ptr()
             else:

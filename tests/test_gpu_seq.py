@@ -129,3 +129,31 @@ def test_seeded_ddpm_steps_vs_oracle_with_regenerated_noise(beatx):
     e = rel_l2(got, want)
     print(f"k_seq seeded 20-step DDPM vs oracle rel-L2 {e:.3e}")
     assert e < LOOP_TOL
+
+
+@pytest.mark.parametrize("noisy", [True, False])
+def test_persistent_multi_step_launch_equals_single_steps_bitwise(beatx, noisy):
+    """syn_denoise_steps on fragment-order latents is ONE launch in which every workgroup carries its sequences through all
+    the steps (skewed starts, the x_next a wave stores is the x_t it loads one step later): same bits as step by step."""
+    from syntalker_amd import engine
+    from syntalker_amd.process import create_gaussian_diffusion
+    B, K = 9, 7                                                        # three workgroups, the last one ragged
+    y = synth.to_device(synth.synth_clip_inputs(B, seed=51), DEV)
+    xT = synth.synth_latent(B, seed=51).to(DEV)
+    pm = beatx.packed()
+    coef = engine.posterior_coefs(create_gaussian_diffusion().tables(), DEV)
+    ts = [600 - 37 * i for i in range(K)]
+    outs = []
+    for steps in (1, K):
+        sb = engine.StepBuffers(B, 1, DEV, layer_mode=5)
+        sb.cond.copy_(beatx.variant_conds(y, [(False, False, None)]).reshape(-1, 512))
+        sb.set_rng(5, 2)
+        g = engine.StepGraph(pm, sb, coef, noisy, fused_rng=noisy, scheduled=True, steps=steps)
+        sb.load_x(xT)                                                  # (capturing ran a warm-up step)
+        g.set_schedule(ts, ts)
+        for _ in range(K // steps):
+            g.replay()
+        assert int(g.counter.item()) == K
+        outs.append((sb.read(sb.x).cpu(), sb.xb.clone().cpu()))
+    assert torch.isfinite(outs[0][0]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
