@@ -114,13 +114,14 @@ typedef struct syn_step {
                           chunks dealt to the members, partial residual streams exchanged through these slots)      */
     int32_t x_fragment_order; /* 0: x_t / x_t_bf16 / noise / x_next / pred_x0 are token-major (above); 1: they are in the
                           wave-per-sequence kernel's fragment order (syn_x_to_fragment), and that kernel runs the step
-                          (n_variants must be 1, syn_model.tape non-NULL).  syn_prefers_fragment_order() says when the
+                          (n_variants <= 4, syn_model.tape non-NULL; of the workspaces only cfg_w is used).  syn_prefers_fragment_order() says when the
                           library would like a caller to keep its latent that way.                                   */
     int32_t reserved2;
 } syn_step;
 
 /* 1 when a step over n_clips x n_variants is best run by the wave-per-sequence kernel, i.e. the caller should keep the
- * latent in fragment order for the whole loop (large single-variant batches); 0 otherwise. */
+ * latent in fragment order for the whole loop (large batches: >= 768 sequences in whole passes of 4 per CU; the <= 4
+ * variants of a guided clip are the waves of one workgroup and meet in the output stage through LDS); 0 otherwise. */
 int32_t syn_prefers_fragment_order(int32_t n_clips, int32_t n_variants);
 
 /* Enqueue one full step on `stream`: one kernel (k_stack, or k_lat for small batches; + k_guided_update when the

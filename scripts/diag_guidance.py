@@ -11,8 +11,10 @@ m = synth.synth_fill_(MDM(synth.default_args()).eval(), 0).cuda()
 pm = m.packed()
 coef = engine.ddim_coefs(create_gaussian_diffusion(use_ddim=True).tables(), 0.0, 'cuda')
 print("clips B, variants V: us per guided step, guided clip-steps/s, reference-evaluation-equivalents/s")
-for B, V, evals in ((1, 2, 2), (1, 4, 9), (8, 2, 2), (8, 4, 9), (512, 2, 2), (256, 4, 9), (1024, 2, 2)):
-    sb = engine.StepBuffers(B, V, 'cuda')
+F_STEP = 1_192_755_200
+for B, V, evals, mode in ((1, 2, 2, 0), (1, 4, 9, 0), (8, 2, 2, 0), (8, 4, 9, 0), (512, 2, 2, 4), (512, 2, 2, 0), (256, 4, 9, 4), (256, 4, 9, 0),
+                          (256, 3, 3, 4), (256, 3, 3, 0), (1024, 2, 2, 4), (1024, 2, 2, 0)):
+    sb = engine.StepBuffers(B, V, 'cuda', layer_mode=mode)      # 0: the library's choice, 4: the token-resident kernel pinned
     sb.cond.normal_(); sb.cfg_w.copy_(torch.tensor([[2.5, -1.5, 0, 0][:V]] * 3)); sb.load_x(torch.randn(B, 1536, 1, 32, device='cuda'))
     sb.t_model.fill_(25); sb.t_coef.fill_(25); sb.set_rng(3, 0)
     g = engine.StepGraph(pm, sb, coef, True, True)
@@ -23,4 +25,6 @@ for B, V, evals in ((1, 2, 2), (1, 4, 9), (8, 2, 2), (8, 4, 9), (512, 2, 2), (25
     for _ in range(n): g.replay()
     e1.record(); torch.cuda.synchronize(); sb.check_sync()
     us = e0.elapsed_time(e1) * 1e3 / n
-    print(f"  B={B:5d} V={V}: {us:9.1f} us  {B / us * 1e6:10.0f} guided clip-steps/s  {B * evals / us * 1e6:11.0f} ref-eval/s")
+    kern = "k_seq" if sb.fragment else ("pinned k_stack" if mode == 4 else "library")
+    print(f"  B={B:5d} V={V} {kern:14s}: {us:9.1f} us  {B / us * 1e6:10.0f} guided clip-steps/s  {B * evals / us * 1e6:11.0f} ref-eval/s  "
+          f"frac {B * V * F_STEP / (us * 1e-6) / 2.5e15:.3f}")

@@ -1669,10 +1669,18 @@ int launch_latency(const lat::LArgs& a, hipStream_t s) {
     return e == hipSuccess ? 0 : fail("k_lat launch", e);
 }
 
+// workgroups of a k_seq launch: 4 sequences each; a guided clip's V variants never straddle a workgroup
+int seq_grid(int n_clips, int n_variants) {
+    const int cpw = n_variants == 1 ? 4 : 4 / n_variants;
+    return (n_clips + cpw - 1) / cpw;
+}
+
 int launch_seq(const seq::QArgs& a, hipStream_t s) {
     static bool once = false;
-    if (!once) { allow_lds(seq::k_seq, seq::kLds); once = true; }
-    hipLaunchKernelGGL(seq::k_seq, dim3((a.R + 3) / 4), dim3(seq::kThreads), seq::kLds, s, a);
+    if (!once) { allow_lds(seq::k_seq<false>, seq::kLds); allow_lds(seq::k_seq<true>, seq::kLds); once = true; }
+    const dim3 grid(seq_grid(a.R, a.V));
+    if (a.V == 1) hipLaunchKernelGGL(seq::k_seq<false>, grid, dim3(seq::kThreads), seq::kLds, s, a);
+    else hipLaunchKernelGGL(seq::k_seq<true>, grid, dim3(seq::kThreads), seq::kLds, s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_seq launch", e);
 }
@@ -1751,13 +1759,15 @@ int32_t syn_prefers_fragment_order(int32_t n_clips, int32_t n_variants) {
     // k_seq runs 4 sequences per CU and pass, k_stack 2; measured per pass at full occupancy (profiles/r02_diag_seq.txt):
     // 1.26 ms against 0.66 ms.  Both quantise to whole passes over the 256 CUs, so the choice follows the pass counts:
     // 1024 / 2048 / 3072 clips -> k_seq, 1280 or 1536 -> k_stack (a second, mostly empty k_seq pass would cost more).
-    if (n_variants != 1 || n_clips < 768) return 0;
-    int dev = 0, cus = 256;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (cus <= 0) cus = 256;
-    const long passes_seq = (n_clips + 4L * cus - 1) / (4L * cus), passes_stack = (n_clips + 2L * cus - 1) / (2L * cus);
-    return passes_seq * 191 < passes_stack * 100 ? 1 : 0;
+    // Guided batches: the V variants of a clip are the waves of one workgroup (2 clips per workgroup at V = 2, one at V = 3
+    // - a wave idles - and 4); k_stack sees V * n_clips sequences.
+    if (n_variants < 1 || n_variants > 4) return 0;
+    const int cus = device_cus();
+    const long wgs = seq_grid(n_clips, n_variants), seqs = (long)n_clips * n_variants;
+    if (wgs < 3L * cus / 4) return 0;                         // (768 clips at V = 1)
+    const long passes_seq = (wgs + cus - 1) / cus, passes_stack = (seqs + 2L * cus - 1) / (2L * cus);
+    // (V = 3 leaves a wave of every workgroup idle: measured 1197 us against k_stack's 1120 at 256 clips)
+    return passes_seq * (n_variants == 3 ? 255 : 191) < passes_stack * 100 ? 1 : 0;
 }
 
 int syn_x_to_fragment(const float* x_bct, int32_t n_clips, float* out_f32, void* out_bf16, void* stream) {
@@ -2159,7 +2169,7 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     if (!md || !st) return fail_msg("syn_denoise_step: null model/step");
     const int B = st->n_clips, V = st->n_variants;
     if (B <= 0 || V <= 0) return fail_msg("syn_denoise_step: n_clips and n_variants must be positive");
-    if (V > 1 && (!st->cfg_w || !st->ws_hc)) return fail_msg("syn_denoise_step: n_variants > 1 needs cfg_w and ws_hc");
+    if (V > 1 && (!st->cfg_w || (!st->ws_hc && !st->x_fragment_order))) return fail_msg("syn_denoise_step: n_variants > 1 needs cfg_w and ws_hc");
     if (!st->cond || !st->t_model || !st->x_t || !st->x_t_bf16 || !st->coef || !st->t_coef || !st->x_next ||
         !st->x_next_bf16 || !st->ws_h || !st->ws_xn || !st->ws_q || !st->ws_k || !st->ws_vt || !st->ws_o || !st->ws_hid)
         return fail_msg("syn_denoise_step: null state/workspace pointer");
@@ -2172,7 +2182,7 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     if (st->x_fragment_order || (st->reserved & 7) == 5) {
         // large single-variant batches: one wave per sequence, weights streamed once per 128 rows (syn_seq.inc)
         if (!st->x_fragment_order) return fail_msg("syn_denoise_step: the wave-per-sequence kernel needs the latent in fragment order (x_fragment_order = 1)");
-        if (V != 1) return fail_msg("syn_denoise_step: fragment-order latents are single-variant only (guided batches run token-major)");
+        if (V > 4) return fail_msg("syn_denoise_step: fragment-order latents take at most 4 variants per clip (a clip's variants are the waves of one workgroup)");
         if (!md->tape || !md->tape_bias) return fail_msg("syn_denoise_step: syn_model.tape is not set");
         if (md->tape_chunks * seq::kChunkFrags != 36096) return fail_msg("syn_denoise_step: syn_model.tape_chunks must count 16-fragment chunks of the 36096-fragment tape (2256)");
         seq::QArgs q;
@@ -2181,11 +2191,11 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
         q.te = md->te; q.rcos = md->rot_cos; q.rsin = md->rot_sin; q.cond = st->cond; q.t_model = st->t_model;
         q.xt = st->x_t; q.xb = (const uint4*)st->x_t_bf16; q.noise = st->noise; q.rng = (const unsigned long long*)st->rng;
         q.coef = st->coef; q.t_coef = st->t_coef; q.xn = st->x_next; q.xnb = (uint4*)st->x_next_bf16; q.x0 = st->pred_x0;
-        q.R = B; q.dbg = g_dbg_mlp;
+        q.R = B; q.V = V; q.cfg_w = st->cfg_w; q.dbg = g_dbg_mlp;
         // The persistent step loop pays when all workgroups are resident at once (one per CU: <= 1024 clips on 256 CUs).  With
         // several rounds of workgroups a round would run ALL its steps before the next one starts, and the rounds' ragged ends
         // add up (measured: -1.7 % at 2048 clips, -2.2 % at 4096): launch the steps one by one there.
-        if (n_steps > 1 && (B + 3) / 4 > device_cus()) {
+        if (n_steps > 1 && seq_grid(B, V) > device_cus()) {
             if (st->noise) return fail_msg("syn_denoise_steps: injected noise is per step - run such steps one by one");
             syn_step one = *st;
             for (int j = 0; j < n_steps; ++j) {

@@ -39,10 +39,8 @@ def h3d():
 @pytest.fixture(params=[4, 3, 5], ids=["whole-step-kernel", "small-batch-kernel", "wave-per-sequence-kernel"])
 def kernel(request, beatx, h3d):
     """Pin one of the step kernels (syn_step.reserved: 4 = token-resident whole-step kernel, 3 = persistent
-    feature-split small-batch kernel, 5 = wave-per-sequence kernel with the latent in fragment order);
+    feature-split small-batch kernel, 5 = wave-per-sequence kernel with the latent in fragment order - guided batches: the variants of a clip are the waves of one workgroup);
     layer_mode 0 = the library's own choice by batch size."""
-    if request.param == 5 and "guidance" in request.node.name:
-        pytest.skip("guided batches (several variants per clip) run on the token-major kernels")
     beatx.layer_mode = h3d.layer_mode = request.param
     yield request.param
     beatx.layer_mode = h3d.layer_mode = 0

@@ -157,3 +157,57 @@ def test_persistent_multi_step_launch_equals_single_steps_bitwise(beatx, noisy):
         outs.append((sb.read(sb.x).cpu(), sb.xb.clone().cpu()))
     assert torch.isfinite(outs[0][0]).all()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("V,B", [(2, 5), (3, 3), (4, 2)])
+def test_guided_batches_on_the_wave_per_sequence_kernel(V, B):
+    """The V variants of a clip are the waves of one workgroup (two clips per workgroup at V = 2: B = 5 leaves a ragged one) and
+    meet in the output stage through LDS.  One noisy guided step against the token-resident kernel (which combines the
+    variants' residual streams BEFORE the output projection: same value up to the bf16 rounding of the combined stream),
+    the fp64 recombination of per-variant evaluations, and a 6-step persistent launch against the same steps one by one."""
+    from syntalker_amd import engine
+    from syntalker_amd.process import create_gaussian_diffusion
+    m = _model("h3d")
+    pm = m.packed()
+    coef = engine.posterior_coefs(create_gaussian_diffusion().tables(), DEV)
+    g = torch.Generator().manual_seed(5)
+    cond = torch.randn(V * B * 32, 512, generator=g).to(DEV) * 0.5
+    w = torch.tensor([[2.5, -1.5, 0.0, 0.0][:V], [1.0, 0.5, -0.5, 0.0][:V], [0.25, 0.25, 0.25, 0.25][:V]])
+    w[2, 0] += 1.0 - w[2].sum(); w[1, 0] += 1.0 - w[1].sum()          # every row sums to 1, as every guidance formula does
+    xT = synth.synth_latent(B, seed=61).to(DEV)
+    tm = (torch.arange(V * B) % B * 97 + 300).int().to(DEV)             # a clip's variants share its timestep
+
+    def run(mode, steps=1, replays=1, want_x0=False):
+        sb = engine.StepBuffers(B, V, DEV, want_x0=want_x0, layer_mode=mode)
+        sb.cond.copy_(cond); sb.cfg_w.copy_(w.to(DEV)); sb.set_rng(11, 4)
+        if steps == 1 and replays == 1:
+            sb.load_x(xT); sb.t_model.copy_(tm); sb.t_coef.copy_(tm[:B])
+            engine.run_step(pm, sb, coef, True, fused_rng=True)
+        else:
+            gr = engine.StepGraph(pm, sb, coef, True, fused_rng=True, scheduled=True, steps=steps)
+            sb.load_x(xT)
+            ts = [500 - 41 * i for i in range(steps * replays)]
+            gr.set_schedule(ts, ts)
+            for _ in range(replays):
+                gr.replay()
+        return sb.read(sb.x).cpu(), (sb.read(sb.x0).cpu() if want_x0 else None), sb
+
+    x5, x05, sb5 = run(5, want_x0=True)
+    assert sb5.fragment
+    x4, x04, _ = run(4, want_x0=True)
+    e = rel_l2(x05, x04)
+    print(f"guided V={V} B={B}: x0_hat k_seq vs k_stack rel-L2 {e:.3e}")
+    assert e < 1.5e-2 and rel_l2(x5, x4) < 1.5e-2
+    # per-variant evaluations (V = 1 batches of the same kernel), recombined in fp64
+    acc = torch.zeros(B, 1536, 1, 32, dtype=torch.float64)
+    for v in range(V):
+        sb = engine.StepBuffers(B, 1, DEV, layer_mode=5)
+        sb.cond.copy_(cond[v * B * 32:(v + 1) * B * 32]); sb.load_x(xT); sb.t_model.copy_(tm[:B]); sb.t_coef.zero_()
+        engine.run_step(pm, sb, engine.identity_coefs(DEV), False)
+        xv = sb.read(sb.x).cpu().double()
+        for c in range(3):
+            acc[:, 512 * c:512 * (c + 1)] += float(w[c, v]) * xv[:, 512 * c:512 * (c + 1)]
+    assert rel_l2(x05.double(), acc) < 1e-5
+    a, _, _ = run(5, steps=1, replays=6)
+    b, _, _ = run(5, steps=6, replays=1)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
