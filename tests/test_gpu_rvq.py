@@ -198,3 +198,21 @@ def test_rvqvae_round_trip_properties_at_batch_size():
     qf, idx2, _, _ = m._quantize(lat)
     assert torch.equal(idx2, idx)
     assert rel_l2(codes.sum(0).permute(0, 2, 1), qf) < 1e-6
+
+
+def test_quantiser_on_the_fp32_matrix_pipe_keeps_the_reference_indices():
+    """More than 1024 rows run the 16-row quantiser, whose distances come from v_mfma_f32_16x16x4_f32 (fp32 in, the same
+    fmaf chain over the 512 dims as the vector version); up to 1024 rows the 4-row vector version runs.  Indices are discrete
+    decisions: both must be the oracle's, bit for bit, and so must the rows they share."""
+    dim = 78
+    m = _model(dim)
+    sd = synth.synth_vq_state_dict(dim, seed=11)
+    rec = synth.synth_vq_rec_latent(sd, "upper", n=40, t=32)             # 1280 rows
+    rec = rec + 0.05 * torch.randn(rec.shape, generator=torch.Generator().manual_seed(3))      # off the codes: real decisions
+    qf16, idx16, c16, p16 = m._quantize(rec.to(DEV))
+    qf4, idx4, _, _ = m._quantize(rec[:32].to(DEV))                      # 1024 rows: vector version
+    want_q, want_idx, wc, wp = rr.residual_vq(sd, rec.permute(0, 2, 1))
+    assert torch.equal(idx16.cpu(), want_idx) and torch.equal(idx4.cpu(), want_idx[:32])
+    assert torch.equal(qf16[:32], qf4)
+    assert rel_l2(qf16.cpu(), want_q.permute(0, 2, 1)) < 1e-6
+    assert abs(float(c16) - float(wc)) < 1e-4 * float(wc) + 1e-9 and abs(float(p16) - float(wp)) < 1e-3 * float(wp)
