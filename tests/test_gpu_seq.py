@@ -211,3 +211,29 @@ def test_guided_batches_on_the_wave_per_sequence_kernel(V, B):
     a, _, _ = run(5, steps=1, replays=6)
     b, _, _ = run(5, steps=6, replays=1)
     assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_persistent_launch_at_the_bench_size_equals_single_steps_bitwise(beatx):
+    """1024 clips = one workgroup on every CU, ten steps per launch (what bench.py times): every clip must come out of the
+    persistent launch with the bits ten single-step launches give it; 1280 clips (more workgroups than CUs) take the
+    step-by-step route inside syn_denoise_steps and must agree as well."""
+    from syntalker_amd import engine
+    from syntalker_amd.process import create_gaussian_diffusion
+    pm = beatx.packed()
+    coef = engine.posterior_coefs(create_gaussian_diffusion().tables(), DEV)
+    for B in (1024, 1280):
+        g = torch.Generator(device=DEV).manual_seed(B)
+        cond = torch.randn(B * 32, 512, device=DEV, generator=g) * 0.5
+        xT = torch.randn(B, 1536, 1, 32, device=DEV, generator=g)
+        ts = [999 - 7 * i for i in range(10)]
+        outs = []
+        for steps in (1, 10):
+            sb = engine.StepBuffers(B, 1, DEV, layer_mode=5)
+            sb.cond.copy_(cond); sb.set_rng(2024, 17)
+            gr = engine.StepGraph(pm, sb, coef, True, fused_rng=True, scheduled=True, steps=steps)
+            sb.load_x(xT)
+            gr.set_schedule(ts, ts)
+            for _ in range(10 // steps):
+                gr.replay()
+            outs.append(sb.x.clone())
+        assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]), B
