@@ -472,11 +472,14 @@ def run_sample(args, rank, local, world, dev, dist):
         spl = 1                                     # steps per launch of the dominant kernel
         if frag:
             # one persistent launch per CH-step replay (syn_denoise_steps): flops and duration per LAUNCH cover CH steps
-            # (more workgroups than CUs: syn_denoise_steps launches the steps one by one, see step_impl)
+            # (more workgroups than CUs: a CH-step replay is several launches, one CU-filling slice of the batch each, see step_impl)
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            dom, spl = "k_seq", (CH if K >= CH and (B + 3) // 4 <= cus else 1)
-            d = {"ms": 0.0, "launches": 1, "flops": F_STEP * B * spl}
-            avg_s = (launch_ms if spl == CH else replay_ms) * 1e-3
+            slices = -(-((B + 3) // 4) // cus)
+            dom, spl = "k_seq", (CH if K >= CH else 1)
+            if spl == 1:
+                slices = 1                                    # (a single step is one launch whatever the batch)
+            d = {"ms": 0.0, "launches": slices, "flops": F_STEP * B * spl}
+            avg_s = (launch_ms if spl == CH else replay_ms) * 1e-3 / slices
         else:
             dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
             d = by_kernel[dom]

@@ -142,7 +142,7 @@ int syn_steps_advance(const int32_t* sched, int32_t* counter, int32_t* t_model, 
 /* n_steps consecutive steps of a hook-free stretch of p_sample_loop / ddim_sample_loop (gaussian_diffusion.py:714-739,
  * 905-931), in place (x_next = x_t): step j takes its timesteps from t_model + j * t_model_stride and
  * t_coef + j * t_coef_stride (the rows syn_steps_advance fills), its noise from rng (noise must be NULL when n_steps > 1).
- * Fragment-order latents: ONE persistent launch - every workgroup carries its four sequences through all the steps, so the
+ * Fragment-order latents: ONE persistent launch per CU-filling slice of the batch - every workgroup carries its four sequences through all the steps, so the
  * workgroups drift out of phase and the HBM traffic of the input / output stages of some overlaps the matrix work of the
  * others.  Token-major latents: the launches of syn_denoise_step, n_steps times. */
 int syn_denoise_steps(const syn_model* model, const syn_step* step, int32_t n_steps, int32_t t_model_stride,

@@ -1678,7 +1678,7 @@ int seq_grid(int n_clips, int n_variants) {
 int launch_seq(const seq::QArgs& a, hipStream_t s) {
     static bool once = false;
     if (!once) { allow_lds(seq::k_seq<false>, seq::kLds); allow_lds(seq::k_seq<true>, seq::kLds); once = true; }
-    const dim3 grid(seq_grid(a.R, a.V));
+    const dim3 grid(a.n_wg > 0 ? a.n_wg : seq_grid(a.R, a.V));
     if (a.V == 1) hipLaunchKernelGGL(seq::k_seq<false>, grid, dim3(seq::kThreads), seq::kLds, s, a);
     else hipLaunchKernelGGL(seq::k_seq<true>, grid, dim3(seq::kThreads), seq::kLds, s, a);
     hipError_t e = hipGetLastError();
@@ -2192,22 +2192,24 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
         q.xt = st->x_t; q.xb = (const uint4*)st->x_t_bf16; q.noise = st->noise; q.rng = (const unsigned long long*)st->rng;
         q.coef = st->coef; q.t_coef = st->t_coef; q.xn = st->x_next; q.xnb = (uint4*)st->x_next_bf16; q.x0 = st->pred_x0;
         q.R = B; q.V = V; q.cfg_w = st->cfg_w; q.dbg = g_dbg_mlp;
-        // The persistent step loop pays when all workgroups are resident at once (one per CU: <= 1024 clips on 256 CUs).  With
-        // several rounds of workgroups a round would run ALL its steps before the next one starts, and the rounds' ragged ends
-        // add up (measured: -1.7 % at 2048 clips, -2.2 % at 4096): launch the steps one by one there.
+        // The persistent step loop wants all its workgroups resident at once (one per CU).  A larger batch goes out as
+        // CU-filling slices, each carried through ALL the steps by its own launch (slices are independent: a sequence never
+        // leaves its wave); run as one launch, a round of workgroups would finish all its steps before the next one starts
+        // and the ragged ends of the rounds add up (measured: -1.7 % at 2048 clips, -2.2 % at 4096 against single steps).
+        if (n_steps > 1 && st->noise) return fail_msg("syn_denoise_steps: injected noise is per step - run such steps one by one");
         if (n_steps > 1 && seq_grid(B, V) > device_cus()) {
-            if (st->noise) return fail_msg("syn_denoise_steps: injected noise is per step - run such steps one by one");
-            syn_step one = *st;
-            for (int j = 0; j < n_steps; ++j) {
-                one.t_model = st->t_model + (size_t)j * tm_stride;
-                one.t_coef = st->t_coef + (size_t)j * tc_stride;
-                if ((rc = step_impl(md, &one, s, nullptr))) return rc;
+            q.n_steps = n_steps; q.tm_stride = tm_stride; q.tc_stride = tc_stride; q.dbg_step = g_seq_dbg_step; q.skew = 0;
+            const int total = seq_grid(B, V), cus = device_cus();
+            for (int w0 = 0; w0 < total; w0 += cus) {
+                q.wg0 = w0; q.n_wg = total - w0 < cus ? total - w0 : cus;
+                if ((rc = launch_seq(q, s))) return rc;
             }
-            return 0;
+            mark(ST_FC2);
+            hipError_t e2 = hipGetLastError();
+            return e2 == hipSuccess ? 0 : fail("syn_denoise_steps", e2);
         }
         q.n_steps = n_steps; q.tm_stride = tm_stride; q.tc_stride = tc_stride; q.dbg_step = g_seq_dbg_step;
         q.skew = n_steps > 1 && g_seq_skew > 0 ? (unsigned)g_seq_skew : 0u;      // (diagnostics: imposed start delays, see k_seq)
-        if (n_steps > 1 && st->noise) return fail_msg("syn_denoise_steps: injected noise is per step - run such steps one by one");
         if ((rc = launch_seq(q, s))) return rc;
         mark(ST_FC2);
         hipError_t e = hipGetLastError();

@@ -215,8 +215,8 @@ def test_guided_batches_on_the_wave_per_sequence_kernel(V, B):
 
 def test_persistent_launch_at_the_bench_size_equals_single_steps_bitwise(beatx):
     """1024 clips = one workgroup on every CU, ten steps per launch (what bench.py times): every clip must come out of the
-    persistent launch with the bits ten single-step launches give it; 1280 clips (more workgroups than CUs) take the
-    step-by-step route inside syn_denoise_steps and must agree as well."""
+    persistent launch with the bits ten single-step launches give it; 1280 clips (more workgroups than CUs) go out as
+    two CU-filling slices, each carried through the ten steps by its own launch, and must agree as well."""
     from syntalker_amd import engine
     from syntalker_amd.process import create_gaussian_diffusion
     pm = beatx.packed()
