@@ -239,7 +239,8 @@ def run_train(args, rank, local, world, dev, dist):
         with torch.cuda.stream(side):                           # DDP is built on the stream its iterations run on
             net = training.make_ddp(model, local, capturable=graph)
         torch.cuda.current_stream(dev).wait_stream(side)
-    opt = torch.optim.Adam(net.parameters(), lr=5e-5, betas=(0.5, 0.999), capturable=graph)
+    # (fused: the same update as the reference trainer's optim.Adam, one multi-tensor kernel instead of ~10 foreach launches)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-5, betas=(0.5, 0.999), capturable=graph, fused=True)
     if graph:
         g = training.GraphedTrainStep(net, diff, opt, x0, {"y": y}, warmup=11 if world > 1 else 3, stream=side)
         last = {}
