@@ -153,6 +153,15 @@ int syn_denoise_steps(const syn_model* model, const syn_step* step, int32_t n_st
  * 4 fc1 GEMM, 5 fc2 GEMM, 6 guidance combine, 7 output GEMM}.  Synchronises `stream`; not graph-capturable. */
 int syn_denoise_step_profile(const syn_model* model, const syn_step* step, void* stream, float* ms_out, int32_t* count_out);
 
+/* Training-mode forward of one Conv1d(k = 15) of the WavEncoder (models/utils/layer.py:144-184 conv1 / conv2 / downsample[0],
+ * called from models/denoiser.py:304-322 with BatchNorm on batch statistics, so nothing is folded): x fp32 channels-last
+ * [n_clips][l_in][cin] (what PyTorch calls an (N, C, 1, L) channels_last tensor), y fp32 [n_clips][l_out][cout],
+ * l_out = (l_in + 2 pad - 15) / stride + 1.  w_hi / w_lo: syn_pack_weight of the hi / lo bf16 halves of the GEMM matrix
+ * W'[cout][tap][cin] (taps zero-padded to a multiple of the stride); products are hi.hi + lo.hi + hi.lo on the bf16 matrix
+ * pipe, i.e. fp32-grade.  bias may be NULL.  Supported (cin, stride, cout): the encoder's own, see the error text. */
+int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
+                         const void* w_hi, const void* w_lo, const float* bias, int32_t cout, float* y, void* stream);
+
 /* ---- training path: fp32 forward / backward of the non-GEMM pieces of a transformer block ----
  * LayerNorm(512, eps 1e-5) of `rows` rows (models/timm_transformer/transformer.py:160,162,183,193); the backward
  * needs scratch of ceil(rows/64)*1024 floats and writes dgamma[512], dbeta[512] (deterministic two-stage sums). */

@@ -1661,6 +1661,17 @@ int launch_conv(const wav::CArgs& a, int n_clips, hipStream_t s) {
     return e == hipSuccess ? 0 : fail("k_conv launch", e);
 }
 
+template <int CINP, int KT, int WN, int WM, int RF>
+int launch_conv_train(const wav::TArgs& a, int n_clips, hipStream_t s) {
+    constexpr int MW = WM * RF * 16, lds = 2 * (MW + KT - 1) * (CINP * 2 + 16);
+    static_assert(lds <= 160 * 1024, "two bf16 planes of the input tile must fit the LDS");
+    static bool once = false;
+    if (!once) { allow_lds(wav::k_conv_train<CINP, KT, WN, WM, RF>, lds); once = true; }
+    hipLaunchKernelGGL((wav::k_conv_train<CINP, KT, WN, WM, RF>), dim3((a.L_out + MW - 1) / MW, n_clips), dim3(WN * WM * 64), lds, s, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv_train launch", e);
+}
+
 int launch_latency(const lat::LArgs& a, hipStream_t s) {
     static bool once = false;
     if (!once) { allow_lds(lat::k_lat, lat::kLds); once = true; }
@@ -2143,6 +2154,28 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, 
     if ((rc = launch_conv<256, 15, 4, 1, 4, wav::E_C2>(a, n_clips, s))) return rc;
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("syn_wav_encode", e);
+}
+
+int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
+                         const void* w_hi, const void* w_lo, const float* bias, int32_t cout, float* y, void* stream) {
+    if (!x || !w_hi || !w_lo || !y || n_clips <= 0 || l_in <= 0) return fail_msg("syn_conv1d_train_fwd: null pointer / empty batch");
+    if (stride < 1 || pad < 0 || pad % stride) return fail_msg("syn_conv1d_train_fwd: padding must be a multiple of the stride");
+    const int l_out = (l_in + 2 * pad - 15) / stride + 1;
+    if (l_out <= 0) return fail_msg("syn_conv1d_train_fwd: input shorter than the kernel");
+    wav::TArgs a;
+    a.X = x; a.x_clip_stride = (long)l_in * cin; a.x_elems = (long)l_in * cin; a.row0 = -pad / stride; a.L_out = l_out;
+    a.Whi = (const uint4*)w_hi; a.Wlo = (const uint4*)w_lo; a.bias = bias; a.Y = y; a.y_clip_stride = (long)l_out * cout;
+    hipStream_t s = (hipStream_t)stream;
+    const int cinp = stride * cin;
+    // (rows of stride * cin floats, ceil(15 / stride) taps; tiles as the eval-mode encoder picks them, halved where two planes
+    // of a 384-channel tile would not fit the LDS)
+    if (cinp == 64 && stride == 1 && cout == 64) return launch_conv_train<64, 15, 1, 4, 4>(a, n_clips, s);
+    if (cinp == 128 && stride == 1 && cout == 128) return launch_conv_train<128, 15, 2, 2, 4>(a, n_clips, s);
+    if (cinp == 256 && stride == 1 && cout == 256) return launch_conv_train<256, 15, 4, 1, 4>(a, n_clips, s);
+    if (cinp == 384 && stride == 6 && cout == 64) return launch_conv_train<384, 3, 1, 4, 1>(a, n_clips, s);
+    if (cinp == 384 && stride == 6 && cout == 128) return launch_conv_train<384, 3, 2, 2, 2>(a, n_clips, s);
+    if (cinp == 384 && stride == 3 && cout == 256) return launch_conv_train<384, 5, 4, 1, 4>(a, n_clips, s);
+    return fail_msg("syn_conv1d_train_fwd: not one of the WavEncoder's convolutions (cin x stride -> cout: 64x1->64, 128x1->128, 256x1->256, 64x6->64, 64x6->128, 128x3->256)");
 }
 
 // Stage classes reported by syn_denoise_step_profile (index into ms[] / count[]).

@@ -250,6 +250,59 @@ class ConvBf16Fn(torch.autograd.Function):
         return gx, gw, None, None
 
 
+class ConvSplitFn(torch.autograd.Function):
+    """(N, C, 1, L) channels_last convolution of the audio encoder, forward on the hand-written implicit-GEMM kernel with
+    operands split into bf16 hi + lo halves (`syn_conv1d_train_fwd`: three MFMAs per product, fp32-grade - the plain bf16
+    forward moves the gradients of the first blocks by 14 %); data and weight gradients on the fp32 kernels of MIOpen.
+    Covers the encoder's Conv1d(k = 15) layers from block 0's conv2 on (block 0's conv1 / shortcut have 1-2 input channels and
+    1 % of the FLOPs)."""
+
+    SUPPORTED = {(64, 1, 64), (128, 1, 128), (256, 1, 256), (64, 6, 64), (64, 6, 128), (128, 3, 256)}
+
+    @staticmethod
+    def run(x, w, stride, pad):
+        """y = conv(x, w) for x (N, Cin, 1, L) channels_last fp32, w (Cout, Cin, 1, 15)."""
+        from .conditioning import wav_gemm_weight
+        n, cin, _, l_in = x.shape
+        cout = w.shape[0]
+        xc = x.contiguous(memory_format=torch.channels_last)                # physically [n][l][cin]
+        wg = wav_gemm_weight(w.detach().reshape(cout, cin, 15).float(), stride)
+        hi = wg.to(torch.bfloat16).float()
+        whi, wlo = engine.pack_weight(hi), engine.pack_weight(wg - hi)
+        l_out = (l_in + 2 * pad - 15) // stride + 1
+        y = torch.empty(n, cout, 1, l_out, device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _lib.check(_lib.load().syn_conv1d_train_fwd(xc.data_ptr(), n, l_in, cin, stride, pad, whi.data_ptr(), wlo.data_ptr(), None, cout,
+                                                    y.data_ptr(), _lib.current_stream(x.device)), "syn_conv1d_train_fwd")
+        return xc, y
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        xc, y = ConvSplitFn.run(x, w, stride, pad)
+        ctx.save_for_backward(xc, w)
+        ctx.geom = (stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.geom
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx = gw = None
+        args = ((1, stride), (0, pad), (1, 1), False, (0, 0), 1)
+        cout, cin = w.shape[0], w.shape[1]
+        if ctx.needs_input_grad[0]:
+            if stride == 1 and pad == 7 and (cout, 1, cin) in ConvSplitFn.SUPPORTED:
+                # the data gradient of a stride-1 'same' convolution is the same convolution with the taps reversed and the
+                # channel roles swapped: the same kernel, fp32-grade like the forward
+                gx = ConvSplitFn.run(gy, w.detach().flip(-1).transpose(0, 1), 1, 7)[1]
+            else:
+                gx = torch.ops.aten.convolution_backward(gy, x, w, None, *args, (True, False, False))[0]
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gy, x, w, None, *args, (False, True, False))[1]
+        return gx, gw, None, None
+
+
+WAV_SPLIT_FWD = True      # the encoder's forward convolutions on syn_conv1d_train_fwd (where the layer is one it covers)
 WAV_BF16_FROM = 0         # first encoder block that uses it
 WAV_BF16 = False          # False | 1: bf16 forward only (data and weight gradients fp32) | 2: bf16 forward + data gradient.
                           # 2 measured 15.1 -> 12.3 ms per step at B = 32, but the gradients of the first encoder blocks
@@ -259,7 +312,12 @@ WAV_BF16 = False          # False | 1: bf16 forward only (data and weight gradie
 
 def _conv_bn(conv, bn, x, training, bf16=False):
     """Conv1d + BatchNorm1d of the module (batch statistics in training, running statistics in eval) on (N, C, 1, L)."""
-    if bf16:
+    if (WAV_SPLIT_FWD and not bf16 and x.is_cuda and x.dim() == 4 and conv.kernel_size[0] == 15 and
+            (conv.in_channels, conv.stride[0], conv.out_channels) in ConvSplitFn.SUPPORTED and conv.padding[0] % conv.stride[0] == 0):
+        y = ConvSplitFn.apply(x, conv.weight.unsqueeze(2), conv.stride[0], conv.padding[0])
+        if conv.bias is not None:
+            y = y + conv.bias.view(1, -1, 1, 1)
+    elif bf16:
         y = ConvBf16Fn.apply(x, conv.weight.unsqueeze(2), conv.stride[0], conv.padding[0])
         if conv.bias is not None:
             y = y + conv.bias.view(1, -1, 1, 1)

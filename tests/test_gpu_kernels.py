@@ -302,3 +302,27 @@ def test_conditioning_kernels_vs_oracle(variant):
         e = rel_l2(full, want)
         print(f"{variant} {flags}: whole per-clip conditioning rel-L2 {e:.2e}")
         assert e < 6e-3
+
+
+@pytest.mark.parametrize("cin,stride,cout,pad,L", [(64, 1, 64, 7, 300), (128, 1, 128, 7, 133), (256, 1, 256, 7, 64), (64, 6, 64, 0, 1001),
+                                                  (64, 6, 128, 0, 379), (128, 3, 256, 0, 200)])
+def test_training_conv_forward_on_split_operands_vs_fp32(cin, stride, cout, pad, L):
+    """syn_conv1d_train_fwd (the WavEncoder's Conv1d(k = 15) layers in training mode: hi + lo bf16 operands, three MFMAs per
+    product) against PyTorch's fp32 convolution in float64: fp32-grade (a plain bf16 forward is at 3e-3), on ragged lengths;
+    and its autograd wrapper returns fp32 gradients for both inputs."""
+    from syntalker_amd import training
+    g = torch.Generator().manual_seed(cin + stride)
+    DEV = "cuda"
+    x = torch.randn(3, cin, 1, L, generator=g).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(cout, cin, 1, 15, generator=g) / (cin * 15) ** 0.5).to(DEV).requires_grad_(True)
+    y = training.ConvSplitFn.apply(x, w, stride, pad)
+    want = torch.nn.functional.conv2d(x.detach().double(), w.detach().double(), None, stride=(1, stride), padding=(0, pad))
+    assert y.shape == want.shape
+    e = rel_l2(y.detach().double().cpu(), want.cpu())
+    print(f"conv {cin}x{stride}->{cout}: rel-L2 vs float64 {e:.2e}")
+    assert e < 2e-5
+    gy = torch.randn(y.shape, generator=g).to(DEV)
+    y.backward(gy)
+    x2, w2 = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    torch.nn.functional.conv2d(x2, w2, None, stride=(1, stride), padding=(0, pad)).backward(gy)
+    assert rel_l2(x.grad.cpu(), x2.grad.cpu()) < 1e-5 and rel_l2(w.grad.cpu(), w2.grad.cpu()) < 1e-5
