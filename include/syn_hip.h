@@ -159,6 +159,12 @@ int syn_denoise_step_profile(const syn_model* model, const syn_step* step, void*
  * l_out = (l_in + 2 pad - 15) / stride + 1.  w_hi / w_lo: syn_pack_weight of the hi / lo bf16 halves of the GEMM matrix
  * W'[cout][tap][cin] (taps zero-padded to a multiple of the stride); products are hi.hi + lo.hi + hi.lo on the bf16 matrix
  * pipe, i.e. fp32-grade.  bias may be NULL.  Supported (cin, stride, cout): the encoder's own, see the error text. */
+/* The two fragment sets syn_conv1d_train_fwd takes, from the module's weight w [cout][cin][15] (fp32) in one launch; each
+ * output holds N * ceil(15 / stride) * stride * C * 2 bytes.  transposed = 1 (stride 1 only): the matrix of the DATA GRADIENT
+ * of that convolution (taps reversed, channel roles swapped: N = cin, C = cout) - the gradient then is
+ * syn_conv1d_train_fwd(dy, ..., cin = cout, stride 1, pad 7, ..., cout = cin). */
+int syn_conv1d_pack_split(const float* w, int32_t cout, int32_t cin, int32_t stride, int32_t transposed, void* out_hi, void* out_lo,
+                          void* stream);
 int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
                          const void* w_hi, const void* w_lo, const float* bias, int32_t cout, float* y, void* stream);
 

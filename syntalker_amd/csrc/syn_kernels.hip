@@ -1451,6 +1451,29 @@ __global__ void k_pack_t(const T* __restrict__ S, int N, int K, uint4* __restric
     out[idx] = __builtin_bit_cast(uint4, r);
 }
 
+// Conv1d(k = 15) weight w[co][ci][15] (fp32) -> the two packed fragment sets (hi, lo bf16 halves) of the training-mode
+// GEMM matrix W'[n][tap * cin + c] (taps zero-padded to KT * stride): one launch instead of ten tensor operations per use.
+// transposed = 1: the matrix of the data gradient of a stride-1 convolution, n = ci, c = co, tap reversed.
+__global__ void k_conv_pack_split(const float* __restrict__ w, int cout, int cin, int kt_stride, int transposed,
+                                  uint4* __restrict__ out_hi, uint4* __restrict__ out_lo) {
+    const int N = transposed ? cin : cout, C = transposed ? cout : cin, K = kt_stride * C, KS = K / 32;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (N / 16) * KS * 64) return;
+    const int lane = idx & 63, f = idx >> 6, ks = f % KS, nf = f / KS;
+    const int n = 16 * nf + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
+    bf16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e, tap = k / C, c = k - tap * C;
+        float v = 0.f;
+        if (tap < 15) v = transposed ? w[((size_t)c * cin + n) * 15 + (14 - tap)] : w[((size_t)n * cin + c) * 15 + tap];
+        h[e] = (__bf16)v;
+        l[e] = (__bf16)(v - (float)h[e]);
+    }
+    out_hi[idx] = __builtin_bit_cast(uint4, h);
+    out_lo[idx] = __builtin_bit_cast(uint4, l);
+}
+
 // (B,1536,32) <-> (B,32,1536): 64 channels x 32 frames per block through a padded LDS tile.
 __global__ __launch_bounds__(256) void k_to_token_major(const float* __restrict__ x, float* __restrict__ of,
                                                          __bf16* __restrict__ ob) {
@@ -2154,6 +2177,20 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, 
     if ((rc = launch_conv<256, 15, 4, 1, 4, wav::E_C2>(a, n_clips, s))) return rc;
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("syn_wav_encode", e);
+}
+
+int syn_conv1d_pack_split(const float* w, int32_t cout, int32_t cin, int32_t stride, int32_t transposed, void* out_hi, void* out_lo,
+                          void* stream) {
+    if (!w || !out_hi || !out_lo || cout % 16 || cin % 16 || stride < 1) return fail_msg("syn_conv1d_pack_split: bad arguments");
+    if (transposed && stride != 1) return fail_msg("syn_conv1d_pack_split: the transposed (data-gradient) form is for stride-1 convolutions");
+    const int kts = (15 + stride - 1) / stride * stride;
+    const int N = transposed ? cin : cout, C = transposed ? cout : cin;
+    if ((kts * C) % 32) return fail_msg("syn_conv1d_pack_split: taps x channels must be a multiple of 32");
+    const int total = (N / 16) * (kts * C / 32) * 64;
+    hipLaunchKernelGGL(k_conv_pack_split, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, cout, cin, kts, transposed,
+                       (uint4*)out_hi, (uint4*)out_lo);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv_pack_split launch", e);
 }
 
 int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,

@@ -260,18 +260,24 @@ class ConvSplitFn(torch.autograd.Function):
     SUPPORTED = {(64, 1, 64), (128, 1, 128), (256, 1, 256), (64, 6, 64), (64, 6, 128), (128, 3, 256)}
 
     @staticmethod
-    def run(x, w, stride, pad):
-        """y = conv(x, w) for x (N, Cin, 1, L) channels_last fp32, w (Cout, Cin, 1, 15)."""
-        from .conditioning import wav_gemm_weight
-        n, cin, _, l_in = x.shape
-        cout = w.shape[0]
+    def run(x, w, stride, pad, transposed=False):
+        """y = conv(x, w) for x (N, Cin, 1, L) channels_last fp32 and the module's weight w (Cout, Cin, 1, 15);
+        transposed: y = the data gradient of that (stride-1, padding-7) convolution for x = dy (N, Cout, 1, L)."""
+        lib = _lib.load()
+        n, cx, _, l_in = x.shape
+        wc = w.detach().float().contiguous()
+        co_w, ci_w = wc.shape[0], wc.shape[1]
+        cin, cout = (co_w, ci_w) if transposed else (ci_w, co_w)
+        assert cx == cin, (x.shape, w.shape, transposed)
         xc = x.contiguous(memory_format=torch.channels_last)                # physically [n][l][cin]
-        wg = wav_gemm_weight(w.detach().reshape(cout, cin, 15).float(), stride)
-        hi = wg.to(torch.bfloat16).float()
-        whi, wlo = engine.pack_weight(hi), engine.pack_weight(wg - hi)
+        kts = -(-15 // stride) * stride
+        whi = torch.empty(cout * kts * cin * 2, dtype=torch.uint8, device=x.device)
+        wlo = torch.empty_like(whi)
+        _lib.check(lib.syn_conv1d_pack_split(wc.data_ptr(), co_w, ci_w, stride, int(transposed), whi.data_ptr(), wlo.data_ptr(),
+                                             _lib.current_stream(x.device)), "syn_conv1d_pack_split")
         l_out = (l_in + 2 * pad - 15) // stride + 1
         y = torch.empty(n, cout, 1, l_out, device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
-        _lib.check(_lib.load().syn_conv1d_train_fwd(xc.data_ptr(), n, l_in, cin, stride, pad, whi.data_ptr(), wlo.data_ptr(), None, cout,
+        _lib.check(lib.syn_conv1d_train_fwd(xc.data_ptr(), n, l_in, cin, stride, pad, whi.data_ptr(), wlo.data_ptr(), None, cout,
                                                     y.data_ptr(), _lib.current_stream(x.device)), "syn_conv1d_train_fwd")
         return xc, y
 
@@ -294,7 +300,7 @@ class ConvSplitFn(torch.autograd.Function):
             if stride == 1 and pad == 7 and (cout, 1, cin) in ConvSplitFn.SUPPORTED:
                 # the data gradient of a stride-1 'same' convolution is the same convolution with the taps reversed and the
                 # channel roles swapped: the same kernel, fp32-grade like the forward
-                gx = ConvSplitFn.run(gy, w.detach().flip(-1).transpose(0, 1), 1, 7)[1]
+                gx = ConvSplitFn.run(gy, w, 1, 7, transposed=True)[1]
             else:
                 gx = torch.ops.aten.convolution_backward(gy, x, w, None, *args, (True, False, False))[0]
         if ctx.needs_input_grad[1]:
