@@ -1695,6 +1695,15 @@ int launch_conv_train(const wav::TArgs& a, int n_clips, hipStream_t s) {
     return e == hipSuccess ? 0 : fail("k_conv_train launch", e);
 }
 
+template <int CO>
+int launch_wgrad(const wav::WArgs& a, hipStream_t s) {
+    static bool once = false;
+    if (!once) { allow_lds(wav::k_conv_wgrad<CO>, wav::wgrad_lds<CO>()); once = true; }
+    hipLaunchKernelGGL(wav::k_conv_wgrad<CO>, dim3(a.cin / 16, a.shares), dim3(512), wav::wgrad_lds<CO>(), s, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv_wgrad launch", e);
+}
+
 int launch_latency(const lat::LArgs& a, hipStream_t s) {
     static bool once = false;
     if (!once) { allow_lds(lat::k_lat, lat::kLds); once = true; }
@@ -2177,6 +2186,33 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, 
     if ((rc = launch_conv<256, 15, 4, 1, 4, wav::E_C2>(a, n_clips, s))) return rc;
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("syn_wav_encode", e);
+}
+
+int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l, int32_t cin) {
+    const int chunks = n_clips * ((l + wav::kWgP - 1) / wav::kWgP), blocks = cin / 16;
+    int shares = (2 * device_cus() + blocks - 1) / blocks;          // ~2 workgroups per CU in total
+    if (shares > chunks) shares = chunks;
+    return shares < 1 ? 1 : shares;
+}
+
+int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l, int32_t cin, int32_t cout, float* ws, float* dw,
+                           void* stream) {
+    if (!x || !dy || !ws || !dw || n_clips <= 0 || l <= 0 || cin % 16) return fail_msg("syn_conv1d_train_wgrad: bad arguments");
+    wav::WArgs a;
+    a.GY = dy; a.gy_clip_stride = (long)l * cout; a.L_out = l; a.X = x; a.x_clip_stride = (long)l * cin; a.x_elems = (long)l * cin;
+    a.cin = cin; a.n_clips = n_clips; a.chunks_per_clip = (l + wav::kWgP - 1) / wav::kWgP;
+    a.shares = syn_conv1d_wgrad_shares(n_clips, l, cin); a.part = ws;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (cout == 64) rc = launch_wgrad<64>(a, s);
+    else if (cout == 128) rc = launch_wgrad<128>(a, s);
+    else if (cout == 256) rc = launch_wgrad<256>(a, s);
+    else return fail_msg("syn_conv1d_train_wgrad: cout must be 64, 128 or 256");
+    if (rc) return rc;
+    const int total = cout * 15 * cin;
+    hipLaunchKernelGGL(wav::k_conv_wgrad_sum, dim3((total + 255) / 256), dim3(256), 0, s, (const float*)ws, a.shares, cout, cin, dw);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv_wgrad_sum launch", e);
 }
 
 int syn_conv1d_pack_split(const float* w, int32_t cout, int32_t cin, int32_t stride, int32_t transposed, void* out_hi, void* out_lo,

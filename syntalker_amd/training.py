@@ -304,10 +304,21 @@ class ConvSplitFn(torch.autograd.Function):
             else:
                 gx = torch.ops.aten.convolution_backward(gy, x, w, None, *args, (True, False, False))[0]
         if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(gy, x, w, None, *args, (False, True, False))[1]
+            if stride == 1 and pad == 7 and cout in (64, 128, 256) and cin % 16 == 0 and WAV_SPLIT_WGRAD:
+                # contraction over positions of two channels-last tensors: transposed through LDS inside the kernel
+                lib = _lib.load()
+                n, _, _, l = x.shape
+                ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l, cin) * cout * 15 * cin, device=x.device, dtype=torch.float32)
+                gw = torch.empty(cout, cin, 1, 15, device=x.device, dtype=torch.float32)
+                _lib.check(lib.syn_conv1d_train_wgrad(x.data_ptr(), gy.data_ptr(), n, l, cin, cout, ws.data_ptr(), gw.data_ptr(),
+                                                      _lib.current_stream(x.device)), "syn_conv1d_train_wgrad")
+                gw = gw.to(w.dtype)
+            else:
+                gw = torch.ops.aten.convolution_backward(gy, x, w, None, *args, (False, True, False))[1]
         return gx, gw, None, None
 
 
+WAV_SPLIT_WGRAD = True    # weight gradients of the stride-1 convolutions on syn_conv1d_train_wgrad
 WAV_SPLIT_FWD = True      # the encoder's forward convolutions on syn_conv1d_train_fwd (where the layer is one it covers)
 WAV_BF16_FROM = 0         # first encoder block that uses it
 WAV_BF16 = False          # False | 1: bf16 forward only (data and weight gradients fp32) | 2: bf16 forward + data gradient.
