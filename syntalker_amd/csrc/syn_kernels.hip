@@ -1566,7 +1566,10 @@ int launch_gemm(const GArgs& a, int mt, int chunks, hipStream_t s) {
         case 128: hipLaunchKernelGGL((k_gemm<128, EPI>), grid, block, 2 * 128 * 128, s, a); break;
         case 64:  hipLaunchKernelGGL((k_gemm<64, EPI>), grid, block, 2 * 64 * 128, s, a); break;
         case 32:  hipLaunchKernelGGL((k_gemm<32, EPI>), grid, block, 2 * 32 * 128 + 1024, s, a); break;
-        default:  return fail_msg("gemm: m_tile must be 32, 64 or 128");
+        case 16:
+            if constexpr (EPI == EPI_PLAIN) { hipLaunchKernelGGL((k_gemm<16, EPI>), grid, block, 2 * 32 * 128 + 1024, s, a); break; }
+            return fail_msg("gemm: 16-row tiles exist for the plain epilogue only");
+        default:  return fail_msg("gemm: m_tile must be 16, 32, 64 or 128");
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_gemm launch", e);
@@ -2035,7 +2038,9 @@ int syn_linear(const void* x_bf16, const void* w_packed, const float* bias, int3
     memset(&a, 0, sizeof(a));
     a.X = (const __bf16*)x_bf16; a.ldx = k; a.x_rows = m_rows; a.W = (const uint4*)w_packed; a.K = k; a.M = m_rows;
     a.bias = bias; a.Yf = y; a.ldyf = n;
-    return launch_gemm<EPI_PLAIN>(a, pick_tile(m_rows), n / kNT, (hipStream_t)stream);
+    // the training step's GEMMs have 512 .. 1536 rows: 16-row tiles give 32 .. 96 x (n / 512) workgroups, twice what 32-row ones do
+    const int mt = m_rows <= 2048 ? 16 : pick_tile(m_rows);
+    return launch_gemm<EPI_PLAIN>(a, mt, n / kNT, (hipStream_t)stream);
 }
 
 int syn_test_handoff(uint32_t* sync_320_zeroed, uint32_t* buf_8x4096, const float* stream, int64_t stream_n, uint32_t* stale_9_zeroed,
@@ -2190,7 +2195,7 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, 
 
 int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l, int32_t cin) {
     const int chunks = n_clips * ((l + wav::kWgP - 1) / wav::kWgP), blocks = cin / 16;
-    int shares = (2 * device_cus() + blocks - 1) / blocks;          // ~2 workgroups per CU in total
+    int shares = (device_cus() + blocks - 1) / blocks;              // one workgroup per CU in total (the partial sums are read back once per share)
     if (shares > chunks) shares = chunks;
     return shares < 1 ? 1 : shares;
 }
