@@ -185,6 +185,10 @@ int syn_ln_bwd(const float* dy, const float* x, const float* gamma, const float*
 /* nn.GELU() (exact erf form, transformer.py:117-151), n % 4 == 0 elements. */
 int syn_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* Backward of an nn.Linear, the operand preparation in one pass over dy [m_rows][n] fp32: its bf16 copy (data-gradient GEMM),
+ * the bf16 transpose [n][m_rows] (weight-gradient GEMM) and colsum_part [m_rows / 64][n] = column sums of every 64-row block
+ * (NULL to skip; the bias gradient is their sum over the first index). */
+int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, void* dy_bf16, void* dy_bf16_t, float* colsum_part, void* stream);
 /* Attention core (transformer.py:83-104, 4 heads x 128, 32 tokens, no mask, no dropout) on the packed output of the
  * qkv Linear: qkv [n_seq][32][3][4][128] -> o [n_seq][32][512]; backward recomputes the probabilities. */
 int syn_attn_fwd(const float* qkv, float* o, int32_t n_seq, void* stream);

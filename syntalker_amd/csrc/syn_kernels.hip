@@ -2092,6 +2092,15 @@ int syn_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
     return e == hipSuccess ? 0 : fail("k_gelu_fwd launch", e);
 }
 
+int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, void* dy_bf16, void* dy_bf16_t, float* colsum_part, void* stream) {
+    if (!dy || !dy_bf16 || !dy_bf16_t || m_rows <= 0 || n <= 0 || m_rows % 64 || n % 64)
+        return fail_msg("syn_linear_bwd_prep: need m_rows % 64 == 0, n % 64 == 0 and non-null pointers");
+    hipLaunchKernelGGL(trn::k_linear_bwd_prep, dim3(n / 64, m_rows / 64), dim3(256), 0, (hipStream_t)stream, dy, m_rows, n, (__bf16*)dy_bf16,
+                       (__bf16*)dy_bf16_t, colsum_part);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_linear_bwd_prep launch", e);
+}
+
 int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
     if (!x || !dy || !dx || n <= 0 || n % 4) return fail_msg("syn_gelu_bwd: n must be a positive multiple of 4");
     hipLaunchKernelGGL(trn::k_gelu_bwd, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (size_t)(n / 4));

@@ -92,8 +92,20 @@ class HipLinearFn(torch.autograd.Function):
         N, K = w.shape
         M = xb.shape[0]
         dy2 = dy.reshape(-1, N)
-        dyb = dy2.to(torch.bfloat16).contiguous()
-        dx = dw = db = None
+        dx = dw = db = dybt = None
+        if LINEAR_BWD_PREP and M % 64 == 0 and N % 64 == 0 and dy2.dtype is torch.float32 and dy2.is_cuda:
+            # one pass over dy: bf16 copy, bf16 transpose (weight gradient) and the bias gradient
+            dy2 = dy2.contiguous()
+            dyb = torch.empty(M, N, dtype=torch.bfloat16, device=dy.device)
+            dybt = torch.empty(N, M, dtype=torch.bfloat16, device=dy.device)
+            want_db = ctx.has_bias and ctx.needs_input_grad[2] and LINEAR_BWD_PREP > 1
+            part = torch.empty(M // 64, N, dtype=torch.float32, device=dy.device) if want_db else None
+            _lib.check(_lib.load().syn_linear_bwd_prep(dy2.data_ptr(), M, N, dyb.data_ptr(), dybt.data_ptr(), _lib.ptr(part),
+                                                       _lib.current_stream(dy.device)), "syn_linear_bwd_prep")
+            if want_db:
+                db = part.sum(0)
+        else:
+            dyb = dy2.to(torch.bfloat16).contiguous()
         if ctx.needs_input_grad[0]:
             if K % 512 == 0 and N % 128 == 0 and w.dtype is torch.float32 and w.is_contiguous():
                 dx = _gemm_packed(dyb, _pack_t(w, K, N), K, N).reshape(ctx.in_shape)       # dy . W, W^T packed in place
@@ -101,12 +113,18 @@ class HipLinearFn(torch.autograd.Function):
                 dx = hip_matmul_nt(dyb, w.t()).reshape(ctx.in_shape)
         if ctx.needs_input_grad[1]:
             if K % 512 == 0 and M % 128 == 0 and xb.is_contiguous():
-                dw = _gemm_packed(dyb.t().contiguous(), _pack_t(xb, K, M), K, M).to(w.dtype)   # dy^T . x, x^T packed in place
+                dw = _gemm_packed(dybt if dybt is not None else dyb.t().contiguous(), _pack_t(xb, K, M), K, M).to(w.dtype)   # dy^T . x, x^T packed in place
             else:
                 dw = hip_matmul_nt(dyb.t(), xb.t()).to(w.dtype)                    # contraction over tokens
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
             db = dy2.sum(0)
         return dx, dw, db
+
+
+import os as _os
+LINEAR_BWD_PREP = int(_os.environ.get("SYN_LINEAR_BWD_PREP", "1"))    # 0: PyTorch cast / transpose / sum; 1: fused cast + transpose (syn_linear_bwd_prep);
+                                                                      # 2: + bias-gradient partial sums from the same pass - correct (eager tests), but the captured
+                                                                      # training graph then dies in the HIP runtime with the memory-aperture violation of DESIGN.md 7
 
 
 def lin(x, module: nn.Linear):
