@@ -2092,6 +2092,40 @@ int syn_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
     return e == hipSuccess ? 0 : fail("k_gelu_fwd launch", e);
 }
 
+int32_t syn_bn_chunks(int64_t rows) { return (int32_t)((rows + trn::kBnRows - 1) / trn::kBnRows); }
+
+int syn_bn_act_fwd(const float* y, const float* shortcut, int64_t rows, int32_t channels, const float* gamma, const float* beta, float eps,
+                   float momentum, float* run_mean, float* run_var, const float* conv_bias, int32_t act, float* ws, float* stats, float* z,
+                   void* stream) {
+    if (!y || !gamma || !beta || !ws || !stats || !z || rows <= 0 || channels <= 0 || channels % 4 || 256 % (channels / 4) || channels > 1024)
+        return fail_msg("syn_bn_act_fwd: need channels in {4 .. 1024} with channels / 4 dividing 256, rows > 0, non-null pointers");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = syn_bn_chunks(rows);
+    hipLaunchKernelGGL(trn::k_bn_stats, dim3(chunks), dim3(256), 0, s, y, (long)rows, channels, ws);
+    hipLaunchKernelGGL(trn::k_bn_finalize, dim3(channels), dim3(256), 0, s, (const float*)ws, chunks, channels, (long)rows, eps, momentum,
+                       stats, run_mean, run_var, conv_bias);
+    const long n4 = rows * channels / 4;
+    hipLaunchKernelGGL(trn::k_bn_apply, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, y, shortcut, (const float*)stats, gamma, beta, channels, n4,
+                       act, z);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_bn_act_fwd", e);
+}
+
+int syn_bn_act_bwd(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, int64_t rows, int32_t channels,
+                   int32_t act, float* ws, float* dgamma_dbeta, float* dy, float* dshortcut, void* stream) {
+    if (!dz || !z || !y || !stats || !gamma || !ws || !dgamma_dbeta || !dy || rows <= 0 || channels % 4 || 256 % (channels / 4))
+        return fail_msg("syn_bn_act_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = syn_bn_chunks(rows);
+    hipLaunchKernelGGL(trn::k_bn_bwd_stats, dim3(chunks), dim3(256), 0, s, dz, z, y, stats, (long)rows, channels, act, ws);
+    hipLaunchKernelGGL(trn::k_bn_bwd_finalize, dim3(channels), dim3(256), 0, s, (const float*)ws, chunks, channels, dgamma_dbeta);
+    const long n4 = rows * channels / 4;
+    hipLaunchKernelGGL(trn::k_bn_bwd_apply, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dz, z, y, stats, gamma, (const float*)dgamma_dbeta,
+                       channels, n4, (long)rows, act, dy, dshortcut);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_bn_act_bwd", e);
+}
+
 int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, void* dy_bf16, void* dy_bf16_t, float* colsum_part, void* stream) {
     if (!dy || !dy_bf16 || !dy_bf16_t || m_rows <= 0 || n <= 0 || m_rows % 64 || n % 64)
         return fail_msg("syn_linear_bwd_prep: need m_rows % 64 == 0, n % 64 == 0 and non-null pointers");

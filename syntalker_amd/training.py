@@ -345,6 +345,69 @@ WAV_BF16 = False          # False | 1: bf16 forward only (data and weight gradie
                           # bf16 rounding ~1.5x per block (scripts/diag_train_grads.py)
 
 
+class BnActFn(torch.autograd.Function):
+    """act(BatchNorm1d(y) [+ shortcut]) on batch statistics for channels_last (N, C, 1, L) fp32 tensors - the tail of every
+    convolution of the encoder's BasicBlock (models/utils/layer.py:171-184) in training mode, as three launches forward and three
+    backward (`syn_bn_act_fwd` / `_bwd`) instead of BatchNorm + add + LeakyReLU passes.  ``conv_bias``: the bias of the convolution
+    that produced y, which the caller has NOT added (it only shifts the running mean; its gradient is exactly zero)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, conv_bias, shortcut, run_mean, run_var, momentum, eps, act):
+        lib = _lib.load()
+        n, c, _, l = y.shape
+        yc = y.contiguous(memory_format=torch.channels_last)
+        sc = None if shortcut is None else shortcut.contiguous(memory_format=torch.channels_last)
+        rows = n * l
+        ws = torch.empty(2 * lib.syn_bn_chunks(rows) * c, device=y.device, dtype=torch.float32)
+        stats = torch.empty(2, c, device=y.device, dtype=torch.float32)
+        z = torch.empty_like(yc, memory_format=torch.channels_last)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        cb = None if conv_bias is None else conv_bias.detach().float().contiguous()
+        _lib.check(lib.syn_bn_act_fwd(yc.data_ptr(), _lib.ptr(sc), rows, c, g.data_ptr(), b.data_ptr(), float(eps), float(momentum),
+                                      _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(cb), int(act), ws.data_ptr(), stats.data_ptr(),
+                                      z.data_ptr(), _lib.current_stream(y.device)), "syn_bn_act_fwd")
+        ctx.save_for_backward(yc, z, stats, g)
+        ctx.act, ctx.has_short, ctx.has_cb = bool(act), shortcut is not None, conv_bias is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        yc, z, stats, g = ctx.saved_tensors
+        n, c, _, l = yc.shape
+        rows = n * l
+        dzc = dz.contiguous(memory_format=torch.channels_last)
+        ws = torch.empty(2 * lib.syn_bn_chunks(rows) * c, device=dz.device, dtype=torch.float32)
+        dgb = torch.empty(2, c, device=dz.device, dtype=torch.float32)
+        dy = torch.empty_like(yc, memory_format=torch.channels_last)
+        dsh = torch.empty_like(yc, memory_format=torch.channels_last) if ctx.has_short else None
+        _lib.check(lib.syn_bn_act_bwd(dzc.data_ptr(), z.data_ptr(), yc.data_ptr(), stats.data_ptr(), g.data_ptr(), rows, c, int(ctx.act),
+                                      ws.data_ptr(), dgb.data_ptr(), dy.data_ptr(), _lib.ptr(dsh), _lib.current_stream(dz.device)),
+                   "syn_bn_act_bwd")
+        dcb = torch.zeros(c, device=dz.device, dtype=torch.float32) if ctx.has_cb else None
+        return dy, dgb[0], dgb[1], dcb, dsh, None, None, None, None, None
+
+
+WAV_FUSED_BN = True       # training mode: BatchNorm (+ shortcut) (+ LeakyReLU) of the encoder on syn_bn_act_fwd / _bwd
+
+
+def _conv_raw(conv, x, bf16=False):
+    """The convolution alone (no bias) on (N, C, 1, L): the split-operand kernel where the layer is one it covers."""
+    if (WAV_SPLIT_FWD and not bf16 and x.is_cuda and x.dim() == 4 and conv.kernel_size[0] == 15 and
+            (conv.in_channels, conv.stride[0], conv.out_channels) in ConvSplitFn.SUPPORTED and conv.padding[0] % conv.stride[0] == 0):
+        return ConvSplitFn.apply(x, conv.weight.unsqueeze(2), conv.stride[0], conv.padding[0])
+    if bf16:
+        return ConvBf16Fn.apply(x, conv.weight.unsqueeze(2), conv.stride[0], conv.padding[0])
+    return F.conv2d(x, conv.weight.unsqueeze(2), None, stride=(1, conv.stride[0]), padding=(0, conv.padding[0]))
+
+
+def _conv_bn_act(conv, bn, x, shortcut, act, bf16=False):
+    """Training-mode conv -> BatchNorm (batch statistics) [+ shortcut] [-> LeakyReLU] with the fused tail."""
+    y = _conv_raw(conv, x, bf16)
+    return BnActFn.apply(y, bn.weight, bn.bias, conv.bias, shortcut, bn.running_mean, bn.running_var,
+                         0.1 if bn.momentum is None else bn.momentum, bn.eps, act)
+
+
 def _conv_bn(conv, bn, x, training, bf16=False):
     """Conv1d + BatchNorm1d of the module (batch statistics in training, running statistics in eval) on (N, C, 1, L)."""
     if (WAV_SPLIT_FWD and not bf16 and x.is_cuda and x.dim() == 4 and conv.kernel_size[0] == 15 and
@@ -363,6 +426,10 @@ def _conv_bn(conv, bn, x, training, bf16=False):
 
 def _wav_block(blk, x, bf16=False):
     """models/utils/layer.py:171-184 with the module's own Conv1d / BatchNorm1d (train or eval statistics)."""
+    if WAV_CHANNELS_LAST and x.dim() == 4 and WAV_FUSED_BN and blk.training and x.is_cuda and blk.bn1.track_running_stats:
+        z = _conv_bn_act(blk.conv1, blk.bn1, x, None, True, bf16)
+        short = x if blk.downsample is None else _conv_bn_act(blk.downsample[0], blk.downsample[1], x, None, False, bf16)
+        return _conv_bn_act(blk.conv2, blk.bn2, z, short, True, bf16)
     if WAV_CHANNELS_LAST and x.dim() == 4:
         tr = blk.training
         z = F.leaky_relu(_conv_bn(blk.conv1, blk.bn1, x, tr, bf16), 0.01)

@@ -326,3 +326,36 @@ def test_training_conv_forward_on_split_operands_vs_fp32(cin, stride, cout, pad,
     x2, w2 = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
     torch.nn.functional.conv2d(x2, w2, None, stride=(1, stride), padding=(0, pad)).backward(gy)
     assert rel_l2(x.grad.cpu(), x2.grad.cpu()) < 1e-5 and rel_l2(w.grad.cpu(), w2.grad.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("C,L,short,act", [(64, 333, False, True), (128, 77, True, True), (256, 40, False, False), (64, 1500, True, True)])
+def test_fused_batchnorm_shortcut_leakyrelu_vs_torch_autograd(C, L, short, act):
+    """syn_bn_act_fwd / _bwd (training-mode BatchNorm1d on batch statistics [+ shortcut] [+ LeakyReLU(0.01)], the tail of every
+    convolution of the audio encoder's BasicBlock) against PyTorch's batch_norm + add + leaky_relu and their autograd:
+    output, running statistics (the convolution's bias enters only there), and the gradients of y, gamma, beta, shortcut."""
+    from syntalker_amd import training
+    DEV = "cuda"
+    g = torch.Generator().manual_seed(C + L)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    y = (mk(3, C, 1, L) * 2 + 0.5).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    sc = mk(3, C, 1, L).contiguous(memory_format=torch.channels_last).requires_grad_(True) if short else None
+    gamma, beta, cb = (mk(C) * 0.5 + 1).requires_grad_(True), mk(C).requires_grad_(True), mk(C).requires_grad_(True)
+    rm, rv = mk(C), mk(C).abs() + 0.5
+    rm2, rv2 = rm.clone(), rv.clone()
+    z = training.BnActFn.apply(y, gamma, beta, cb, sc, rm, rv, 0.1, 1e-5, act)
+    dz = mk(*z.shape)
+    z.backward(dz)
+    y2, g2, b2, cb2 = (t.detach().clone().requires_grad_(True) for t in (y, gamma, beta, cb))
+    sc2 = sc.detach().clone().requires_grad_(True) if short else None
+    p = torch.nn.functional.batch_norm(y2 + cb2.view(1, -1, 1, 1), rm2, rv2, g2, b2, True, 0.1, 1e-5)
+    if short:
+        p = p + sc2
+    want = torch.nn.functional.leaky_relu(p, 0.01) if act else p
+    want.backward(dz)
+    assert rel_l2(z.detach().cpu(), want.detach().cpu()) < 1e-5
+    assert torch.allclose(rm, rm2, rtol=1e-5, atol=1e-6) and torch.allclose(rv, rv2, rtol=1e-4, atol=1e-6)
+    assert rel_l2(y.grad.cpu(), y2.grad.cpu()) < 1e-4
+    assert rel_l2(gamma.grad.cpu(), g2.grad.cpu()) < 1e-4 and rel_l2(beta.grad.cpu(), b2.grad.cpu()) < 1e-4
+    assert float(cb.grad.abs().max()) == 0.0 and float(cb2.grad.abs().max()) < 1e-3 * float(dz.abs().sum() / C)
+    if short:
+        assert rel_l2(sc.grad.cpu(), sc2.grad.cpu()) < 1e-6
