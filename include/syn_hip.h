@@ -159,13 +159,15 @@ int syn_denoise_step_profile(const syn_model* model, const syn_step* step, void*
  * l_out = (l_in + 2 pad - 15) / stride + 1.  w_hi / w_lo: syn_pack_weight of the hi / lo bf16 halves of the GEMM matrix
  * W'[cout][tap][cin] (taps zero-padded to a multiple of the stride); products are hi.hi + lo.hi + hi.lo on the bf16 matrix
  * pipe, i.e. fp32-grade.  bias may be NULL.  Supported (cin, stride, cout): the encoder's own, see the error text. */
-/* Weight gradient of a stride-1, padding-7 Conv1d(k = 15) of the encoder (cout 64 / 128 / 256, cin a multiple of 16):
- * dw [cout][cin][15] = sum over clips and positions of dy[l][co] x[l + t - 7][ci], x / dy fp32 channels-last [n_clips][l][c].
- * Split operands like the forward (fp32-grade); workgroup partial sums go through ws - syn_conv1d_wgrad_shares(n_clips, l, cin)
- * * cout * 15 * cin floats - and are added in a fixed order (no atomics). */
-int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l, int32_t cin);
-int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l, int32_t cin, int32_t cout, float* ws, float* dw,
-                           void* stream);
+/* Weight gradient of a stride-1, padding-7 Conv1d(k = 15) of the encoder (cout 64 / 128 / 256; cin a multiple of 16; the
+ * stride / pad arguments are there for the strided layers, which are not instantiated): dw [cout][cin][15] = sum over clips and output
+ * positions of dy[l][co] x[l stride + t - pad][ci], x fp32 channels-last [n_clips][l_in][cin], dy [n_clips][l_out][cout].
+ * Split operands like the forward (fp32-grade); workgroup partial sums go through ws -
+ * syn_conv1d_wgrad_shares(n_clips, l_out, stride * cin) * cout * ceil(15 / stride) * stride * cin floats - and are added in a
+ * fixed order (no atomics). */
+int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows);
+int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
+                           int32_t cout, float* ws, float* dw, void* stream);
 
 /* The two fragment sets syn_conv1d_train_fwd takes, from the module's weight w [cout][cin][15] (fp32) in one launch; each
  * output holds N * ceil(15 / stride) * stride * C * 2 bytes.  transposed = 1 (stride 1 only): the matrix of the DATA GRADIENT

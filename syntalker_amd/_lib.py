@@ -115,7 +115,7 @@ def load():
     lib.syn_bn_act_fwd.argtypes = [vp, vp, C.c_int64, i32, vp, vp, C.c_float, C.c_float, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.syn_bn_act_bwd.argtypes = [vp, vp, vp, vp, vp, C.c_int64, i32, i32, vp, vp, vp, vp, vp]
     lib.syn_linear_bwd_prep.argtypes = [vp, i32, i32, vp, vp, vp, vp]
-    lib.syn_conv1d_train_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.syn_conv1d_train_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.syn_conv1d_wgrad_shares.argtypes = [i32, i32, i32]
     lib.syn_conv1d_pack_split.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
     lib.syn_conv1d_train_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp]

@@ -1698,11 +1698,11 @@ int launch_conv_train(const wav::TArgs& a, int n_clips, hipStream_t s) {
     return e == hipSuccess ? 0 : fail("k_conv_train launch", e);
 }
 
-template <int CO>
+template <int CO, int TAPS>
 int launch_wgrad(const wav::WArgs& a, hipStream_t s) {
     static bool once = false;
-    if (!once) { allow_lds(wav::k_conv_wgrad<CO>, wav::wgrad_lds<CO>()); once = true; }
-    hipLaunchKernelGGL(wav::k_conv_wgrad<CO>, dim3(a.cin / 16, a.shares), dim3(512), wav::wgrad_lds<CO>(), s, a);
+    if (!once) { allow_lds(wav::k_conv_wgrad<CO, TAPS>, wav::wgrad_lds(CO)); once = true; }
+    hipLaunchKernelGGL((wav::k_conv_wgrad<CO, TAPS>), dim3(a.cin / 16, a.shares), dim3(512), wav::wgrad_lds(CO), s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_wgrad launch", e);
 }
@@ -2236,29 +2236,35 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, 
     return e == hipSuccess ? 0 : fail("syn_wav_encode", e);
 }
 
-int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l, int32_t cin) {
-    const int chunks = n_clips * ((l + wav::kWgP - 1) / wav::kWgP), blocks = cin / 16;
+int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows) {
+    const int chunks = n_clips * ((l_out + wav::kWgP - 1) / wav::kWgP), blocks = cin_rows / 16;
     int shares = (device_cus() + blocks - 1) / blocks;              // one workgroup per CU in total (the partial sums are read back once per share)
     if (shares > chunks) shares = chunks;
     return shares < 1 ? 1 : shares;
 }
 
-int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l, int32_t cin, int32_t cout, float* ws, float* dw,
-                           void* stream) {
-    if (!x || !dy || !ws || !dw || n_clips <= 0 || l <= 0 || cin % 16) return fail_msg("syn_conv1d_train_wgrad: bad arguments");
+int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
+                           int32_t cout, float* ws, float* dw, void* stream) {
+    if (!x || !dy || !ws || !dw || n_clips <= 0 || l_in <= 0 || cin % 16 || stride < 1) return fail_msg("syn_conv1d_train_wgrad: bad arguments");
+    if (!(stride == 1 && pad == 7)) return fail_msg("syn_conv1d_train_wgrad: stride 1 with padding 7 only");
+    const int l_out = (l_in + 2 * pad - 15) / stride + 1, taps = (15 + stride - 1) / stride, cinp = stride * cin;
+    if (l_out <= 0) return fail_msg("syn_conv1d_train_wgrad: input shorter than the kernel");
     wav::WArgs a;
-    a.GY = dy; a.gy_clip_stride = (long)l * cout; a.L_out = l; a.X = x; a.x_clip_stride = (long)l * cin; a.x_elems = (long)l * cin;
-    a.cin = cin; a.n_clips = n_clips; a.chunks_per_clip = (l + wav::kWgP - 1) / wav::kWgP;
-    a.shares = syn_conv1d_wgrad_shares(n_clips, l, cin); a.part = ws;
+    a.GY = dy; a.gy_clip_stride = (long)l_out * cout; a.L_out = l_out; a.X = x; a.x_clip_stride = (long)l_in * cin; a.x_elems = (long)l_in * cin;
+    a.cin = cinp; a.n_clips = n_clips; a.chunks_per_clip = (l_out + wav::kWgP - 1) / wav::kWgP; a.row0 = stride == 1 ? -7 : 0;
+    a.shares = syn_conv1d_wgrad_shares(n_clips, l_out, cinp); a.part = ws;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (cout == 64) rc = launch_wgrad<64>(a, s);
-    else if (cout == 128) rc = launch_wgrad<128>(a, s);
-    else if (cout == 256) rc = launch_wgrad<256>(a, s);
-    else return fail_msg("syn_conv1d_train_wgrad: cout must be 64, 128 or 256");
+    if (cout == 64 && taps == 15) rc = launch_wgrad<64, 15>(a, s);
+    else if (cout == 128 && taps == 15) rc = launch_wgrad<128, 15>(a, s);
+    else if (cout == 256 && taps == 15) rc = launch_wgrad<256, 15>(a, s);
+    // (the strided layers, read as stride-1 ones over rows of stride * Cin channels, run correctly through <CO, 3> / <CO, 5> instances
+    // of the same kernel but slowly - 24 channel blocks each re-stage the whole dy tile for 3-5 taps of work: 1.3 ms against MIOpen's
+    // 0.3 ms per step - so they are not instantiated)
+    else return fail_msg("syn_conv1d_train_wgrad: stride-1 convolutions with 64 / 128 / 256 output channels only");
     if (rc) return rc;
     const int total = cout * 15 * cin;
-    hipLaunchKernelGGL(wav::k_conv_wgrad_sum, dim3((total + 255) / 256), dim3(256), 0, s, (const float*)ws, a.shares, cout, cin, dw);
+    hipLaunchKernelGGL(wav::k_conv_wgrad_sum, dim3((total + 255) / 256), dim3(256), 0, s, (const float*)ws, a.shares, cout, cin, stride, taps, dw);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_wgrad_sum launch", e);
 }

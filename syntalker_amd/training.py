@@ -322,13 +322,14 @@ class ConvSplitFn(torch.autograd.Function):
             else:
                 gx = torch.ops.aten.convolution_backward(gy, x, w, None, *args, (True, False, False))[0]
         if ctx.needs_input_grad[1]:
-            if stride == 1 and pad == 7 and cout in (64, 128, 256) and cin % 16 == 0 and WAV_SPLIT_WGRAD:
+            if WAV_SPLIT_WGRAD and stride == 1 and pad == 7 and (cin, stride, cout) in ConvSplitFn.SUPPORTED:
                 # contraction over positions of two channels-last tensors: transposed through LDS inside the kernel
                 lib = _lib.load()
                 n, _, _, l = x.shape
-                ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l, cin) * cout * 15 * cin, device=x.device, dtype=torch.float32)
+                l_out, kts = gy.shape[-1], -(-15 // stride) * stride
+                ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l_out, stride * cin) * cout * kts * cin, device=x.device, dtype=torch.float32)
                 gw = torch.empty(cout, cin, 1, 15, device=x.device, dtype=torch.float32)
-                _lib.check(lib.syn_conv1d_train_wgrad(x.data_ptr(), gy.data_ptr(), n, l, cin, cout, ws.data_ptr(), gw.data_ptr(),
+                _lib.check(lib.syn_conv1d_train_wgrad(x.data_ptr(), gy.data_ptr(), n, l, cin, stride, pad, cout, ws.data_ptr(), gw.data_ptr(),
                                                       _lib.current_stream(x.device)), "syn_conv1d_train_wgrad")
                 gw = gw.to(w.dtype)
             else:
