@@ -13,6 +13,13 @@ for (M,K,N) in ((1024,512,1536),(1024,512,512),(1024,512,1024),(1024,1024,512),(
     x=torch.randn(M,K,device=dev).bfloat16(); w=torch.randn(N,K,device=dev)
     wb=w.bfloat16()
     wp=engine.pack_weight(w)
+    from syntalker_amd import _lib
+    tt=[]
+    for mt in (16, 32, 64, 128):
+        _lib.load().syn_debug_linear_tile(mt)
+        tt.append(bench(lambda: training._gemm_packed(x, wp, N, K)))
+    _lib.load().syn_debug_linear_tile(0)
+    print("   row tiles 16/32/64/128:", " ".join(f"{v:6.1f}" for v in tt), "us")
     t_mine=bench(lambda: training._gemm_packed(x, wp, N, K))
     try:
         t_lib=bench(lambda: torch.mm(x, wb.t(), out_dtype=torch.float32))

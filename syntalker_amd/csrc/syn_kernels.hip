@@ -2030,6 +2030,8 @@ int syn_test_gemm(const void* x_bf16, const void* w_packed, const float* bias, i
     return launch_gemm<EPI_PLAIN>(a, m_tile ? m_tile : pick_tile(m_rows), n / kNT, (hipStream_t)stream);
 }
 
+static int g_linear_mt = 0;
+
 int syn_linear(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k, float* y,
                void* stream) {
     if (!x_bf16 || !w_packed || !y || n % kNT || k % 128 || m_rows <= 0)
@@ -2039,9 +2041,11 @@ int syn_linear(const void* x_bf16, const void* w_packed, const float* bias, int3
     a.X = (const __bf16*)x_bf16; a.ldx = k; a.x_rows = m_rows; a.W = (const uint4*)w_packed; a.K = k; a.M = m_rows;
     a.bias = bias; a.Yf = y; a.ldyf = n;
     // the training step's GEMMs have 512 .. 1536 rows: 16-row tiles give 32 .. 96 x (n / 512) workgroups, twice what 32-row ones do
-    const int mt = m_rows <= 2048 ? 16 : pick_tile(m_rows);
+    const int mt = g_linear_mt > 0 ? g_linear_mt : (m_rows <= 2048 ? 16 : pick_tile(m_rows));
     return launch_gemm<EPI_PLAIN>(a, mt, n / kNT, (hipStream_t)stream);
 }
+
+void syn_debug_linear_tile(int rows) { g_linear_mt = rows; }       /* diagnostics: pin syn_linear's row tile (16 / 32 / 64 / 128), 0 = automatic */
 
 int syn_test_handoff(uint32_t* sync_320_zeroed, uint32_t* buf_8x4096, const float* stream, int64_t stream_n, uint32_t* stale_9_zeroed,
                      int32_t words, int32_t rounds, int32_t mode, void* stream_h) {
