@@ -460,7 +460,10 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     if h3d and y.get("uncond_audio", False):
         audio, word = torch.zeros_like(audio), torch.zeros_like(word)
     a = audio.unsqueeze(1) if audio.dim() == 2 else audio.transpose(1, 2)
-    if WAV_CHANNELS_LAST:
+    # (train.py:90 may have converted the BatchNorms to SyncBatchNorm: their statistics are all-reduced over the ranks inside the
+    # module's own forward, so those models take the module path below instead of the functional / fused one)
+    sync_bn = any(isinstance(mod, nn.SyncBatchNorm) for mod in m.WavEncoder.modules())
+    if WAV_CHANNELS_LAST and not sync_bn:
         a = a.unsqueeze(2).contiguous(memory_format=torch.channels_last)       # (B, C, 1, L), channel innermost
     for i, blk in enumerate(m.WavEncoder.feat_extractor):
         a = _wav_block(blk, a, WAV_BF16 and i >= WAV_BF16_FROM)
