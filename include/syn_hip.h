@@ -170,11 +170,19 @@ int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int
                            int32_t cout, float* ws, float* dw, void* stream);
 
 /* The two fragment sets syn_conv1d_train_fwd takes, from the module's weight w [cout][cin][15] (fp32) in one launch; each
- * output holds N * ceil(15 / stride) * stride * C * 2 bytes.  transposed = 1 (stride 1 only): the matrix of the DATA GRADIENT
+ * output holds syn_conv1d_pack_bytes(...) bytes.  transposed = 1: the matrix of the DATA GRADIENT (stride 1; for a strided
+ * convolution the form syn_conv1d_train_dgrad_strided takes)
  * of that convolution (taps reversed, channel roles swapped: N = cin, C = cout) - the gradient then is
  * syn_conv1d_train_fwd(dy, ..., cin = cout, stride 1, pad 7, ..., cout = cin). */
 int syn_conv1d_pack_split(const float* w, int32_t cout, int32_t cin, int32_t stride, int32_t transposed, void* out_hi, void* out_lo,
                           void* stream);
+/* Bytes of each of syn_conv1d_pack_split's two outputs. */
+int64_t syn_conv1d_pack_bytes(int32_t cout, int32_t cin, int32_t stride, int32_t transposed);
+/* Data gradient of a STRIDED, unpadded Conv1d(k = 15) of the encoder ((cout, stride) = (64, 6), (128, 6), (256, 3)): dx fp32
+ * channels-last [n_clips][l_in][cin] from dy [n_clips][l_out][cout]; w_hi / w_lo = syn_conv1d_pack_split(w, ..., stride,
+ * transposed = 1).  A stride-1 convolution over dy whose output rows are `stride` consecutive positions x cin channels. */
+int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t cout,
+                                   const void* w_hi, const void* w_lo, float* dx, void* stream);
 int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
                          const void* w_hi, const void* w_lo, const float* bias, int32_t cout, float* y, void* stream);
 

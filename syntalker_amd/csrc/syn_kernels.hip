@@ -1454,9 +1454,11 @@ __global__ void k_pack_t(const T* __restrict__ S, int N, int K, uint4* __restric
 // Conv1d(k = 15) weight w[co][ci][15] (fp32) -> the two packed fragment sets (hi, lo bf16 halves) of the training-mode
 // GEMM matrix W'[n][tap * cin + c] (taps zero-padded to KT * stride): one launch instead of ten tensor operations per use.
 // transposed = 1: the matrix of the data gradient of a stride-1 convolution, n = ci, c = co, tap reversed.
-__global__ void k_conv_pack_split(const float* __restrict__ w, int cout, int cin, int kt_stride, int transposed,
+// transposed = 2: the data gradient of a STRIDED, unpadded convolution read as a stride-1 one from dy (cout channels) to rows of
+// stride * cin channels: W''[n = r cin + ci][i][co] = w[co][ci][(taps - 1 - i) stride + r], taps = kt_stride (the tap count here).
+__global__ void k_conv_pack_split(const float* __restrict__ w, int cout, int cin, int kt_stride, int transposed, int stride,
                                   uint4* __restrict__ out_hi, uint4* __restrict__ out_lo) {
-    const int N = transposed ? cin : cout, C = transposed ? cout : cin, K = kt_stride * C, KS = K / 32;
+    const int N = transposed == 2 ? stride * cin : (transposed ? cin : cout), C = transposed ? cout : cin, K = kt_stride * C, KS = K / 32;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (N / 16) * KS * 64) return;
     const int lane = idx & 63, f = idx >> 6, ks = f % KS, nf = f / KS;
@@ -1466,7 +1468,12 @@ __global__ void k_conv_pack_split(const float* __restrict__ w, int cout, int cin
     for (int e = 0; e < 8; ++e) {
         const int k = k0 + e, tap = k / C, c = k - tap * C;
         float v = 0.f;
-        if (tap < 15) v = transposed ? w[((size_t)c * cin + n) * 15 + (14 - tap)] : w[((size_t)n * cin + c) * 15 + tap];
+        if (transposed == 2) {
+            const int r = n / cin, ci = n - r * cin, t = (kt_stride - 1 - tap) * stride + r;
+            if (t < 15) v = w[((size_t)c * cin + ci) * 15 + t];
+        } else if (tap < 15) {
+            v = transposed ? w[((size_t)c * cin + n) * 15 + (14 - tap)] : w[((size_t)n * cin + c) * 15 + tap];
+        }
         h[e] = (__bf16)v;
         l[e] = (__bf16)(v - (float)h[e]);
     }
@@ -2273,18 +2280,55 @@ int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int
     return e == hipSuccess ? 0 : fail("k_conv_wgrad_sum launch", e);
 }
 
+// taps of the strided data-gradient GEMM, padded so that taps * cout / 32 is a multiple of the weight ring's 3
+static int dgrad_taps(int stride, int cout) {
+    int kt = (15 + stride - 1) / stride;
+    while ((kt * cout / 32) % 3) ++kt;
+    return kt;
+}
+
 int syn_conv1d_pack_split(const float* w, int32_t cout, int32_t cin, int32_t stride, int32_t transposed, void* out_hi, void* out_lo,
                           void* stream) {
     if (!w || !out_hi || !out_lo || cout % 16 || cin % 16 || stride < 1) return fail_msg("syn_conv1d_pack_split: bad arguments");
-    if (transposed && stride != 1) return fail_msg("syn_conv1d_pack_split: the transposed (data-gradient) form is for stride-1 convolutions");
-    const int kts = (15 + stride - 1) / stride * stride;
-    const int N = transposed ? cin : cout, C = transposed ? cout : cin;
+    int kts, N, C, mode = transposed ? 1 : 0;
+    if (transposed && stride > 1) { mode = 2; kts = dgrad_taps(stride, cout); N = stride * cin; C = cout; }
+    else { kts = (15 + stride - 1) / stride * stride; N = transposed ? cin : cout; C = transposed ? cout : cin; }
     if ((kts * C) % 32) return fail_msg("syn_conv1d_pack_split: taps x channels must be a multiple of 32");
     const int total = (N / 16) * (kts * C / 32) * 64;
-    hipLaunchKernelGGL(k_conv_pack_split, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, cout, cin, kts, transposed,
+    hipLaunchKernelGGL(k_conv_pack_split, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, cout, cin, kts, mode, stride,
                        (uint4*)out_hi, (uint4*)out_lo);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_pack_split launch", e);
+}
+
+int64_t syn_conv1d_pack_bytes(int32_t cout, int32_t cin, int32_t stride, int32_t transposed) {
+    if (transposed && stride > 1) return (int64_t)stride * cin * dgrad_taps(stride, cout) * cout * 2;
+    const int kts = (15 + stride - 1) / stride * stride;
+    return (int64_t)cout * kts * cin * 2;
+}
+
+// Data gradient of a strided, unpadded Conv1d(k = 15) of the encoder: dx [n][l_in][cin] from dy [n][l_out][cout] - a stride-1
+// convolution over dy whose output rows are stride consecutive positions x cin channels; three launches of 128 columns each.
+int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t cout,
+                                   const void* w_hi, const void* w_lo, float* dx, void* stream) {
+    if (!dy || !w_hi || !w_lo || !dx || n_clips <= 0 || l_in < 15 || stride < 2) return fail_msg("syn_conv1d_train_dgrad_strided: bad arguments");
+    const int l_out = (l_in - 15) / stride + 1, kt = dgrad_taps(stride, cout), q_rows = (l_in + stride - 1) / stride, np = stride * cin;
+    if (np % 128) return fail_msg("syn_conv1d_train_dgrad_strided: stride * cin must be a multiple of 128");
+    hipStream_t s = (hipStream_t)stream;
+    for (int c0 = 0; c0 < np; c0 += 128) {
+        wav::TArgs a;
+        a.X = dy; a.x_clip_stride = (long)l_out * cout; a.x_elems = (long)l_out * cout; a.row0 = -(kt - 1); a.L_out = q_rows;
+        const size_t frag0 = (size_t)(c0 / 16) * (kt * cout / 32) * 64;
+        a.Whi = (const uint4*)w_hi + frag0; a.Wlo = (const uint4*)w_lo + frag0; a.bias = nullptr;
+        a.Y = dx; a.y_clip_stride = (long)l_in * cin; a.y_pitch = np; a.y_col0 = c0; a.y_elems = (long)l_in * cin;
+        int rc;
+        if (cout == 64 && kt == 3) rc = launch_conv_train<64, 3, 2, 2, 4>(a, n_clips, s);
+        else if (cout == 128 && kt == 3) rc = launch_conv_train<128, 3, 2, 2, 4>(a, n_clips, s);
+        else if (cout == 256 && kt == 6) rc = launch_conv_train<256, 6, 2, 2, 4>(a, n_clips, s);
+        else return fail_msg("syn_conv1d_train_dgrad_strided: (cout, stride) must be (64, 6), (128, 6) or (256, 3)");
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
@@ -2296,6 +2340,7 @@ int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
     wav::TArgs a;
     a.X = x; a.x_clip_stride = (long)l_in * cin; a.x_elems = (long)l_in * cin; a.row0 = -pad / stride; a.L_out = l_out;
     a.Whi = (const uint4*)w_hi; a.Wlo = (const uint4*)w_lo; a.bias = bias; a.Y = y; a.y_clip_stride = (long)l_out * cout;
+    a.y_pitch = 0; a.y_col0 = 0; a.y_elems = 0;
     hipStream_t s = (hipStream_t)stream;
     const int cinp = stride * cin;
     // (rows of stride * cin floats, ceil(15 / stride) taps; tiles as the eval-mode encoder picks them, halved where two planes

@@ -319,6 +319,20 @@ class ConvSplitFn(torch.autograd.Function):
                 # the data gradient of a stride-1 'same' convolution is the same convolution with the taps reversed and the
                 # channel roles swapped: the same kernel, fp32-grade like the forward
                 gx = ConvSplitFn.run(gy, w, 1, 7, transposed=True)[1]
+            elif WAV_SPLIT_DGRAD_STRIDED and pad == 0 and (cout, stride) in ((64, 6), (128, 6), (256, 3)) and (stride * cin) % 128 == 0:
+                # a strided convolution's data gradient = a stride-1 convolution over dy whose output rows are `stride` consecutive
+                # positions x cin channels (three 128-column launches of the forward kernel)
+                lib = _lib.load()
+                n, _, _, l_in = x.shape
+                wc = w.detach().float().contiguous()
+                nb = lib.syn_conv1d_pack_bytes(cout, cin, stride, 1)
+                whi = torch.empty(nb, dtype=torch.uint8, device=x.device)
+                wlo = torch.empty_like(whi)
+                _lib.check(lib.syn_conv1d_pack_split(wc.data_ptr(), cout, cin, stride, 1, whi.data_ptr(), wlo.data_ptr(),
+                                                     _lib.current_stream(x.device)), "syn_conv1d_pack_split")
+                gx = torch.empty(n, cin, 1, l_in, device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+                _lib.check(lib.syn_conv1d_train_dgrad_strided(gy.data_ptr(), n, l_in, cin, stride, cout, whi.data_ptr(), wlo.data_ptr(),
+                                                              gx.data_ptr(), _lib.current_stream(x.device)), "syn_conv1d_train_dgrad_strided")
             else:
                 gx = torch.ops.aten.convolution_backward(gy, x, w, None, *args, (True, False, False))[0]
         if ctx.needs_input_grad[1]:
@@ -337,6 +351,7 @@ class ConvSplitFn(torch.autograd.Function):
         return gx, gw, None, None
 
 
+WAV_SPLIT_DGRAD_STRIDED = True    # data gradients of the strided convolutions on syn_conv1d_train_dgrad_strided
 WAV_SPLIT_WGRAD = True    # weight gradients of the stride-1 convolutions on syn_conv1d_train_wgrad
 WAV_SPLIT_FWD = True      # the encoder's forward convolutions on syn_conv1d_train_fwd (where the layer is one it covers)
 WAV_BF16_FROM = 0         # first encoder block that uses it
