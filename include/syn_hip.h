@@ -120,7 +120,8 @@ typedef struct syn_step {
 } syn_step;
 
 /* 1 when a step over n_clips x n_variants is best run by the wave-per-sequence kernel, i.e. the caller should keep the
- * latent in fragment order for the whole loop (large batches: >= 768 sequences in whole passes of 4 per CU; the <= 4
+ * latent in fragment order for the whole loop (batches whose passes of 4 sequences per CU beat the token-resident kernel's passes
+ * of 2: 513..1024, 1537..2048, ... sequences; the <= 4
  * variants of a guided clip are the waves of one workgroup and meet in the output stage through LDS); 0 otherwise. */
 int32_t syn_prefers_fragment_order(int32_t n_clips, int32_t n_variants);
 

@@ -1817,7 +1817,8 @@ int32_t syn_prefers_fragment_order(int32_t n_clips, int32_t n_variants) {
     if (n_variants < 1 || n_variants > 4) return 0;
     const int cus = device_cus();
     const long wgs = seq_grid(n_clips, n_variants), seqs = (long)n_clips * n_variants;
-    if (wgs < 3L * cus / 4) return 0;                         // (768 clips at V = 1)
+    // (no minimum fill: from 513 sequences on k_stack needs a second, mostly empty round - 1.10 ms per step whatever the size - where
+    // k_seq's single pass of 129..192 workgroups takes 0.88-0.92 ms: 612 k against 492 k clip-steps/s at 544 clips, 763 k against 630 k at 704)
     const long passes_seq = (wgs + cus - 1) / cus, passes_stack = (seqs + 2L * cus - 1) / (2L * cus);
     // (V = 3 leaves a wave of every workgroup idle: measured 1197 us against k_stack's 1120 at 256 clips)
     return passes_seq * (n_variants == 3 ? 255 : 191) < passes_stack * 100 ? 1 : 0;
