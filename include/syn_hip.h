@@ -161,7 +161,8 @@ int syn_denoise_step_profile(const syn_model* model, const syn_step* step, void*
  * W'[cout][tap][cin] (taps zero-padded to a multiple of the stride); products are hi.hi + lo.hi + hi.lo on the bf16 matrix
  * pipe, i.e. fp32-grade.  bias may be NULL.  Supported (cin, stride, cout): the encoder's own, see the error text. */
 /* Weight gradient of a stride-1, padding-7 Conv1d(k = 15) of the encoder (cout 64 / 128 / 256; cin a multiple of 16; the
- * stride / pad arguments are there for the strided layers, which are not instantiated): dw [cout][cin][15] = sum over clips and output
+ * encoder's unpadded strided layers too - (cin, stride, cout) = (64, 6, 64), (64, 6, 128), (128, 3, 256), read as stride-1 convolutions
+ * over rows of stride x cin = 384 channels): dw [cout][cin][15] = sum over clips and output
  * positions of dy[l][co] x[l stride + t - pad][ci], x fp32 channels-last [n_clips][l_in][cin], dy [n_clips][l_out][cout].
  * Split operands like the forward (fp32-grade); workgroup partial sums go through ws -
  * syn_conv1d_wgrad_shares(n_clips, l_out, stride * cin) * cout * ceil(15 / stride) * stride * cin floats - and are added in a
@@ -169,6 +170,18 @@ int syn_denoise_step_profile(const syn_model* model, const syn_step* step, void*
 int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows);
 int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
                            int32_t cout, float* ws, float* dw, void* stream);
+
+/* The encoder's first layer in training mode - Conv1d(cin = 1 | 2 -> 64, k 15, stride, padding) of block 0's conv1 and of its
+ * shortcut (models/denoiser.py:308, models/utils/layer.py:150,158; stride 5, padding 1700 there) - without the bias (see
+ * syn_bn_act_fwd): plain fp32 FMAs.  x fp32 [n_clips][l_in][cin] (the waveform as the reference passes it), w the module's weight
+ * [64][cin][15], y / dy fp32 channels-last [n_clips][l_out][64], l_out = (l_in + 2 pad - 15) / stride + 1.  The weight gradient
+ * needs ws of syn_conv1d_first_parts(n_clips, l_out) * 64 * cin * 15 floats (workgroup partial sums, added in a fixed order) and
+ * writes dw [64][cin][15].  There is no data gradient: the waveform is an input. */
+int32_t syn_conv1d_first_parts(int32_t n_clips, int32_t l_out);
+int syn_conv1d_first_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, const float* w, float* y,
+                         void* stream);
+int syn_conv1d_first_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws,
+                           float* dw, void* stream);
 
 /* The two fragment sets syn_conv1d_train_fwd takes, from the module's weight w [cout][cin][15] (fp32) in one launch; each
  * output holds syn_conv1d_pack_bytes(...) bytes.  transposed = 1: the matrix of the DATA GRADIENT (stride 1; for a strided

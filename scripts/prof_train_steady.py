@@ -18,7 +18,7 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     for _ in range(5): training.train_step(m, d, s, opt, x0, {"y": y})
     torch.cuda.synchronize()
-rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:22]
+rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:int(sys.argv[2]) if len(sys.argv) > 2 else 22]
 tot = sum(e.device_time_total for e in prof.key_averages())
 print(f"total device time per step: {tot / 5 / 1e3:.2f} ms")
 for e in rows:

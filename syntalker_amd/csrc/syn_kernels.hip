@@ -1705,6 +1705,16 @@ int launch_conv_train(const wav::TArgs& a, int n_clips, hipStream_t s) {
     return e == hipSuccess ? 0 : fail("k_conv_train launch", e);
 }
 
+template <int CO_T, int TAPS>
+int launch_wgrad_s(const wav::WArgs& a, hipStream_t s) {
+    static_assert(wav::wgrad_s_lds(CO_T) <= 160 * 1024, "dy and x' tiles must fit the LDS");
+    static bool once = false;
+    if (!once) { allow_lds(wav::k_conv_wgrad_s<CO_T, TAPS>, wav::wgrad_s_lds(CO_T)); once = true; }
+    hipLaunchKernelGGL((wav::k_conv_wgrad_s<CO_T, TAPS>), dim3(a.cin / wav::kWsJ, a.shares, a.co_n / CO_T), dim3(512), wav::wgrad_s_lds(CO_T), s, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv_wgrad_s launch", e);
+}
+
 template <int CO, int TAPS>
 int launch_wgrad(const wav::WArgs& a, hipStream_t s) {
     static bool once = false;
@@ -2249,8 +2259,10 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, 
 }
 
 int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows) {
-    const int chunks = n_clips * ((l_out + wav::kWgP - 1) / wav::kWgP), blocks = cin_rows / 16;
-    int shares = (device_cus() + blocks - 1) / blocks;              // one workgroup per CU in total (the partial sums are read back once per share)
+    const int chunks = n_clips * ((l_out + wav::kWgP - 1) / wav::kWgP);
+    const bool strided = cin_rows == 384;                           // (the stride-1 layers have 64 / 128 / 256 row channels)
+    const int blocks = strided ? cin_rows / wav::kWsJ : cin_rows / 16;
+    int shares = strided ? device_cus() / blocks : (device_cus() + blocks - 1) / blocks;   // one workgroup per CU in total (the partial sums are read back once per share)
     if (shares > chunks) shares = chunks;
     return shares < 1 ? 1 : shares;
 }
@@ -2258,27 +2270,73 @@ int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows
 int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
                            int32_t cout, float* ws, float* dw, void* stream) {
     if (!x || !dy || !ws || !dw || n_clips <= 0 || l_in <= 0 || cin % 16 || stride < 1) return fail_msg("syn_conv1d_train_wgrad: bad arguments");
-    if (!(stride == 1 && pad == 7)) return fail_msg("syn_conv1d_train_wgrad: stride 1 with padding 7 only");
+    if (!((stride == 1 && pad == 7) || (pad == 0 && stride * cin == 384 && (stride == 3 || stride == 6))))
+        return fail_msg("syn_conv1d_train_wgrad: stride 1 with padding 7, or the encoder's unpadded strided layers (stride x cin = 384)");
     const int l_out = (l_in + 2 * pad - 15) / stride + 1, taps = (15 + stride - 1) / stride, cinp = stride * cin;
     if (l_out <= 0) return fail_msg("syn_conv1d_train_wgrad: input shorter than the kernel");
     wav::WArgs a;
     a.GY = dy; a.gy_clip_stride = (long)l_out * cout; a.L_out = l_out; a.X = x; a.x_clip_stride = (long)l_in * cin; a.x_elems = (long)l_in * cin;
-    a.cin = cinp; a.n_clips = n_clips; a.chunks_per_clip = (l_out + wav::kWgP - 1) / wav::kWgP; a.row0 = stride == 1 ? -7 : 0;
+    a.cin = cinp; a.co_n = cout; a.n_clips = n_clips; a.chunks_per_clip = (l_out + wav::kWgP - 1) / wav::kWgP; a.row0 = stride == 1 ? -7 : 0;
     a.shares = syn_conv1d_wgrad_shares(n_clips, l_out, cinp); a.part = ws;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (cout == 64 && taps == 15) rc = launch_wgrad<64, 15>(a, s);
     else if (cout == 128 && taps == 15) rc = launch_wgrad<128, 15>(a, s);
     else if (cout == 256 && taps == 15) rc = launch_wgrad<256, 15>(a, s);
-    // (the strided layers, read as stride-1 ones over rows of stride * Cin channels, run correctly through <CO, 3> / <CO, 5> instances
-    // of the same kernel but slowly - 24 channel blocks each re-stage the whole dy tile for 3-5 taps of work: 1.3 ms against MIOpen's
-    // 0.3 ms per step - so they are not instantiated)
-    else return fail_msg("syn_conv1d_train_wgrad: stride-1 convolutions with 64 / 128 / 256 output channels only");
+    // the strided layers, read as stride-1 ones over rows of stride * Cin = 384 channels: waves = row channels, not taps
+    else if (cout == 64 && taps == 3) rc = launch_wgrad_s<64, 3>(a, s);
+    else if (cout == 128 && taps == 3) rc = launch_wgrad_s<128, 3>(a, s);
+    else if (cout == 256 && taps == 5) rc = launch_wgrad_s<128, 5>(a, s);
+    else return fail_msg("syn_conv1d_train_wgrad: 64 / 128 / 256 output channels; strided: (64 | 128, stride 6), (256, stride 3)");
     if (rc) return rc;
     const int total = cout * 15 * cin;
     hipLaunchKernelGGL(wav::k_conv_wgrad_sum, dim3((total + 255) / 256), dim3(256), 0, s, (const float*)ws, a.shares, cout, cin, stride, taps, dw);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_wgrad_sum launch", e);
+}
+
+int32_t syn_conv1d_first_parts(int32_t n_clips, int32_t l_out) { return n_clips * ((l_out + wav::kF1Chunk - 1) / wav::kF1Chunk); }
+
+static int first_layer_args(wav::FArgs& a, const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, const char* who) {
+    if (!x || n_clips <= 0 || l_in <= 0 || (cin != 1 && cin != 2) || stride < 1 || stride > 8 || pad < 0) return fail_msg(who);
+    a.X = x; a.L_in = l_in; a.n_clips = n_clips; a.stride = stride; a.pad = pad;
+    a.L_out = (l_in + 2 * pad - 15) / stride + 1;
+    if (a.L_out <= 0) return fail_msg(who);
+    a.W = nullptr; a.Y = nullptr; a.DY = nullptr; a.part = nullptr; a.chunks_per_clip = (a.L_out + wav::kF1Chunk - 1) / wav::kF1Chunk;
+    return 0;
+}
+
+int syn_conv1d_first_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, const float* w, float* y,
+                         void* stream) {
+    wav::FArgs a;
+    if (!w || !y) return fail_msg("syn_conv1d_first_fwd: bad arguments");
+    if (int rc = first_layer_args(a, x, n_clips, l_in, cin, stride, pad, "syn_conv1d_first_fwd: bad arguments (cin 1 | 2, 64 output channels)")) return rc;
+    a.W = w; a.Y = y;
+    const dim3 grid((a.L_out + wav::kF1Tile - 1) / wav::kF1Tile, n_clips);
+    const size_t lds = (size_t)((wav::kF1Tile - 1) * stride + 15) * cin * sizeof(float);
+    if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_fwd<1>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(wav::k_conv_first_fwd<2>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv_first_fwd launch", e);
+}
+
+int syn_conv1d_first_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws,
+                           float* dw, void* stream) {
+    wav::FArgs a;
+    if (!dy || !ws || !dw) return fail_msg("syn_conv1d_first_wgrad: bad arguments");
+    if (int rc = first_layer_args(a, x, n_clips, l_in, cin, stride, pad, "syn_conv1d_first_wgrad: bad arguments (cin 1 | 2, 64 output channels)")) return rc;
+    a.DY = dy; a.part = ws;
+    const size_t win = (size_t)((wav::kF1Chunk - 1) * stride + 15) * cin, red = (size_t)4 * cin * 15 * 64;
+    const size_t lds = (win > red ? win : red) * sizeof(float);
+    if (lds > 64 * 1024) return fail_msg("syn_conv1d_first_wgrad: stride too large for the window");
+    const dim3 grid(a.chunks_per_clip, n_clips);
+    hipStream_t s = (hipStream_t)stream;
+    if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_wgrad<1>, grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(wav::k_conv_first_wgrad<2>, grid, dim3(256), lds, s, a);
+    const int n = 64 * cin * 15;
+    hipLaunchKernelGGL(wav::k_conv_first_wsum, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)ws, n_clips * a.chunks_per_clip, n, dw);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv_first_wgrad launch", e);
 }
 
 // taps of the strided data-gradient GEMM, padded so that taps * cout / 32 is a multiple of the weight ring's 3

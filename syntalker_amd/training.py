@@ -336,8 +336,10 @@ class ConvSplitFn(torch.autograd.Function):
             else:
                 gx = torch.ops.aten.convolution_backward(gy, x, w, None, *args, (True, False, False))[0]
         if ctx.needs_input_grad[1]:
-            if WAV_SPLIT_WGRAD and stride == 1 and pad == 7 and (cin, stride, cout) in ConvSplitFn.SUPPORTED:
-                # contraction over positions of two channels-last tensors: transposed through LDS inside the kernel
+            if (WAV_SPLIT_WGRAD and (cin, stride, cout) in ConvSplitFn.SUPPORTED and
+                    ((stride == 1 and pad == 7) or (WAV_SPLIT_WGRAD_STRIDED and stride > 1 and pad == 0))):
+                # contraction over positions of two channels-last tensors: transposed through LDS inside the kernel (a strided layer
+                # as a stride-1 one over rows of stride x cin channels, a wave per 16 of them)
                 lib = _lib.load()
                 n, _, _, l = x.shape
                 l_out, kts = gy.shape[-1], -(-15 // stride) * stride
@@ -351,8 +353,44 @@ class ConvSplitFn(torch.autograd.Function):
         return gx, gw, None, None
 
 
+class ConvFirstFn(torch.autograd.Function):
+    """The encoder's first layer, Conv1d(1 | 2 -> 64, k 15, stride 5, padding 1700) of block 0's conv1 and of its shortcut
+    (models/denoiser.py:308), on the waveform as the reference passes it, (N, L, cin) fp32: forward and weight gradient on plain
+    fp32 FMAs (`syn_conv1d_first_fwd` / `_wgrad`); the waveform takes no gradient.  Returns (N, 64, 1, L_out) channels_last."""
+
+    @staticmethod
+    def forward(ctx, wav, w, stride, pad):
+        lib = _lib.load()
+        n, l_in, cin = wav.shape
+        wavc, wc = wav.detach().float().contiguous(), w.detach().float().contiguous()
+        l_out = (l_in + 2 * pad - 15) // stride + 1
+        y = torch.empty(n, 64, 1, l_out, device=wav.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _lib.check(lib.syn_conv1d_first_fwd(wavc.data_ptr(), n, l_in, cin, stride, pad, wc.data_ptr(), y.data_ptr(),
+                                            _lib.current_stream(wav.device)), "syn_conv1d_first_fwd")
+        ctx.save_for_backward(wavc)
+        ctx.geom = (stride, pad, w.shape, w.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (wavc,) = ctx.saved_tensors
+        stride, pad, wshape, wdtype = ctx.geom
+        if not ctx.needs_input_grad[1]:
+            return None, None, None, None
+        lib = _lib.load()
+        n, l_in, cin = wavc.shape
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        ws = torch.empty(lib.syn_conv1d_first_parts(n, gy.shape[-1]) * 64 * cin * 15, device=gy.device, dtype=torch.float32)
+        gw = torch.empty(64, cin, 15, device=gy.device, dtype=torch.float32)
+        _lib.check(lib.syn_conv1d_first_wgrad(wavc.data_ptr(), gy.data_ptr(), n, l_in, cin, stride, pad, ws.data_ptr(), gw.data_ptr(),
+                                              _lib.current_stream(gy.device)), "syn_conv1d_first_wgrad")
+        return None, gw.reshape(wshape).to(wdtype), None, None
+
+
 WAV_SPLIT_DGRAD_STRIDED = True    # data gradients of the strided convolutions on syn_conv1d_train_dgrad_strided
 WAV_SPLIT_WGRAD = True    # weight gradients of the stride-1 convolutions on syn_conv1d_train_wgrad
+WAV_SPLIT_WGRAD_STRIDED = True    # ... and of the strided ones (k_conv_wgrad_s)
+WAV_FIRST_LAYER = True    # block 0's conv1 / shortcut convolution (1-2 input channels) on syn_conv1d_first_fwd / _wgrad
 WAV_SPLIT_FWD = True      # the encoder's forward convolutions on syn_conv1d_train_fwd (where the layer is one it covers)
 WAV_BF16_FROM = 0         # first encoder block that uses it
 WAV_BF16 = False          # False | 1: bf16 forward only (data and weight gradients fp32) | 2: bf16 forward + data gradient.
@@ -412,6 +450,10 @@ def _conv_raw(conv, x, bf16=False):
     if (WAV_SPLIT_FWD and not bf16 and x.is_cuda and x.dim() == 4 and conv.kernel_size[0] == 15 and
             (conv.in_channels, conv.stride[0], conv.out_channels) in ConvSplitFn.SUPPORTED and conv.padding[0] % conv.stride[0] == 0):
         return ConvSplitFn.apply(x, conv.weight.unsqueeze(2), conv.stride[0], conv.padding[0])
+    if (WAV_FIRST_LAYER and x.is_cuda and x.dim() == 4 and not x.requires_grad and conv.kernel_size[0] == 15 and conv.in_channels in (1, 2)
+            and conv.out_channels == 64 and conv.dilation[0] == 1 and 1 <= conv.stride[0] <= 8):
+        n, cin, _, l = x.shape                                               # channels_last (N, cin, 1, L) = the waveform (N, L, cin)
+        return ConvFirstFn.apply(x.permute(0, 2, 3, 1).reshape(n, l, cin), conv.weight, conv.stride[0], conv.padding[0])
     if bf16:
         return ConvBf16Fn.apply(x, conv.weight.unsqueeze(2), conv.stride[0], conv.padding[0])
     return F.conv2d(x, conv.weight.unsqueeze(2), None, stride=(1, conv.stride[0]), padding=(0, conv.padding[0]))

@@ -328,6 +328,30 @@ def test_training_conv_forward_on_split_operands_vs_fp32(cin, stride, cout, pad,
     assert rel_l2(x.grad.cpu(), x2.grad.cpu()) < 1e-5 and rel_l2(w.grad.cpu(), w2.grad.cpu()) < 1e-5
 
 
+@pytest.mark.parametrize("cin,stride,pad,L", [(1, 5, 1700, 6001), (2, 5, 1700, 12345), (2, 5, 0, 644), (1, 3, 4, 77)])
+def test_training_first_layer_conv_vs_fp64(cin, stride, pad, L):
+    """syn_conv1d_first_fwd / _wgrad (block 0's conv1 and shortcut convolution: Conv1d(1 | 2 -> 64, k 15, stride 5, padding 1700),
+    models/denoiser.py:308, on the waveform layout (N, L, cin)) against PyTorch's convolution in float64: plain fp32 FMAs, so
+    fp32 rounding only, on ragged lengths and several position chunks per clip; no gradient for the waveform."""
+    from syntalker_amd import training
+    g = torch.Generator().manual_seed(cin + L)
+    DEV = "cuda"
+    wav = torch.randn(3, L, cin, generator=g).to(DEV)
+    w = (torch.randn(64, cin, 15, generator=g) / (cin * 15) ** 0.5).to(DEV).requires_grad_(True)
+    y = training.ConvFirstFn.apply(wav, w, stride, pad)
+    x4 = wav.permute(0, 2, 1).unsqueeze(2)                                      # (N, cin, 1, L)
+    w2 = w.detach().double().clone().requires_grad_(True)
+    want = torch.nn.functional.conv2d(x4.double(), w2.unsqueeze(2), None, stride=(1, stride), padding=(0, pad))
+    assert y.shape == want.shape and y.is_contiguous(memory_format=torch.channels_last)
+    e = rel_l2(y.detach().double().cpu(), want.detach().cpu())
+    gy = torch.randn(y.shape, generator=g).to(DEV)
+    y.backward(gy)
+    want.backward(gy.double())
+    eg = rel_l2(w.grad.double().cpu(), w2.grad.cpu())
+    print(f"first layer cin {cin} stride {stride} L {L}: forward {e:.2e}, weight gradient {eg:.2e} vs float64")
+    assert e < 1e-6 and eg < 1e-5
+
+
 @pytest.mark.parametrize("C,L,short,act", [(64, 333, False, True), (128, 77, True, True), (256, 40, False, False), (64, 1500, True, True)])
 def test_fused_batchnorm_shortcut_leakyrelu_vs_torch_autograd(C, L, short, act):
     """syn_bn_act_fwd / _bwd (training-mode BatchNorm1d on batch statistics [+ shortcut] [+ LeakyReLU(0.01)], the tail of every
