@@ -1718,8 +1718,9 @@ int launch_wgrad_s(const wav::WArgs& a, hipStream_t s) {
 template <int CO, int TAPS>
 int launch_wgrad(const wav::WArgs& a, hipStream_t s) {
     static bool once = false;
-    if (!once) { allow_lds(wav::k_conv_wgrad<CO, TAPS>, wav::wgrad_lds(CO)); once = true; }
-    hipLaunchKernelGGL((wav::k_conv_wgrad<CO, TAPS>), dim3(a.cin / 16, a.shares), dim3(512), wav::wgrad_lds(CO), s, a);
+    constexpr int CB = wav::wgrad_cb(CO);
+    if (!once) { allow_lds(wav::k_conv_wgrad<CO, TAPS, CB>, wav::wgrad_lds(CO)); once = true; }
+    hipLaunchKernelGGL((wav::k_conv_wgrad<CO, TAPS, CB>), dim3(a.cin / (16 * CB), a.shares), dim3(512), wav::wgrad_lds(CO), s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_wgrad launch", e);
 }
@@ -2261,9 +2262,13 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, 
 int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows) {
     const int chunks = n_clips * ((l_out + wav::kWgP - 1) / wav::kWgP);
     const bool strided = cin_rows == 384;                           // (the stride-1 layers have 64 / 128 / 256 row channels)
-    const int blocks = strided ? cin_rows / wav::kWsJ : cin_rows / 16;
+    const int blocks = strided ? cin_rows / wav::kWsJ : cin_rows / (16 * wav::wgrad_cb(cin_rows));   // (stride-1 layers: cout = cin)
     int shares = strided ? device_cus() / blocks : (device_cus() + blocks - 1) / blocks;   // one workgroup per CU in total (the partial sums are read back once per share)
     if (shares > chunks) shares = chunks;
+    // every share writes a partial sum of the whole gradient block and k_conv_wgrad_sum reads them all back: with few chunks per
+    // share that traffic outweighs the parallelism (time ~ chunks / shares x t_chunk + shares x t_partial, t_chunk / t_partial ~ 21)
+    const int balanced = (int)sqrtf(21.f * (float)chunks);
+    if (!strided && shares > balanced) shares = balanced;
     return shares < 1 ? 1 : shares;
 }
 
@@ -2286,7 +2291,7 @@ int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int
     // the strided layers, read as stride-1 ones over rows of stride * Cin = 384 channels: waves = row channels, not taps
     else if (cout == 64 && taps == 3) rc = launch_wgrad_s<64, 3>(a, s);
     else if (cout == 128 && taps == 3) rc = launch_wgrad_s<128, 3>(a, s);
-    else if (cout == 256 && taps == 5) rc = launch_wgrad_s<128, 5>(a, s);
+    else if (cout == 256 && taps == 5) rc = launch_wgrad_s<64, 5>(a, s);     // (128-channel blocks spill: 20 accumulator tiles per wave is the limit)
     else return fail_msg("syn_conv1d_train_wgrad: 64 / 128 / 256 output channels; strided: (64 | 128, stride 6), (256, stride 3)");
     if (rc) return rc;
     const int total = cout * 15 * cin;
@@ -2326,15 +2331,15 @@ int syn_conv1d_first_wgrad(const float* x, const float* dy, int32_t n_clips, int
     if (!dy || !ws || !dw) return fail_msg("syn_conv1d_first_wgrad: bad arguments");
     if (int rc = first_layer_args(a, x, n_clips, l_in, cin, stride, pad, "syn_conv1d_first_wgrad: bad arguments (cin 1 | 2, 64 output channels)")) return rc;
     a.DY = dy; a.part = ws;
-    const size_t win = (size_t)((wav::kF1Chunk - 1) * stride + 15) * cin, red = (size_t)4 * cin * 15 * 64;
+    const size_t win = (size_t)((wav::kF1Chunk - 1) * stride + 15) * cin, red = (size_t)8 * cin * 15 * 64;
     const size_t lds = (win > red ? win : red) * sizeof(float);
     if (lds > 64 * 1024) return fail_msg("syn_conv1d_first_wgrad: stride too large for the window");
     const dim3 grid(a.chunks_per_clip, n_clips);
     hipStream_t s = (hipStream_t)stream;
-    if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_wgrad<1>, grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(wav::k_conv_first_wgrad<2>, grid, dim3(256), lds, s, a);
+    if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_wgrad<1>, grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(wav::k_conv_first_wgrad<2>, grid, dim3(512), lds, s, a);
     const int n = 64 * cin * 15;
-    hipLaunchKernelGGL(wav::k_conv_first_wsum, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)ws, n_clips * a.chunks_per_clip, n, dw);
+    hipLaunchKernelGGL(wav::k_conv_first_wsum, dim3((n + 63) / 64), dim3(1024), 0, s, (const float*)ws, n_clips * a.chunks_per_clip, n, dw);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_first_wgrad launch", e);
 }
