@@ -200,6 +200,12 @@ int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_i
 int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
                          const void* w_hi, const void* w_lo, const float* bias, int32_t cout, float* y, void* stream);
 
+/* Every bf16 fragment set the training step's Linear layers need, from the fp32 master weights in ONE launch (the weights change
+ * once per step, in optimizer.step()): job j packs src (n x k row-major, transposed = 0: as syn_pack_weight; k x n row-major,
+ * transposed = 1: as syn_pack_weight_t) into out.  jobs_dev: device array; max_fragments = max over the jobs of n / 16 * k / 32. */
+typedef struct syn_pack_job { const float* src; void* out; int32_t n, k, transposed, pad_; } syn_pack_job;
+int syn_pack_weights(const syn_pack_job* jobs_dev, int32_t n_jobs, int64_t max_fragments, void* stream);
+
 /* ---- training path: fp32 forward / backward of the non-GEMM pieces of a transformer block ----
  * LayerNorm(512, eps 1e-5) of `rows` rows (models/timm_transformer/transformer.py:160,162,183,193); the backward
  * needs scratch of ceil(rows/64)*1024 floats and writes dgamma[512], dbeta[512] (deterministic two-stage sums). */
@@ -224,8 +230,10 @@ int syn_bn_act_bwd(const float* dz, const float* z, const float* y, const float*
 
 /* Backward of an nn.Linear, the operand preparation in one pass over dy [m_rows][n] fp32: its bf16 copy (data-gradient GEMM),
  * the bf16 transpose [n][m_rows] (weight-gradient GEMM) and colsum_part [m_rows / 64][n] = column sums of every 64-row block
- * (NULL to skip; the bias gradient is their sum over the first index). */
-int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, void* dy_bf16, void* dy_bf16_t, float* colsum_part, void* stream);
+ * (NULL to skip; the bias gradient is their sum over the first index).  With colsum [n] (and counters: n / 64 ints, zero before the
+ * first use, left zero by every launch) the launch also adds the partial sums up, in row-block order: the bias gradient itself. */
+int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, void* dy_bf16, void* dy_bf16_t, float* colsum_part, int32_t* counters,
+                        float* colsum, void* stream);
 /* Attention core (transformer.py:83-104, 4 heads x 128, 32 tokens, no mask, no dropout) on the packed output of the
  * qkv Linear: qkv [n_seq][32][3][4][128] -> o [n_seq][32][512]; backward recomputes the probabilities. */
 int syn_attn_fwd(const float* qkv, float* o, int32_t n_seq, void* stream);

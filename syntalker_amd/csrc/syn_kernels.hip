@@ -1451,6 +1451,29 @@ __global__ void k_pack_t(const T* __restrict__ S, int N, int K, uint4* __restric
     out[idx] = __builtin_bit_cast(uint4, r);
 }
 
+// The step's weight packs in ONE launch: job j packs src_j (fp32) as k_pack (transposed = 0: src [n][k]) or as k_pack_t
+// (transposed = 1: src [k][n]) into out_j.  Grid (blocks of the largest job, jobs).
+struct PackJob { const float* src; uint4* out; int n, k, transposed, pad_; };
+__global__ void k_pack_many(const PackJob* __restrict__ jobs) {
+    const PackJob j = jobs[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int KS = j.k / 32;
+    if (idx >= (j.n / 16) * KS * 64) return;
+    const int lane = idx & 63, f = idx >> 6, ks = f % KS, nf = f / KS;
+    bf16x8 r;
+    if (j.transposed) {
+        const float* src = j.src + (size_t)(32 * ks + 8 * (lane >> 4)) * j.n + 16 * nf + (lane & 15);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (__bf16)src[(size_t)e * j.n];
+    } else {
+        const float* src = j.src + (size_t)(16 * nf + (lane & 15)) * j.k + 32 * ks + 8 * (lane >> 4);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+        r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
+        r[4] = (__bf16)b[0]; r[5] = (__bf16)b[1]; r[6] = (__bf16)b[2]; r[7] = (__bf16)b[3];
+    }
+    j.out[idx] = __builtin_bit_cast(uint4, r);
+}
+
 // Conv1d(k = 15) weight w[co][ci][15] (fp32) -> the two packed fragment sets (hi, lo bf16 halves) of the training-mode
 // GEMM matrix W'[n][tap * cin + c] (taps zero-padded to KT * stride): one launch instead of ten tensor operations per use.
 // transposed = 1: the matrix of the data gradient of a stride-1 convolution, n = ci, c = co, tap reversed.
@@ -1796,6 +1819,15 @@ int syn_pack_weight(const float* w, int32_t n, int32_t k, void* out_packed, void
     hipLaunchKernelGGL(k_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, n, k, (uint4*)out_packed);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_pack launch", e);
+}
+
+int syn_pack_weights(const syn_pack_job* jobs_dev, int32_t n_jobs, int64_t max_fragments, void* stream) {
+    static_assert(sizeof(syn_pack_job) == sizeof(PackJob), "syn_pack_job is PackJob");
+    if (!jobs_dev || n_jobs <= 0 || max_fragments <= 0) return fail_msg("syn_pack_weights: bad arguments");
+    hipLaunchKernelGGL(k_pack_many, dim3((unsigned)((max_fragments * 64 + 255) / 256), n_jobs), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const PackJob*>(jobs_dev));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_pack_many launch", e);
 }
 
 int syn_pack_weight_t(const void* s_kn, int32_t is_bf16, int32_t n, int32_t k, void* out_packed, void* stream) {
@@ -2149,11 +2181,13 @@ int syn_bn_act_bwd(const float* dz, const float* z, const float* y, const float*
     return e == hipSuccess ? 0 : fail("syn_bn_act_bwd", e);
 }
 
-int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, void* dy_bf16, void* dy_bf16_t, float* colsum_part, void* stream) {
+int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, void* dy_bf16, void* dy_bf16_t, float* colsum_part, int32_t* counters,
+                        float* colsum, void* stream) {
     if (!dy || !dy_bf16 || !dy_bf16_t || m_rows <= 0 || n <= 0 || m_rows % 64 || n % 64)
         return fail_msg("syn_linear_bwd_prep: need m_rows % 64 == 0, n % 64 == 0 and non-null pointers");
+    if (colsum && (!colsum_part || !counters)) return fail_msg("syn_linear_bwd_prep: colsum needs colsum_part and counters");
     hipLaunchKernelGGL(trn::k_linear_bwd_prep, dim3(n / 64, m_rows / 64), dim3(256), 0, (hipStream_t)stream, dy, m_rows, n, (__bf16*)dy_bf16,
-                       (__bf16*)dy_bf16_t, colsum_part);
+                       (__bf16*)dy_bf16_t, colsum_part, counters, colsum);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_linear_bwd_prep launch", e);
 }

@@ -73,6 +73,74 @@ def _gemm_packed(xb: torch.Tensor, wp: torch.Tensor, n: int, k: int) -> torch.Te
     return y
 
 
+class WeightPacks:
+    """The bf16 fragment sets the step's Linear layers take - W for the forward GEMM, W^T for the data-gradient GEMM - packed from
+    the fp32 master weights in ONE launch per step (`syn_pack_weights`) instead of one launch per use (82 per step): the weights
+    only change in optimizer.step().  `refresh()` at the top of every training forward; HipLinearFn looks a weight up by object
+    identity and in-place version, so a stale or foreign tensor simply takes the per-call packing path."""
+
+    def __init__(self, weights):
+        import numpy as np
+        self.items = {}
+        jobs, self.max_frag = [], 0
+        dev = None
+        for w in weights:
+            if not (w.is_cuda and w.dtype is torch.float32 and w.is_contiguous() and w.dim() == 2) or id(w) in self.items:
+                continue
+            dev = w.device
+            N, K = w.shape
+            fwd = torch.empty(N * K * 2, dtype=torch.uint8, device=dev) if N % 512 == 0 and K % 128 == 0 else None
+            tr = torch.empty(N * K * 2, dtype=torch.uint8, device=dev) if K % 512 == 0 and N % 128 == 0 else None
+            if fwd is None and tr is None:
+                continue
+            if fwd is not None:
+                jobs.append((w.data_ptr(), fwd.data_ptr(), N, K, 0, 0))
+            if tr is not None:
+                jobs.append((w.data_ptr(), tr.data_ptr(), K, N, 1, 0))       # fragments of W^T [K][N] from the row-major [N][K]
+            self.max_frag = max(self.max_frag, (N // 16) * (K // 32))
+            self.items[id(w)] = [__import__("weakref").ref(w), w.data_ptr(), -1, fwd, tr]
+        self.n_jobs = len(jobs)
+        if jobs:
+            arr = np.array(jobs, dtype=np.dtype([("src", "<u8"), ("out", "<u8"), ("n", "<i4"), ("k", "<i4"), ("t", "<i4"), ("pad", "<i4")]))
+            self.jobs = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
+
+    def valid(self) -> bool:
+        return all(r() is not None and r().data_ptr() == ptr for r, ptr, *_ in self.items.values())
+
+    def refresh(self):
+        if not self.n_jobs:
+            return
+        _lib.check(_lib.load().syn_pack_weights(self.jobs.data_ptr(), self.n_jobs, self.max_frag, _lib.current_stream(self.jobs.device)),
+                   "syn_pack_weights")
+        for it in self.items.values():
+            it[2] = it[0]()._version
+
+    def lookup(self, w):
+        it = self.items.get(id(w))
+        if it is None or it[0]() is not w or it[2] != w._version or it[1] != w.data_ptr():
+            return None, None
+        return it[3], it[4]
+
+
+WEIGHT_PACKS = bool(int(__import__("os").environ.get("SYN_WEIGHT_PACKS", "1")))       # training forward: pack every Linear weight (and its transpose) in one launch per step
+_packs: "WeightPacks | None" = None
+
+
+def _lookup_packs(w):
+    return _packs.lookup(w) if (_packs is not None and WEIGHT_PACKS) else (None, None)
+
+
+_bias_counters = {}
+
+
+def _counters(device):
+    """Arrival counters of syn_linear_bwd_prep's in-launch bias-gradient sum: zero before the first use, left zero by every launch."""
+    c = _bias_counters.get(device)
+    if c is None:
+        c = _bias_counters[device] = torch.zeros(1024, dtype=torch.int32, device=device)
+    return c
+
+
 class HipLinearFn(torch.autograd.Function):
     """y = x W^T + b with forward, dgrad and wgrad on syn_linear."""
 
@@ -80,7 +148,14 @@ class HipLinearFn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         K = x.shape[-1]
         xb = x.reshape(-1, K).to(torch.bfloat16)
-        y = hip_matmul_nt(xb, w, b)
+        pk, ctx.pack_t = _lookup_packs(w)
+        if pk is not None and (b is None or (b.dtype is torch.float32 and b.is_contiguous())):
+            xb = xb.contiguous()
+            y = torch.empty(xb.shape[0], w.shape[0], dtype=torch.float32, device=x.device)
+            _lib.check(_lib.load().syn_linear(xb.data_ptr(), pk.data_ptr(), _lib.ptr(b), xb.shape[0], w.shape[0], K, y.data_ptr(),
+                                              _lib.current_stream(y.device)), "syn_linear")
+        else:
+            y = hip_matmul_nt(xb, w, b)
         ctx.save_for_backward(xb, w)
         ctx.has_bias = b is not None
         ctx.in_shape = x.shape
@@ -100,15 +175,20 @@ class HipLinearFn(torch.autograd.Function):
             dybt = torch.empty(N, M, dtype=torch.bfloat16, device=dy.device)
             want_db = ctx.has_bias and ctx.needs_input_grad[2] and LINEAR_BWD_PREP > 1
             part = torch.empty(M // 64, N, dtype=torch.float32, device=dy.device) if want_db else None
+            in_launch = want_db and LINEAR_BWD_PREP > 2 and N // 64 <= 1024
+            if in_launch:
+                db = torch.empty(N, dtype=torch.float32, device=dy.device)
             _lib.check(_lib.load().syn_linear_bwd_prep(dy2.data_ptr(), M, N, dyb.data_ptr(), dybt.data_ptr(), _lib.ptr(part),
+                                                       _lib.ptr(_counters(dy.device)) if in_launch else None, _lib.ptr(db) if in_launch else None,
                                                        _lib.current_stream(dy.device)), "syn_linear_bwd_prep")
-            if want_db:
+            if want_db and not in_launch:
                 db = part.sum(0)
         else:
             dyb = dy2.to(torch.bfloat16).contiguous()
         if ctx.needs_input_grad[0]:
             if K % 512 == 0 and N % 128 == 0 and w.dtype is torch.float32 and w.is_contiguous():
-                dx = _gemm_packed(dyb, _pack_t(w, K, N), K, N).reshape(ctx.in_shape)       # dy . W, W^T packed in place
+                wt = ctx.pack_t if ctx.pack_t is not None else _pack_t(w, K, N)          # W^T: the step's pack, or packed in place
+                dx = _gemm_packed(dyb, wt, K, N).reshape(ctx.in_shape)                    # dy . W
             else:
                 dx = hip_matmul_nt(dyb, w.t()).reshape(ctx.in_shape)
         if ctx.needs_input_grad[1]:
@@ -123,6 +203,10 @@ class HipLinearFn(torch.autograd.Function):
 
 import os as _os
 LINEAR_BWD_PREP = int(_os.environ.get("SYN_LINEAR_BWD_PREP", "1"))    # 0: PyTorch cast / transpose / sum; 1: fused cast + transpose (syn_linear_bwd_prep);
+                                                                      # 3: + the bias gradient from the same launch (last block of a column block adds the partial
+                                                                      #    sums) - correct (test_step_weight_packs_and_in_launch_bias_gradient) but measured 21 us per
+                                                                      #    launch against 4 + 8: the agent-scope release in front of the arrival counter writes the
+                                                                      #    XCD's L2 back; and like 2 it aborts the captured bench-size step;
                                                                       # 2: + bias-gradient partial sums from the same pass - correct (eager tests), but the captured
                                                                       # training graph then dies in the HIP runtime with the memory-aperture violation of DESIGN.md 7
 
@@ -508,6 +592,13 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     engine._require_cuda(x, "x")
     bs, C, _, T = x.shape
     training = m.training
+    global _packs
+    if WEIGHT_PACKS and torch.is_grad_enabled():
+        pk = m.__dict__.get("_syn_weight_packs")
+        if pk is None or not pk.valid():
+            pk = m.__dict__["_syn_weight_packs"] = WeightPacks([mod.weight for mod in m.modules() if isinstance(mod, nn.Linear)])
+        pk.refresh()
+        _packs = pk
     h3d = m.variant == "h3d"
     te = m.embed_timestep
     e = te.sequence_pos_encoder.pe[timesteps]                                   # (B,1,512)
@@ -544,13 +635,21 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
             st = st * (1. - mask) + null * mask
         seq = lin(torch.cat((seq, st.unsqueeze(0).repeat(T, 1, 1)), dim=2), m.input_process3)
     h = _rotary(m, seq.permute(1, 0, 2))
-    for blk in m.mytimmblocks:
+    # DropPath (timm_transformer/transformer.py:21-38: one Bernoulli(keep) / keep factor per sample and residual branch): all the
+    # step's factors from one draw, and x + branch * factor as one fused multiply-add instead of bernoulli, div, mul, add per branch
+    dp = None
+    if HIP_BLOCK_OPS and training and drop_path > 0.:
+        keep = 1. - drop_path
+        dp = h.new_empty(2 * len(m.mytimmblocks), bs, 1, 1).bernoulli_(keep).div_(keep)
+    for i, blk in enumerate(m.mytimmblocks):
         if HIP_BLOCK_OPS:
             z = HipLayerNormFn.apply(h, blk.norm1.weight, blk.norm1.bias)
             o = HipAttentionFn.apply(lin(z, blk.attn.qkv))           # (B, T, 3 x 4 heads x 128) -> (B, T, 512)
-            h = h + _drop_path(lin(o, blk.attn.proj), drop_path, training)
+            br = lin(o, blk.attn.proj)
+            h = h + br if dp is None else torch.addcmul(h, br, dp[2 * i])
             z = HipLayerNormFn.apply(h, blk.norm2.weight, blk.norm2.bias)
-            h = h + _drop_path(lin(HipGeluFn.apply(lin(z, blk.mlp.fc1)), blk.mlp.fc2), drop_path, training)
+            br = lin(HipGeluFn.apply(lin(z, blk.mlp.fc1)), blk.mlp.fc2)
+            h = h + br if dp is None else torch.addcmul(h, br, dp[2 * i + 1])
         else:
             z = F.layer_norm(h, (512,), blk.norm1.weight, blk.norm1.bias, 1e-5)
             qkv = lin(z, blk.attn.qkv).reshape(bs, T, 3, 4, 128).permute(2, 0, 3, 1, 4)

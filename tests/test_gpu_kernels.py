@@ -328,6 +328,48 @@ def test_training_conv_forward_on_split_operands_vs_fp32(cin, stride, cout, pad,
     assert rel_l2(x.grad.cpu(), x2.grad.cpu()) < 1e-5 and rel_l2(w.grad.cpu(), w2.grad.cpu()) < 1e-5
 
 
+def test_step_weight_packs_and_in_launch_bias_gradient(monkeypatch):
+    """syn_pack_weights (every Linear weight and its transpose as bf16 fragments, one launch) against the per-use packers,
+    bitwise; a weight updated in place falls out of the cache until the next refresh; and syn_linear_bwd_prep's bias gradient
+    from the same launch (arrival counter, last block adds the partial sums) against dy.sum(0), twice in a row (the counters
+    reset themselves) and bitwise run-to-run."""
+    from syntalker_amd import training, engine
+    DEV = "cuda"
+    g = torch.Generator().manual_seed(5)
+    ws = [torch.randn(n, k, generator=g).to(DEV) for n, k in ((512, 512), (1536, 512), (512, 2048), (1024, 512), (256, 300))]
+    pk = training.WeightPacks(ws)
+    pk.refresh()
+    for w in ws[:4]:
+        N, K = w.shape
+        fwd, tr = pk.lookup(w)
+        assert fwd is not None and torch.equal(fwd, engine.pack_weight(w).view(torch.uint8).reshape(-1))
+        if K % 512 == 0 and N % 128 == 0:
+            assert torch.equal(tr, training._pack_t(w, K, N))
+    assert pk.lookup(ws[4]) == (None, None)                        # (256, 300): not a shape the GEMM takes unpadded
+    ws[0].add_(1.0)
+    assert pk.lookup(ws[0]) == (None, None)                        # stale until the next refresh
+    pk.refresh()
+    assert torch.equal(pk.lookup(ws[0])[0], engine.pack_weight(ws[0]).view(torch.uint8).reshape(-1))
+    training._packs = pk
+    monkeypatch.setattr(training, "LINEAR_BWD_PREP", 3)
+    for M, N, K in ((1024, 512, 512), (128, 1536, 512), (1024, 512, 2048)):
+        w = next(t for t in ws if t.shape == (N, K)).requires_grad_(True)
+        b = torch.randn(N, generator=g).to(DEV).requires_grad_(True)
+        x = torch.randn(M, K, generator=g).to(DEV).requires_grad_(True)
+        dy = torch.randn(M, N, generator=g).to(DEV)
+        grads = []
+        for _ in range(2):
+            w.grad = b.grad = x.grad = None
+            training.HipLinearFn.apply(x, w, b).backward(dy)
+            grads.append((b.grad.clone(), x.grad.clone(), w.grad.clone()))
+        assert all(torch.equal(p, q) for p, q in zip(*grads))
+        assert rel_l2(grads[0][0].cpu(), dy.sum(0).cpu()) < 1e-6
+        xb, wb, dyb = x.detach().bfloat16().float(), w.detach().bfloat16().float(), dy.bfloat16().float()
+        assert rel_l2(grads[0][1].cpu(), (dyb @ wb).cpu()) < 1e-5 and rel_l2(grads[0][2].cpu(), (dyb.t() @ xb).cpu()) < 1e-5
+        w.requires_grad_(False)
+    training._packs = None
+
+
 @pytest.mark.parametrize("cin,stride,pad,L", [(1, 5, 1700, 6001), (2, 5, 1700, 12345), (2, 5, 0, 644), (1, 3, 4, 77)])
 def test_training_first_layer_conv_vs_fp64(cin, stride, pad, L):
     """syn_conv1d_first_fwd / _wgrad (block 0's conv1 and shortcut convolution: Conv1d(1 | 2 -> 64, k 15, stride 5, padding 1700),
