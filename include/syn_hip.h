@@ -220,13 +220,14 @@ int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* st
  * positions: z = act(gamma (y - mean) rstd + beta [+ shortcut]).  ws: 2 * syn_bn_chunks(rows) * channels floats; stats
  * [2][channels] receives mean / rstd for the backward; run_mean / run_var may be NULL; conv_bias (or NULL): the bias of the
  * convolution that produced y, NOT added to y by the caller - under batch statistics it only shifts the running mean.  Backward: dgamma_dbeta [2][channels],
- * dy, and dshortcut (NULL when there is none) from dz, the saved z and y. */
+ * dy, and dshortcut (NULL when there is none) from dz, the saved z and y.  z may be NULL when there was no shortcut (beta then
+ * required): the activation's sign is recomputed from y, which the passes read anyway. */
 int32_t syn_bn_chunks(int64_t rows);
 int syn_bn_act_fwd(const float* y, const float* shortcut, int64_t rows, int32_t channels, const float* gamma, const float* beta, float eps,
                    float momentum, float* run_mean, float* run_var, const float* conv_bias, int32_t act, float* ws, float* stats, float* z,
                    void* stream);
-int syn_bn_act_bwd(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, int64_t rows, int32_t channels,
-                   int32_t act, float* ws, float* dgamma_dbeta, float* dy, float* dshortcut, void* stream);
+int syn_bn_act_bwd(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, const float* beta, int64_t rows,
+                   int32_t channels, int32_t act, float* ws, float* dgamma_dbeta, float* dy, float* dshortcut, void* stream);
 
 /* Backward of an nn.Linear, the operand preparation in one pass over dy [m_rows][n] fp32: its bf16 copy (data-gradient GEMM),
  * the bf16 transpose [n][m_rows] (weight-gradient GEMM) and colsum_part [m_rows / 64][n] = column sums of every 64-row block

@@ -113,7 +113,7 @@ def load():
     lib.syn_cond_encode.argtypes = [C.POINTER(SynCondWeights), vp, vp, vp, vp, i32, vp, vp, vp]
     lib.syn_bn_chunks.argtypes = [C.c_int64]
     lib.syn_bn_act_fwd.argtypes = [vp, vp, C.c_int64, i32, vp, vp, C.c_float, C.c_float, vp, vp, vp, i32, vp, vp, vp, vp]
-    lib.syn_bn_act_bwd.argtypes = [vp, vp, vp, vp, vp, C.c_int64, i32, i32, vp, vp, vp, vp, vp]
+    lib.syn_bn_act_bwd.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, i32, i32, vp, vp, vp, vp, vp]
     lib.syn_linear_bwd_prep.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.syn_pack_weights.argtypes = [vp, i32, C.c_int64, vp]
     lib.syn_conv1d_train_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]

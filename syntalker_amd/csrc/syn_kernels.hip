@@ -2166,16 +2166,17 @@ int syn_bn_act_fwd(const float* y, const float* shortcut, int64_t rows, int32_t 
     return e == hipSuccess ? 0 : fail("syn_bn_act_fwd", e);
 }
 
-int syn_bn_act_bwd(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, int64_t rows, int32_t channels,
-                   int32_t act, float* ws, float* dgamma_dbeta, float* dy, float* dshortcut, void* stream) {
-    if (!dz || !z || !y || !stats || !gamma || !ws || !dgamma_dbeta || !dy || rows <= 0 || channels % 4 || 256 % (channels / 4))
+int syn_bn_act_bwd(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, const float* beta, int64_t rows,
+                   int32_t channels, int32_t act, float* ws, float* dgamma_dbeta, float* dy, float* dshortcut, void* stream) {
+    if (!dz || !y || !stats || !gamma || !ws || !dgamma_dbeta || !dy || rows <= 0 || channels % 4 || 256 % (channels / 4))
         return fail_msg("syn_bn_act_bwd: bad arguments");
+    if (act && !z && (dshortcut || !beta)) return fail_msg("syn_bn_act_bwd: z may only be omitted (with beta given) when no shortcut entered the activation");
     hipStream_t s = (hipStream_t)stream;
     const int chunks = syn_bn_chunks(rows);
-    hipLaunchKernelGGL(trn::k_bn_bwd_stats, dim3(chunks), dim3(256), 0, s, dz, z, y, stats, (long)rows, channels, act, ws);
+    hipLaunchKernelGGL(trn::k_bn_bwd_stats, dim3(chunks), dim3(256), 0, s, dz, z, y, stats, gamma, beta, (long)rows, channels, act, ws);
     hipLaunchKernelGGL(trn::k_bn_bwd_finalize, dim3(channels), dim3(256), 0, s, (const float*)ws, chunks, channels, dgamma_dbeta);
     const long n4 = rows * channels / 4;
-    hipLaunchKernelGGL(trn::k_bn_bwd_apply, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dz, z, y, stats, gamma, (const float*)dgamma_dbeta,
+    hipLaunchKernelGGL(trn::k_bn_bwd_apply, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dz, z, y, stats, gamma, beta, (const float*)dgamma_dbeta,
                        channels, n4, (long)rows, act, dy, dshortcut);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("syn_bn_act_bwd", e);

@@ -504,14 +504,15 @@ class BnActFn(torch.autograd.Function):
         _lib.check(lib.syn_bn_act_fwd(yc.data_ptr(), _lib.ptr(sc), rows, c, g.data_ptr(), b.data_ptr(), float(eps), float(momentum),
                                       _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(cb), int(act), ws.data_ptr(), stats.data_ptr(),
                                       z.data_ptr(), _lib.current_stream(y.device)), "syn_bn_act_fwd")
-        ctx.save_for_backward(yc, z, stats, g)
+        # (without a shortcut the backward recomputes the activation's sign from y and does not read z)
+        ctx.save_for_backward(yc, z if (act and shortcut is not None) else None, stats, g, b)
         ctx.act, ctx.has_short, ctx.has_cb = bool(act), shortcut is not None, conv_bias is not None
         return z
 
     @staticmethod
     def backward(ctx, dz):
         lib = _lib.load()
-        yc, z, stats, g = ctx.saved_tensors
+        yc, z, stats, g, b = ctx.saved_tensors
         n, c, _, l = yc.shape
         rows = n * l
         dzc = dz.contiguous(memory_format=torch.channels_last)
@@ -519,7 +520,7 @@ class BnActFn(torch.autograd.Function):
         dgb = torch.empty(2, c, device=dz.device, dtype=torch.float32)
         dy = torch.empty_like(yc, memory_format=torch.channels_last)
         dsh = torch.empty_like(yc, memory_format=torch.channels_last) if ctx.has_short else None
-        _lib.check(lib.syn_bn_act_bwd(dzc.data_ptr(), z.data_ptr(), yc.data_ptr(), stats.data_ptr(), g.data_ptr(), rows, c, int(ctx.act),
+        _lib.check(lib.syn_bn_act_bwd(dzc.data_ptr(), _lib.ptr(z), yc.data_ptr(), stats.data_ptr(), g.data_ptr(), b.data_ptr(), rows, c, int(ctx.act),
                                       ws.data_ptr(), dgb.data_ptr(), dy.data_ptr(), _lib.ptr(dsh), _lib.current_stream(dz.device)),
                    "syn_bn_act_bwd")
         dcb = torch.zeros(c, device=dz.device, dtype=torch.float32) if ctx.has_cb else None
