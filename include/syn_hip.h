@@ -229,6 +229,10 @@ int syn_bn_act_fwd(const float* y, const float* shortcut, int64_t rows, int32_t 
 int syn_bn_act_bwd(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, const float* beta, int64_t rows,
                    int32_t channels, int32_t act, float* ws, float* dgamma_dbeta, float* dy, float* dshortcut, void* stream);
 
+/* Gradient of an nn.Embedding table (models/denoiser.py:72, the word embedding in front of text_encoder_body): dw [vocab][dim] =
+ * sum over the positions p with ids[p] == v of dy[p][:], added in increasing p (no atomics on the result; every row written).
+ * ids int64 [n_pos] (n_pos <= 8192 per call), dy fp32 [n_pos][dim]. */
+int syn_embedding_wgrad(const int64_t* ids, const float* dy, int32_t n_pos, int32_t vocab, int32_t dim, float* dw, void* stream);
 /* Backward of an nn.Linear, the operand preparation in one pass over dy [m_rows][n] fp32: its bf16 copy (data-gradient GEMM),
  * the bf16 transpose [n][m_rows] (weight-gradient GEMM) and colsum_part [m_rows / 64][n] = column sums of every 64-row block
  * (NULL to skip; the bias gradient is their sum over the first index).  With colsum [n] (and counters: n / 64 ints, zero before the

@@ -2193,6 +2193,15 @@ int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, void* dy_bf1
     return e == hipSuccess ? 0 : fail("k_linear_bwd_prep launch", e);
 }
 
+int syn_embedding_wgrad(const int64_t* ids, const float* dy, int32_t n_pos, int32_t vocab, int32_t dim, float* dw, void* stream) {
+    if (!ids || !dy || !dw || n_pos <= 0 || n_pos > trn::kEmbMaxPos || vocab <= 0 || dim <= 0)
+        return fail_msg("syn_embedding_wgrad: bad arguments (at most 8192 positions per call)");
+    hipLaunchKernelGGL(trn::k_embedding_wgrad, dim3((vocab + trn::kEmbRows - 1) / trn::kEmbRows), dim3(320), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long*>(ids), dy, n_pos, vocab, dim, dw);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_embedding_wgrad launch", e);
+}
+
 int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
     if (!x || !dy || !dx || n <= 0 || n % 4) return fail_msg("syn_gelu_bwd: n must be a positive multiple of 4");
     hipLaunchKernelGGL(trn::k_gelu_bwd, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (size_t)(n / 4));

@@ -201,14 +201,53 @@ class HipLinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+class EmbeddingFn(torch.autograd.Function):
+    """nn.Embedding lookup (models/denoiser.py:72,147: the word ids in front of text_encoder_body) whose table gradient comes from
+    `syn_embedding_wgrad` - one deterministic launch - instead of PyTorch-ROCm's embedding_dense_backward (a chain of ~15 sort /
+    scan / segment launches, and the op that made the captured training step abort in the HIP runtime)."""
+
+    @staticmethod
+    def forward(ctx, ids, weight):
+        ctx.save_for_backward(ids)
+        ctx.wshape, ctx.wdtype = weight.shape, weight.dtype
+        return weight.detach()[ids]
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        V, D = ctx.wshape
+        idc = ids.reshape(-1).to(torch.int64).contiguous()
+        dyc = dy.reshape(-1, D).float().contiguous()
+        dw = torch.empty(V, D, device=dy.device, dtype=torch.float32)
+        lib = _lib.load()
+        first = True
+        for lo in range(0, idc.numel(), 8192):                  # (the bench's 32 clips x 128 frames are one call)
+            n = min(8192, idc.numel() - lo)
+            tgt = dw if first else torch.empty_like(dw)
+            _lib.check(lib.syn_embedding_wgrad(idc[lo:].data_ptr(), dyc[lo:].data_ptr(), n, V, D, tgt.data_ptr(), _lib.current_stream(dy.device)),
+                       "syn_embedding_wgrad")
+            if not first:
+                dw += tgt
+            first = False
+        return None, dw.to(ctx.wdtype)
+
+
+def _embed(module: nn.Embedding, ids):
+    w = module.weight
+    if (w.is_cuda and w.requires_grad and torch.is_grad_enabled() and module.padding_idx is None and module.max_norm is None
+            and not _os.environ.get("SYN_TORCH_EMBEDDING_GRAD")):   # (set: PyTorch's op, to reproduce the captured step's abort)
+        return EmbeddingFn.apply(ids, w)
+    return module(ids)
+
+
 import os as _os
-LINEAR_BWD_PREP = int(_os.environ.get("SYN_LINEAR_BWD_PREP", "1"))    # 0: PyTorch cast / transpose / sum; 1: fused cast + transpose (syn_linear_bwd_prep);
-                                                                      # 3: + the bias gradient from the same launch (last block of a column block adds the partial
-                                                                      #    sums) - correct (test_step_weight_packs_and_in_launch_bias_gradient) but measured 21 us per
-                                                                      #    launch against 4 + 8: the agent-scope release in front of the arrival counter writes the
-                                                                      #    XCD's L2 back; and like 2 it aborts the captured bench-size step;
-                                                                      # 2: + bias-gradient partial sums from the same pass - correct (eager tests), but the captured
-                                                                      # training graph then dies in the HIP runtime with the memory-aperture violation of DESIGN.md 7
+LINEAR_BWD_PREP = int(_os.environ.get("SYN_LINEAR_BWD_PREP", "2"))    # 0: PyTorch cast / transpose / sum; 1: fused cast + transpose (syn_linear_bwd_prep);
+                                                                      # 2: + per-64-row partial column sums from the same pass, the bias gradient = their (16-row) sum;
+                                                                      # 3: the bias gradient itself from that launch (last block of a column block adds the partial
+                                                                      #    sums) - correct (test_step_weight_packs_and_in_launch_bias_gradient) but 21 us per launch
+                                                                      #    against 4 + 4: the agent-scope release in front of the arrival counter writes the XCD's L2 back.
+                                                                      # (2 and 3 used to abort the captured bench-size step: that was PyTorch-ROCm's
+                                                                      #  embedding_dense_backward inside the graph, not these - see EmbeddingFn and DESIGN.md 7)
 
 
 def lin(x, module: nn.Linear):
@@ -619,7 +658,7 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     if a.dim() == 4:
         a = a.squeeze(2)
     a_feat = a.transpose(1, 2).permute(1, 0, 2)                                  # (128, B, 256)
-    w_feat = lin(m.text_pre_encoder_body(word), m.text_encoder_body).permute(1, 0, 2)
+    w_feat = lin(_embed(m.text_pre_encoder_body, word), m.text_encoder_body).permute(1, 0, 2)
     at = lin(torch.cat([a_feat, w_feat], dim=2), m.mix_audio_text)
     at = F.avg_pool1d(at.permute(1, 2, 0), getattr(m.args, "vqvae_squeeze_scale", 4) if not h3d else 4).permute(2, 0, 1)
     xt = x.reshape(bs, C, 1, T).permute(3, 0, 1, 2).reshape(T, bs, C)
@@ -708,13 +747,17 @@ class GraphedTrainStep:
         step = GraphedTrainStep(model, diffusion, optimizer, x0, {"y": y})
         loss = step(x0, t, {"y": y})          # t from the schedule sampler (host RNG, as in the reference)
 
-    Each call waits for its replay to finish: back-to-back un-synchronised replays of this ~1 000-node graph abort in
-    the HIP runtime (HSA memory-aperture violation, reproduced with PyTorch-ROCm ops only), synchronised ones ran 400
-    steps cleanly.  Call `close()` (or let the object die) before interpreter shutdown."""
+    Replays are stream-ordered like any launch; nothing waits for them.  (Round 1 synchronised after every replay because
+    back-to-back replays aborted in the HIP runtime with an HSA memory-aperture violation.  Root cause, found in round 2: the
+    word-embedding gradient - PyTorch-ROCm's embedding_dense_backward, a chain of ~15 sort / scan / segment kernels - does not
+    survive being replayed at the bench size; with `EmbeddingFn` in its place 300 un-synchronised replays run clean, and so do the
+    launch variants that used to trip the same abort.  SYN_TORCH_EMBEDDING_GRAD=1 brings the op back to reproduce it.)
+    Call `close()` (or let the object die) before interpreter shutdown."""
 
     def __init__(self, model, diffusion, optimizer, x0, model_kwargs, grad_norm: float = 0.99, warmup: int = 3, stream=None):
         engine._require_cuda(x0, "x0")
         self.model, self.opt, self.grad_norm, self.diffusion = model, optimizer, grad_norm, diffusion
+        self.sync = bool(_os.environ.get("SYN_TRAIN_GRAPH_SYNC"))   # wait for every replay (not needed: see the class docstring)
         self.wrapped = diffusion._wrap_model(model)          # its timestep map is uploaded once, outside the capture
         self.x0 = x0.detach().clone()
         self.t = torch.zeros(x0.shape[0], dtype=torch.long, device=x0.device)
@@ -745,7 +788,8 @@ class GraphedTrainStep:
             if torch.is_tensor(v):
                 self.y[k].copy_(v)
         self.graph.replay()
-        torch.cuda.current_stream(self.x0.device).synchronize()
+        if self.sync:
+            torch.cuda.current_stream(self.x0.device).synchronize()
         return self.loss
 
     def close(self):

@@ -328,6 +328,35 @@ def test_training_conv_forward_on_split_operands_vs_fp32(cin, stride, cout, pad,
     assert rel_l2(x.grad.cpu(), x2.grad.cpu()) < 1e-5 and rel_l2(w.grad.cpu(), w2.grad.cpu()) < 1e-5
 
 
+def test_embedding_gradient_vs_torch():
+    """syn_embedding_wgrad (training.EmbeddingFn: the word-embedding table's gradient, one deterministic launch) against
+    torch.nn.functional.embedding's autograd: repeated ids, untouched rows exactly zero, a vocabulary that is not a multiple of the
+    block's 16 rows, bitwise run-to-run."""
+    from syntalker_amd import training
+    DEV = "cuda"
+    g = torch.Generator().manual_seed(11)
+    V, D = 11195, 300
+    w = torch.randn(V, D, generator=g).to(DEV).requires_grad_(True)
+    ids = torch.randint(0, V, (32, 128), generator=g)
+    ids[:, :40] = torch.randint(0, 50, (32, 40), generator=g)         # heavy repeats
+    ids[0, 0], ids[0, 1] = 0, V - 1
+    ids = ids.to(DEV)
+    dy = torch.randn(32, 128, D, generator=g).to(DEV)
+    outs = []
+    for _ in range(2):
+        w.grad = None
+        y = training.EmbeddingFn.apply(ids, w)
+        assert torch.equal(y, w.detach()[ids])
+        y.backward(dy)
+        outs.append(w.grad.clone())
+    assert torch.equal(*outs)
+    w2 = w.detach().clone().requires_grad_(True)
+    torch.nn.functional.embedding(ids, w2).backward(dy)
+    assert rel_l2(outs[0].cpu(), w2.grad.cpu()) < 1e-6
+    untouched = torch.ones(V, dtype=torch.bool); untouched[ids.cpu().reshape(-1)] = False
+    assert float(outs[0].cpu()[untouched].abs().max()) == 0.0
+
+
 def test_step_weight_packs_and_in_launch_bias_gradient(monkeypatch):
     """syn_pack_weights (every Linear weight and its transpose as bf16 fragments, one launch) against the per-use packers,
     bitwise; a weight updated in place falls out of the cache until the next refresh; and syn_linear_bwd_prep's bias gradient

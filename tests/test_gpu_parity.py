@@ -514,6 +514,31 @@ def test_graph_replayed_train_step(beatx):
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
 
 
+def test_captured_train_step_at_the_bench_size_replays_back_to_back(beatx):
+    """The whole training step of BASELINE config 3 (32 clips, 68 266 audio samples x 2 channels) captured in one hipGraph and
+    replayed 40 times with NOTHING waiting between the replays.  Round 1 had to synchronise after every replay (HSA
+    memory-aperture violation otherwise, and with the bias-gradient partial sums even then); the op behind it was PyTorch-ROCm's
+    embedding_dense_backward, replaced by training.EmbeddingFn.  Loss finite and falling on a fixed batch."""
+    from syntalker_amd import training
+    from syntalker_amd.process import create_gaussian_diffusion
+    assert training.LINEAR_BWD_PREP >= 2
+    B = 32
+    m = _model("beatx").train()
+    d = create_gaussian_diffusion()
+    opt = torch.optim.Adam(m.parameters(), lr=2e-4, betas=(0.5, 0.999), capturable=True, fused=True)
+    y = synth.to_device(synth.synth_clip_inputs(B, seed=62, mask_batch=B), DEV)
+    y["audio"] = torch.randn(B, 68266, 2, generator=torch.Generator().manual_seed(62)).to(DEV)
+    x0 = synth.synth_latent(B, seed=62, name="x0").to(DEV)
+    t = (torch.arange(B, device=DEV) * 31) % 1000
+    step = training.GraphedTrainStep(m, d, opt, x0, {"y": y})
+    assert not step.sync
+    losses = [step(x0, t, {"y": y}).clone() for _ in range(40)]          # (clones are stream-ordered copies of the static loss)
+    torch.cuda.synchronize()
+    step.close()
+    losses = [float(v) for v in losses]
+    assert all(np.isfinite(losses)) and np.mean(losses[-5:]) < np.mean(losses[:5])
+
+
 def test_ddp_wrapper_inside_the_captured_training_step():
     """One rank over RCCL under torchrun (the GPU boxes have one GPU): `make_ddp(capturable=True)` + `GraphedTrainStep`
     capture the whole step with the wrapper's bucketed all-reduces inside the graph, and replays keep training
