@@ -311,11 +311,11 @@ __device__ __forceinline__ f32x4 randn4(uint64_t seed, uint64_t stream_id, uint6
 }
 
 template <int MT, int EPI>
-__global__ __launch_bounds__(kThreads) void k_gemm(const GArgs a) {
+__device__ __forceinline__ void gemm_body(const GArgs& a, const int bx, const int by) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MF = MT / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lr = lane & 15;
-    const int m0 = blockIdx.x * MT, chunk = blockIdx.y;
+    const int m0 = bx * MT, chunk = by;
     const int KS = a.K / 32;
 
     // Accumulators start from the additive epilogue terms (residual + bias, or conditioning + time row):
@@ -461,6 +461,19 @@ __global__ __launch_bounds__(kThreads) void k_gemm(const GArgs a) {
             }
         }
     }
+}
+
+template <int MT, int EPI>
+__global__ __launch_bounds__(kThreads) void k_gemm(const GArgs a) { gemm_body<MT, EPI>(a, blockIdx.x, blockIdx.y); }
+
+// Two independent plain GEMMs in one launch (grid z picks; x / y sized for the larger): the data-gradient and weight-gradient GEMMs of
+// an nn.Linear's backward are 64 - 128 workgroups each on 256 CUs and do not depend on each other.
+struct GPair { GArgs g[2]; int gx[2], gy[2]; };
+template <int MT>
+__global__ __launch_bounds__(kThreads) void k_gemm_pair(const GPair p) {
+    const int z = blockIdx.z;
+    if ((int)blockIdx.x >= p.gx[z] || (int)blockIdx.y >= p.gy[z]) return;
+    gemm_body<MT, EPI_PLAIN>(p.g[z], blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2094,6 +2107,30 @@ int syn_linear(const void* x_bf16, const void* w_packed, const float* bias, int3
     // the training step's GEMMs have 512 .. 1536 rows: 16-row tiles give 32 .. 96 x (n / 512) workgroups, twice what 32-row ones do
     const int mt = g_linear_mt > 0 ? g_linear_mt : (m_rows <= 2048 ? 16 : pick_tile(m_rows));
     return launch_gemm<EPI_PLAIN>(a, mt, n / kNT, (hipStream_t)stream);
+}
+
+int syn_linear_pair(const void* x1_bf16, const void* w1_packed, int32_t m1, int32_t n1, int32_t k1, float* y1,
+                    const void* x2_bf16, const void* w2_packed, int32_t m2, int32_t n2, int32_t k2, float* y2, void* stream) {
+    if (!x1_bf16 || !w1_packed || !y1 || !x2_bf16 || !w2_packed || !y2 || n1 % kNT || n2 % kNT || k1 % 128 || k2 % 128 || m1 <= 0 || m2 <= 0)
+        return fail_msg("syn_linear_pair: need n % 512 == 0, k % 128 == 0, m_rows > 0 and non-null pointers");
+    if (m1 > 2048 || m2 > 2048 || g_linear_mt > 0) {                 // larger row tiles: two launches
+        if (int rc = syn_linear(x1_bf16, w1_packed, nullptr, m1, n1, k1, y1, stream)) return rc;
+        return syn_linear(x2_bf16, w2_packed, nullptr, m2, n2, k2, y2, stream);
+    }
+    GPair p;
+    memset(&p, 0, sizeof(p));
+    const void* xs[2] = {x1_bf16, x2_bf16}; const void* ws[2] = {w1_packed, w2_packed};
+    const int ms[2] = {m1, m2}, ns[2] = {n1, n2}, ks[2] = {k1, k2}; float* ys[2] = {y1, y2};
+    for (int i = 0; i < 2; ++i) {
+        GArgs& a = p.g[i];
+        a.X = (const __bf16*)xs[i]; a.ldx = ks[i]; a.x_rows = ms[i]; a.W = (const uint4*)ws[i]; a.K = ks[i]; a.M = ms[i];
+        a.Yf = ys[i]; a.ldyf = ns[i];
+        p.gx[i] = (ms[i] + 15) / 16; p.gy[i] = ns[i] / kNT;
+    }
+    const dim3 grid(p.gx[0] > p.gx[1] ? p.gx[0] : p.gx[1], p.gy[0] > p.gy[1] ? p.gy[0] : p.gy[1], 2);
+    hipLaunchKernelGGL((k_gemm_pair<16>), grid, dim3(kThreads), 2 * 32 * 128 + 1024, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_gemm_pair launch", e);
 }
 
 void syn_debug_linear_tile(int rows) { g_linear_mt = rows; }       /* diagnostics: pin syn_linear's row tile (16 / 32 / 64 / 128), 0 = automatic */

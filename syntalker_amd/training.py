@@ -185,6 +185,19 @@ class HipLinearFn(torch.autograd.Function):
                 db = part.sum(0)
         else:
             dyb = dy2.to(torch.bfloat16).contiguous()
+        if (LINEAR_BWD_PAIR and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dybt is not None and K % 512 == 0 and N % 128 == 0
+                and M % 128 == 0 and w.dtype is torch.float32 and w.is_contiguous() and xb.is_contiguous()):
+            # dy . W and dy^T . x - independent, half a chip each - as one launch
+            wt = ctx.pack_t if ctx.pack_t is not None else _pack_t(w, K, N)
+            dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+            dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+            _lib.check(_lib.load().syn_linear_pair(dyb.data_ptr(), wt.data_ptr(), M, K, N, dx.data_ptr(),
+                                                   dybt.data_ptr(), _pack_t(xb, K, M).data_ptr(), N, K, M, dw.data_ptr(),
+                                                   _lib.current_stream(dy.device)), "syn_linear_pair")
+            dx = dx.reshape(ctx.in_shape)
+            if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
+                db = dy2.sum(0)
+            return dx, dw.to(w.dtype), db
         if ctx.needs_input_grad[0]:
             if K % 512 == 0 and N % 128 == 0 and w.dtype is torch.float32 and w.is_contiguous():
                 wt = ctx.pack_t if ctx.pack_t is not None else _pack_t(w, K, N)          # W^T: the step's pack, or packed in place
@@ -241,6 +254,7 @@ def _embed(module: nn.Embedding, ids):
 
 
 import os as _os
+LINEAR_BWD_PAIR = bool(int(_os.environ.get("SYN_LINEAR_BWD_PAIR", "1")))   # a Linear's two backward GEMMs as one launch (syn_linear_pair)
 LINEAR_BWD_PREP = int(_os.environ.get("SYN_LINEAR_BWD_PREP", "2"))    # 0: PyTorch cast / transpose / sum; 1: fused cast + transpose (syn_linear_bwd_prep);
                                                                       # 2: + per-64-row partial column sums from the same pass, the bias gradient = their (16-row) sum;
                                                                       # 3: the bias gradient itself from that launch (last block of a column block adds the partial
