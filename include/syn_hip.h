@@ -208,10 +208,11 @@ int syn_pack_weights(const syn_pack_job* jobs_dev, int32_t n_jobs, int64_t max_f
 
 /* ---- training path: fp32 forward / backward of the non-GEMM pieces of a transformer block ----
  * LayerNorm(512, eps 1e-5) of `rows` rows (models/timm_transformer/transformer.py:160,162,183,193); the backward
- * needs scratch of ceil(rows/64)*1024 floats and writes dgamma[512], dbeta[512] (deterministic two-stage sums). */
+ * needs scratch of ceil(rows/16)*1024 floats and writes dgamma[512], dbeta[512] (deterministic two-stage sums); `add` (NULL or
+ * [rows][512]) is added to dx: the gradient that reaches x along the block's residual connection (transformer.py:195-198). */
 int syn_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int32_t rows, void* stream);
-int syn_ln_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma,
-               float* dbeta, float* scratch, int32_t rows, void* stream);
+int syn_ln_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* add, float* dx,
+               float* dgamma, float* dbeta, float* scratch, int32_t rows, void* stream);
 /* nn.GELU() (exact erf form, transformer.py:117-151), n % 4 == 0 elements. */
 int syn_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);

@@ -105,7 +105,7 @@ def load():
     lib.syn_step_advance.argtypes = [vp, vp, vp, i32, vp, i32, vp]
     lib.syn_steps_advance.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp]
     lib.syn_ln_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp]
-    lib.syn_ln_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    lib.syn_ln_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.syn_gelu_fwd.argtypes = [vp, vp, i64, vp]
     lib.syn_gelu_bwd.argtypes = [vp, vp, vp, i64, vp]
     lib.syn_attn_fwd.argtypes = [vp, vp, i32, vp]

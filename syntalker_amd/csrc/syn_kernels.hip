@@ -2166,12 +2166,13 @@ int syn_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, 
     return e == hipSuccess ? 0 : fail("k_ln_fwd launch", e);
 }
 
-int syn_ln_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma,
-               float* dbeta, float* scratch, int32_t rows, void* stream) {
+int syn_ln_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* add, float* dx,
+               float* dgamma, float* dbeta, float* scratch, int32_t rows, void* stream) {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !scratch || rows <= 0) return fail_msg("syn_ln_bwd: bad arguments");
-    const int per = 64, nwg = (rows + per - 1) / per;             // scratch: [nwg][2][512] floats
+    const int per = 16, nwg = (rows + per - 1) / per;             // scratch: [nwg][2][512] floats (16 rows per workgroup: 1024 rows = 64 workgroups;
+                                                                  // with 64 rows the 16 workgroups walked their rows one dependent load after the other, 14 us)
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(trn::k_ln_bwd, dim3(nwg), dim3(256), 0, s, dy, x, gamma, mean, rstd, dx, scratch, rows, per);
+    hipLaunchKernelGGL(trn::k_ln_bwd, dim3(nwg), dim3(256), 0, s, dy, x, gamma, mean, rstd, add, dx, scratch, rows, per);
     hipLaunchKernelGGL(trn::k_colsum, dim3(4), dim3(256), 0, s, scratch, nwg, 2 * SYN_D, SYN_D, dgamma, dbeta);   // partials [p][dgamma | dbeta]
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_ln_bwd launch", e);

@@ -297,15 +297,37 @@ class HipLayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        dx, dg, db = HipLayerNormFn._bwd(ctx, dy, None)
+        return dx, dg, db
+
+    @staticmethod
+    def _bwd(ctx, dy, dres):
         xc, gc, mean, rstd = ctx.saved_tensors
         rows = xc.shape[0]
         dyc = _f32c(dy).view(-1, 512)
+        add = None if dres is None else _f32c(dres).view(-1, 512)
         dx = torch.empty_like(xc)
         dg, db = torch.empty(512, device=dy.device), torch.empty(512, device=dy.device)
-        scratch = torch.empty((rows + 63) // 64 * 1024, device=dy.device)
-        _lib.check(_lib.load().syn_ln_bwd(dyc.data_ptr(), xc.data_ptr(), gc.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-                                          dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), rows, _lib.current_stream(dx.device)), "syn_ln_bwd")
+        scratch = torch.empty((rows + 15) // 16 * 1024, device=dy.device)
+        _lib.check(_lib.load().syn_ln_bwd(dyc.data_ptr(), xc.data_ptr(), gc.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _lib.ptr(add),
+                                          dx.data_ptr(), dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), rows, _lib.current_stream(dx.device)),
+                   "syn_ln_bwd")
         return dx.view(dy.shape), dg, db
+
+
+class HipLnForkFn(torch.autograd.Function):
+    """A pre-LN residual block's entry (transformer.py:195-198: x + f(norm(x))): returns (LayerNorm(x), x).  x feeds both the
+    norm and the residual add, and autograd would add the two gradients with a copy and an in-place add per block half; here the
+    residual path's gradient goes into the LayerNorm backward kernel as its addend - one gradient for x, no extra launch."""
+
+    @staticmethod
+    def forward(ctx, x, g, b):
+        y = HipLayerNormFn.forward(ctx, x, g, b)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        return HipLayerNormFn._bwd(ctx, dy, dres)
 
 
 class HipGeluFn(torch.autograd.Function):
@@ -697,11 +719,11 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
         dp = h.new_empty(2 * len(m.mytimmblocks), bs, 1, 1).bernoulli_(keep).div_(keep)
     for i, blk in enumerate(m.mytimmblocks):
         if HIP_BLOCK_OPS:
-            z = HipLayerNormFn.apply(h, blk.norm1.weight, blk.norm1.bias)
+            z, h = HipLnForkFn.apply(h, blk.norm1.weight, blk.norm1.bias)
             o = HipAttentionFn.apply(lin(z, blk.attn.qkv))           # (B, T, 3 x 4 heads x 128) -> (B, T, 512)
             br = lin(o, blk.attn.proj)
             h = h + br if dp is None else torch.addcmul(h, br, dp[2 * i])
-            z = HipLayerNormFn.apply(h, blk.norm2.weight, blk.norm2.bias)
+            z, h = HipLnForkFn.apply(h, blk.norm2.weight, blk.norm2.bias)
             br = lin(HipGeluFn.apply(lin(z, blk.mlp.fc1)), blk.mlp.fc2)
             h = h + br if dp is None else torch.addcmul(h, br, dp[2 * i + 1])
         else:
