@@ -2249,7 +2249,9 @@ int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* st
 
 int syn_attn_fwd(const float* qkv, float* o, int32_t n_seq, void* stream) {
     if (!qkv || !o || n_seq <= 0) return fail_msg("syn_attn_fwd: bad arguments");
-    hipLaunchKernelGGL(trn::k_attn_fwd, dim3(n_seq * SYN_HEADS), dim3(256), 0, (hipStream_t)stream, qkv, o);
+    static const bool v1 = getenv("SYN_ATTN_BWD_V1") != nullptr;    // diagnostics: the first version of the kernels
+    if (v1) hipLaunchKernelGGL(trn::k_attn_fwd, dim3(n_seq * SYN_HEADS), dim3(256), 0, (hipStream_t)stream, qkv, o);
+    else hipLaunchKernelGGL(trn::k_attn_fwd2, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnFwd2Lds, (hipStream_t)stream, qkv, o);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_attn_fwd launch", e);
 }
@@ -2257,8 +2259,10 @@ int syn_attn_fwd(const float* qkv, float* o, int32_t n_seq, void* stream) {
 int syn_attn_bwd(const float* qkv, const float* d_o, float* dqkv, int32_t n_seq, void* stream) {
     if (!qkv || !d_o || !dqkv || n_seq <= 0) return fail_msg("syn_attn_bwd: bad arguments");
     static bool once = false;
-    if (!once) { allow_lds(trn::k_attn_bwd, trn::kAttnBwdLds); once = true; }
-    hipLaunchKernelGGL(trn::k_attn_bwd, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnBwdLds, (hipStream_t)stream, qkv, d_o, dqkv);
+    static const bool v1 = getenv("SYN_ATTN_BWD_V1") != nullptr;    // diagnostics: the first version of the kernel (one LDS float per FMA)
+    if (!once) { allow_lds(trn::k_attn_bwd, trn::kAttnBwdLds); allow_lds(trn::k_attn_bwd2, trn::kAttnBwd2Lds); once = true; }
+    if (v1) hipLaunchKernelGGL(trn::k_attn_bwd, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnBwdLds, (hipStream_t)stream, qkv, d_o, dqkv);
+    else hipLaunchKernelGGL(trn::k_attn_bwd2, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnBwd2Lds, (hipStream_t)stream, qkv, d_o, dqkv);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_attn_bwd launch", e);
 }
