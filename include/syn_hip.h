@@ -371,6 +371,10 @@ int syn_vq_codes(const int32_t* idx, const float* codebooks, float* q_f32, void*
  * models/timm_transformer/transformer.py:85,102,146,149 and models/denoiser.py:148,162,170,195 in training. */
 int syn_linear(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k, float* y,
                void* stream);
+/* syn_linear and, in the same launch, syn_pack_weight_t(x_bf16, 1, k, m_rows, xt_packed): the fragments of x^T the weight-gradient
+ * GEMM of the backward will take, packed in the shadow of the forward GEMM (which fills a quarter to three quarters of the chip). */
+int syn_linear_and_pack(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k, float* y,
+                        void* xt_packed, void* stream);
 /* Two independent syn_linear calls (no bias) as ONE launch: the data-gradient GEMM dy . W and the weight-gradient GEMM dy^T . x of
  * an nn.Linear's backward fill half the chip each and do not depend on each other.  Same result as two calls, bitwise. */
 int syn_linear_pair(const void* x1_bf16, const void* w1_packed, int32_t m1, int32_t n1, int32_t k1, float* y1,

@@ -71,6 +71,18 @@ struct GArgs {
     int ablate;   // diagnostics (syn_test_gemm only): 1 = weights loaded once, 2 = activations staged once, 4 = no store
 };
 
+// Rotary pair (models/denoiser.py:178-186) with its roundings pinned: u' = fma(u, cos, -(w sin)), w' = fma(w, cos, u sin), the
+// inner products rounded on their own.  Written out because the whole-step kernel and the per-layer kernels must round alike
+// (test_fused_layer_kernels_equal_unfused_bitwise) and the compiler's choice of which product to fuse moved with an unrelated edit.
+__device__ __forceinline__ void rotary4(f32x4& u, f32x4& w, const f32x4 cs, const f32x4 sn) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ws = __fmul_rn(w[e], sn[e]), us = __fmul_rn(u[e], sn[e]);
+        const float a = __builtin_fmaf(u[e], cs[e], -ws), b = __builtin_fmaf(w[e], cs[e], us);
+        u[e] = a; w[e] = b;
+    }
+}
+
 __device__ __forceinline__ bf16x4 to_bf16x4(f32x4 v) {
     bf16x4 r;
     r[0] = (__bf16)v[0]; r[1] = (__bf16)v[1]; r[2] = (__bf16)v[2]; r[3] = (__bf16)v[3];
@@ -390,9 +402,7 @@ __device__ __forceinline__ void gemm_body(const GArgs& a, const int bx, const in
                 const int j = nf * 16 + g * 4;
                 const f32x4 cs = *reinterpret_cast<const f32x4*>(a.rcos + pos * 32 + j);
                 const f32x4 sn = *reinterpret_cast<const f32x4*>(a.rsin + pos * 32 + j);
-                const f32x4 u = acc[nf][mf], w = acc[nf + 2][mf];
-                acc[nf][mf] = u * cs - w * sn;
-                acc[nf + 2][mf] = w * cs + u * sn;
+                rotary4(acc[nf][mf], acc[nf + 2][mf], cs, sn);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -474,6 +484,24 @@ __global__ __launch_bounds__(kThreads) void k_gemm_pair(const GPair p) {
     const int z = blockIdx.z;
     if ((int)blockIdx.x >= p.gx[z] || (int)blockIdx.y >= p.gy[z]) return;
     gemm_body<MT, EPI_PLAIN>(p.g[z], blockIdx.x, blockIdx.y);
+}
+
+// A forward GEMM of the training step fills a quarter to three quarters of the chip (16-row tiles x n / 512 columns), and the
+// backward will need x^T as packed fragments (the weight-gradient GEMM's B operand): grid z = 1 packs them in the GEMM's shadow.
+struct GPack { GArgs g; const __bf16* src; uint4* out; int n, k; };          // pack: fragments of W = src^T, src row-major [k][n] (k_pack_t)
+template <int MT>
+__global__ __launch_bounds__(kThreads) void k_gemm_and_pack(const GPack p) {
+    if (blockIdx.z == 0) { gemm_body<MT, EPI_PLAIN>(p.g, blockIdx.x, blockIdx.y); return; }
+    const int KS = p.k / 32, total = (p.n / 16) * KS * 64;
+    const int stride = gridDim.x * gridDim.y * kThreads;
+    for (int idx = (blockIdx.y * gridDim.x + blockIdx.x) * kThreads + threadIdx.x; idx < total; idx += stride) {
+        const int lane = idx & 63, f = idx >> 6, ks = f % KS, nf = f / KS;
+        const __bf16* src = p.src + (size_t)(32 * ks + 8 * (lane >> 4)) * p.n + 16 * nf + (lane & 15);
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = src[(size_t)e * p.n];
+        p.out[idx] = __builtin_bit_cast(uint4, r);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1126,9 +1154,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
                 const int j = nf * 16 + g * 4;
                 const f32x4 cs = *reinterpret_cast<const f32x4*>(a.in.rcos + pos * 32 + j);
                 const f32x4 sn = *reinterpret_cast<const f32x4*>(a.in.rsin + pos * 32 + j);
-                const f32x4 u = h[nf][mf], w = h[nf + 2][mf];
-                h[nf][mf] = u * cs - w * sn;
-                h[nf + 2][mf] = w * cs + u * sn;
+                rotary4(h[nf][mf], h[nf + 2][mf], cs, sn);
             }
         }
     } else {
@@ -2107,6 +2133,25 @@ int syn_linear(const void* x_bf16, const void* w_packed, const float* bias, int3
     // the training step's GEMMs have 512 .. 1536 rows: 16-row tiles give 32 .. 96 x (n / 512) workgroups, twice what 32-row ones do
     const int mt = g_linear_mt > 0 ? g_linear_mt : (m_rows <= 2048 ? 16 : pick_tile(m_rows));
     return launch_gemm<EPI_PLAIN>(a, mt, n / kNT, (hipStream_t)stream);
+}
+
+int syn_linear_and_pack(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k, float* y,
+                        void* xt_packed, void* stream) {
+    if (!x_bf16 || !w_packed || !y || !xt_packed || n % kNT || k % 128 || m_rows <= 0 || m_rows % 32 || k % 16)
+        return fail_msg("syn_linear_and_pack: need n % 512 == 0, k % 128 == 0, m_rows % 32 == 0 and non-null pointers");
+    if (m_rows > 2048 || g_linear_mt > 0) {                          // larger row tiles: two launches
+        if (int rc = syn_linear(x_bf16, w_packed, bias, m_rows, n, k, y, stream)) return rc;
+        return syn_pack_weight_t(x_bf16, 1, k, m_rows, xt_packed, stream);
+    }
+    GPack p;
+    memset(&p, 0, sizeof(p));
+    GArgs& a = p.g;
+    a.X = (const __bf16*)x_bf16; a.ldx = k; a.x_rows = m_rows; a.W = (const uint4*)w_packed; a.K = k; a.M = m_rows;
+    a.bias = bias; a.Yf = y; a.ldyf = n;
+    p.src = (const __bf16*)x_bf16; p.out = (uint4*)xt_packed; p.n = k; p.k = m_rows;     // x [m][k] is the row-major [k' = m][n' = k] of x^T [k][m]
+    hipLaunchKernelGGL((k_gemm_and_pack<16>), dim3((m_rows + 15) / 16, n / kNT, 2), dim3(kThreads), 2 * 32 * 128 + 1024, (hipStream_t)stream, p);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_gemm_and_pack launch", e);
 }
 
 int syn_linear_pair(const void* x1_bf16, const void* w1_packed, int32_t m1, int32_t n1, int32_t k1, float* y1,

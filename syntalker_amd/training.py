@@ -149,13 +149,22 @@ class HipLinearFn(torch.autograd.Function):
         K = x.shape[-1]
         xb = x.reshape(-1, K).to(torch.bfloat16)
         pk, ctx.pack_t = _lookup_packs(w)
+        xt = None
         if pk is not None and (b is None or (b.dtype is torch.float32 and b.is_contiguous())):
             xb = xb.contiguous()
-            y = torch.empty(xb.shape[0], w.shape[0], dtype=torch.float32, device=x.device)
-            _lib.check(_lib.load().syn_linear(xb.data_ptr(), pk.data_ptr(), _lib.ptr(b), xb.shape[0], w.shape[0], K, y.data_ptr(),
-                                              _lib.current_stream(y.device)), "syn_linear")
+            M = xb.shape[0]
+            y = torch.empty(M, w.shape[0], dtype=torch.float32, device=x.device)
+            if LINEAR_FWD_PACK and ctx.needs_input_grad[1] and K % 512 == 0 and M % 128 == 0 and M <= 2048:
+                # the weight gradient's B operand (x^T as fragments) packed in the shadow of this GEMM instead of by a launch in the backward
+                xt = torch.empty(K * M * 2, dtype=torch.uint8, device=x.device)
+                _lib.check(_lib.load().syn_linear_and_pack(xb.data_ptr(), pk.data_ptr(), _lib.ptr(b), M, w.shape[0], K, y.data_ptr(), xt.data_ptr(),
+                                                           _lib.current_stream(y.device)), "syn_linear_and_pack")
+            else:
+                _lib.check(_lib.load().syn_linear(xb.data_ptr(), pk.data_ptr(), _lib.ptr(b), M, w.shape[0], K, y.data_ptr(),
+                                                  _lib.current_stream(y.device)), "syn_linear")
         else:
             y = hip_matmul_nt(xb, w, b)
+        ctx.xt = xt
         ctx.save_for_backward(xb, w)
         ctx.has_bias = b is not None
         ctx.in_shape = x.shape
@@ -192,7 +201,7 @@ class HipLinearFn(torch.autograd.Function):
             dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
             dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
             _lib.check(_lib.load().syn_linear_pair(dyb.data_ptr(), wt.data_ptr(), M, K, N, dx.data_ptr(),
-                                                   dybt.data_ptr(), _pack_t(xb, K, M).data_ptr(), N, K, M, dw.data_ptr(),
+                                                   dybt.data_ptr(), (ctx.xt if ctx.xt is not None else _pack_t(xb, K, M)).data_ptr(), N, K, M, dw.data_ptr(),
                                                    _lib.current_stream(dy.device)), "syn_linear_pair")
             dx = dx.reshape(ctx.in_shape)
             if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
@@ -254,6 +263,7 @@ def _embed(module: nn.Embedding, ids):
 
 
 import os as _os
+LINEAR_FWD_PACK = bool(int(_os.environ.get("SYN_LINEAR_FWD_PACK", "1")))   # x^T fragments for the weight gradient from the forward GEMM's launch
 LINEAR_BWD_PAIR = bool(int(_os.environ.get("SYN_LINEAR_BWD_PAIR", "1")))   # a Linear's two backward GEMMs as one launch (syn_linear_pair)
 LINEAR_BWD_PREP = int(_os.environ.get("SYN_LINEAR_BWD_PREP", "2"))    # 0: PyTorch cast / transpose / sum; 1: fused cast + transpose (syn_linear_bwd_prep);
                                                                       # 2: + per-64-row partial column sums from the same pass, the bias gradient = their (16-row) sum;

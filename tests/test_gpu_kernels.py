@@ -397,6 +397,13 @@ def test_step_weight_packs_and_in_launch_bias_gradient(monkeypatch):
         training.HipLinearFn.apply(x, w, b).backward(dy)
         assert torch.equal(x.grad, grads[0][1]) and torch.equal(w.grad, grads[0][2])
         monkeypatch.setattr(training, "LINEAR_BWD_PAIR", True)
+        monkeypatch.setattr(training, "LINEAR_FWD_PACK", False)      # x^T packed by its own launch in the backward: the same bits
+        w.grad = b.grad = x.grad = None
+        y2 = training.HipLinearFn.apply(x, w, b)
+        y2.backward(dy)
+        assert torch.equal(x.grad, grads[0][1]) and torch.equal(w.grad, grads[0][2])
+        monkeypatch.setattr(training, "LINEAR_FWD_PACK", True)
+        assert torch.equal(y2, training.HipLinearFn.apply(x, w, b))
         assert rel_l2(grads[0][0].cpu(), dy.sum(0).cpu()) < 1e-6
         xb, wb, dyb = x.detach().bfloat16().float(), w.detach().bfloat16().float(), dy.bfloat16().float()
         assert rel_l2(grads[0][1].cpu(), (dyb @ wb).cpu()) < 1e-5 and rel_l2(grads[0][2].cpu(), (dyb.t() @ xb).cpu()) < 1e-5
