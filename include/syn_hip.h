@@ -198,7 +198,11 @@ int64_t syn_conv1d_pack_bytes(int32_t cout, int32_t cin, int32_t stride, int32_t
 int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t cout,
                                    const void* w_hi, const void* w_lo, float* dx, void* stream);
 int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
-                         const void* w_hi, const void* w_lo, const float* bias, int32_t cout, float* y, void* stream);
+                         const void* w_hi, const void* w_lo, const float* bias, int32_t cout, float* y, float* bn_part, void* stream);
+/* bn_part (NULL, or syn_conv1d_train_fwd_tiles(...) x 2 x cout floats; bias must then be NULL): per-workgroup sum and sum of squares
+ * of every output channel, straight from the accumulators - the BatchNorm that follows takes them as syn_bn_act_fwd's ws with
+ * ws_chunks = that tile count and skips its own pass over y. */
+int32_t syn_conv1d_train_fwd_tiles(int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, int32_t cout);
 
 /* Every bf16 fragment set the training step's Linear layers need, from the fp32 master weights in ONE launch (the weights change
  * once per step, in optimizer.step()): job j packs src (n x k row-major, transposed = 0: as syn_pack_weight; k x n row-major,
@@ -225,8 +229,8 @@ int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* st
  * required): the activation's sign is recomputed from y, which the passes read anyway. */
 int32_t syn_bn_chunks(int64_t rows);
 int syn_bn_act_fwd(const float* y, const float* shortcut, int64_t rows, int32_t channels, const float* gamma, const float* beta, float eps,
-                   float momentum, float* run_mean, float* run_var, const float* conv_bias, int32_t act, float* ws, float* stats, float* z,
-                   void* stream);
+                   float momentum, float* run_mean, float* run_var, const float* conv_bias, int32_t act, float* ws, int32_t ws_chunks, float* stats,
+                   float* z, void* stream);
 int syn_bn_act_bwd(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, const float* beta, int64_t rows,
                    int32_t channels, int32_t act, float* ws, float* dgamma_dbeta, float* dy, float* dshortcut, void* stream);
 

@@ -2233,13 +2233,14 @@ int syn_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
 int32_t syn_bn_chunks(int64_t rows) { return (int32_t)((rows + trn::kBnRows - 1) / trn::kBnRows); }
 
 int syn_bn_act_fwd(const float* y, const float* shortcut, int64_t rows, int32_t channels, const float* gamma, const float* beta, float eps,
-                   float momentum, float* run_mean, float* run_var, const float* conv_bias, int32_t act, float* ws, float* stats, float* z,
-                   void* stream) {
+                   float momentum, float* run_mean, float* run_var, const float* conv_bias, int32_t act, float* ws, int32_t ws_chunks, float* stats,
+                   float* z, void* stream) {
     if (!y || !gamma || !beta || !ws || !stats || !z || rows <= 0 || channels <= 0 || channels % 4 || 256 % (channels / 4) || channels > 1024)
         return fail_msg("syn_bn_act_fwd: need channels in {4 .. 1024} with channels / 4 dividing 256, rows > 0, non-null pointers");
     hipStream_t s = (hipStream_t)stream;
-    const int chunks = syn_bn_chunks(rows);
-    hipLaunchKernelGGL(trn::k_bn_stats, dim3(chunks), dim3(256), 0, s, y, (long)rows, channels, ws);
+    // ws_chunks > 0: ws already holds that many [2][channels] partial sums (written by the convolution's epilogue, syn_conv1d_train_fwd)
+    const int chunks = ws_chunks > 0 ? ws_chunks : syn_bn_chunks(rows);
+    if (ws_chunks <= 0) hipLaunchKernelGGL(trn::k_bn_stats, dim3(chunks), dim3(256), 0, s, y, (long)rows, channels, ws);
     hipLaunchKernelGGL(trn::k_bn_finalize, dim3(channels), dim3(256), 0, s, (const float*)ws, chunks, channels, (long)rows, eps, momentum,
                        stats, run_mean, run_var, conv_bias);
     const long n4 = rows * channels / 4;
@@ -2515,7 +2516,7 @@ int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_i
         a.X = dy; a.x_clip_stride = (long)l_out * cout; a.x_elems = (long)l_out * cout; a.row0 = -(kt - 1); a.L_out = q_rows;
         const size_t frag0 = (size_t)(c0 / 16) * (kt * cout / 32) * 64;
         a.Whi = (const uint4*)w_hi + frag0; a.Wlo = (const uint4*)w_lo + frag0; a.bias = nullptr;
-        a.Y = dx; a.y_clip_stride = (long)l_in * cin; a.y_pitch = np; a.y_col0 = c0; a.y_elems = (long)l_in * cin;
+        a.Y = dx; a.y_clip_stride = (long)l_in * cin; a.y_pitch = np; a.y_col0 = c0; a.y_elems = (long)l_in * cin; a.bn_part = nullptr;
         int rc;
         if (cout == 64 && kt == 3) rc = launch_conv_train<64, 3, 2, 2, 4>(a, n_clips, s);
         else if (cout == 128 && kt == 3) rc = launch_conv_train<128, 3, 2, 2, 4>(a, n_clips, s);
@@ -2526,8 +2527,21 @@ int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_i
     return 0;
 }
 
+// positions per workgroup tile of syn_conv1d_train_fwd's kernel instance (0: not one of the encoder's layers)
+static int conv_train_tile(int cinp, int stride, int cout) {
+    if (cinp == 64 && stride == 1 && cout == 64) return 256;
+    if (cinp == 128 && stride == 1 && cout == 128) return 128;
+    if ((cinp == 256 && stride == 1 && cout == 256) || (cinp == 384 && (stride == 6 || stride == 3))) return 64;
+    return 0;
+}
+
+int32_t syn_conv1d_train_fwd_tiles(int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, int32_t cout) {
+    const int mw = conv_train_tile(stride * cin, stride, cout), l_out = (l_in + 2 * pad - 15) / stride + 1;
+    return mw && l_out > 0 && n_clips > 0 ? n_clips * ((l_out + mw - 1) / mw) : 0;
+}
+
 int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
-                         const void* w_hi, const void* w_lo, const float* bias, int32_t cout, float* y, void* stream) {
+                         const void* w_hi, const void* w_lo, const float* bias, int32_t cout, float* y, float* bn_part, void* stream) {
     if (!x || !w_hi || !w_lo || !y || n_clips <= 0 || l_in <= 0) return fail_msg("syn_conv1d_train_fwd: null pointer / empty batch");
     if (stride < 1 || pad < 0 || pad % stride) return fail_msg("syn_conv1d_train_fwd: padding must be a multiple of the stride");
     const int l_out = (l_in + 2 * pad - 15) / stride + 1;
@@ -2535,7 +2549,8 @@ int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
     wav::TArgs a;
     a.X = x; a.x_clip_stride = (long)l_in * cin; a.x_elems = (long)l_in * cin; a.row0 = -pad / stride; a.L_out = l_out;
     a.Whi = (const uint4*)w_hi; a.Wlo = (const uint4*)w_lo; a.bias = bias; a.Y = y; a.y_clip_stride = (long)l_out * cout;
-    a.y_pitch = 0; a.y_col0 = 0; a.y_elems = 0;
+    a.y_pitch = 0; a.y_col0 = 0; a.y_elems = 0; a.bn_part = bn_part;
+    if (bn_part && bias) return fail_msg("syn_conv1d_train_fwd: the statistics are those of the convolution without its bias (pass bias = NULL)");
     hipStream_t s = (hipStream_t)stream;
     const int cinp = stride * cin;
     // (rows of stride * cin floats, ceil(15 / stride) taps; tiles as the eval-mode encoder picks them, halved where two planes

@@ -447,7 +447,7 @@ class ConvSplitFn(torch.autograd.Function):
     SUPPORTED = {(64, 1, 64), (128, 1, 128), (256, 1, 256), (64, 6, 64), (64, 6, 128), (128, 3, 256)}
 
     @staticmethod
-    def run(x, w, stride, pad, transposed=False):
+    def run(x, w, stride, pad, transposed=False, want_stats=False):
         """y = conv(x, w) for x (N, Cin, 1, L) channels_last fp32 and the module's weight w (Cout, Cin, 1, 15);
         transposed: y = the data gradient of that (stride-1, padding-7) convolution for x = dy (N, Cout, 1, L)."""
         lib = _lib.load()
@@ -464,13 +464,20 @@ class ConvSplitFn(torch.autograd.Function):
                                              _lib.current_stream(x.device)), "syn_conv1d_pack_split")
         l_out = (l_in + 2 * pad - 15) // stride + 1
         y = torch.empty(n, cout, 1, l_out, device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        part = None
+        if want_stats and WAV_CONV_BN_STATS:
+            # BatchNorm's per-channel sums from the convolution's accumulators: the BatchNorm that follows skips its pass over y
+            tiles = lib.syn_conv1d_train_fwd_tiles(n, l_in, cin, stride, pad, cout)
+            part = torch.empty(tiles, 2, cout, device=x.device, dtype=torch.float32)
         _lib.check(lib.syn_conv1d_train_fwd(xc.data_ptr(), n, l_in, cin, stride, pad, whi.data_ptr(), wlo.data_ptr(), None, cout,
-                                                    y.data_ptr(), _lib.current_stream(x.device)), "syn_conv1d_train_fwd")
+                                                    y.data_ptr(), _lib.ptr(part), _lib.current_stream(x.device)), "syn_conv1d_train_fwd")
+        if part is not None:
+            y._syn_bn_part = part                                            # picked up by BnActFn.forward (same tensor object)
         return xc, y
 
     @staticmethod
     def forward(ctx, x, w, stride, pad):
-        xc, y = ConvSplitFn.run(x, w, stride, pad)
+        xc, y = ConvSplitFn.run(x, w, stride, pad, want_stats=True)
         ctx.save_for_backward(xc, w)
         ctx.geom = (stride, pad)
         return y
@@ -581,13 +588,17 @@ class BnActFn(torch.autograd.Function):
         yc = y.contiguous(memory_format=torch.channels_last)
         sc = None if shortcut is None else shortcut.contiguous(memory_format=torch.channels_last)
         rows = n * l
-        ws = torch.empty(2 * lib.syn_bn_chunks(rows) * c, device=y.device, dtype=torch.float32)
+        part = getattr(y, "_syn_bn_part", None)                  # the producing convolution's per-tile sums (ConvSplitFn.run)
+        if part is not None and part.shape[2] == c and part.device == y.device:
+            ws, ws_chunks = part, part.shape[0]
+        else:
+            ws, ws_chunks = torch.empty(2 * lib.syn_bn_chunks(rows) * c, device=y.device, dtype=torch.float32), 0
         stats = torch.empty(2, c, device=y.device, dtype=torch.float32)
         z = torch.empty_like(yc, memory_format=torch.channels_last)
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         cb = None if conv_bias is None else conv_bias.detach().float().contiguous()
         _lib.check(lib.syn_bn_act_fwd(yc.data_ptr(), _lib.ptr(sc), rows, c, g.data_ptr(), b.data_ptr(), float(eps), float(momentum),
-                                      _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(cb), int(act), ws.data_ptr(), stats.data_ptr(),
+                                      _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(cb), int(act), ws.data_ptr(), ws_chunks, stats.data_ptr(),
                                       z.data_ptr(), _lib.current_stream(y.device)), "syn_bn_act_fwd")
         # (without a shortcut the backward recomputes the activation's sign from y and does not read z)
         ctx.save_for_backward(yc, z if (act and shortcut is not None) else None, stats, g, b)
@@ -612,6 +623,7 @@ class BnActFn(torch.autograd.Function):
         return dy, dgb[0], dgb[1], dcb, dsh, None, None, None, None, None
 
 
+WAV_CONV_BN_STATS = bool(int(_os.environ.get("SYN_CONV_BN_STATS", "1")))   # BatchNorm's per-channel sums from the convolution's epilogue
 WAV_FUSED_BN = True       # training mode: BatchNorm (+ shortcut) (+ LeakyReLU) of the encoder on syn_bn_act_fwd / _bwd
 
 
