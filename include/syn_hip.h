@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define SYN_ABI_VERSION 2
+#define SYN_ABI_VERSION 3     /* 3: training entry points reworked (syn_ln_bwd add, syn_bn_act_* ws_chunks / beta, syn_conv1d_train_fwd bn_part,
+                                * syn_linear_bwd_prep colsum; new: syn_linear_pair / _and_pack, syn_pack_weights, syn_embedding_wgrad, syn_conv1d_first_*) */
 #define SYN_D        512   /* hidden width               (models/denoiser.py:19)  */
 #define SYN_T        32    /* latent frames per clip     (128 pose frames / 4)    */
 #define SYN_C        1536  /* latent channels            (models/denoiser.py:37)  */
