@@ -81,6 +81,7 @@ class WeightPacks:
 
     def __init__(self, weights):
         import numpy as np
+        self.owner = lambda: None                                # the model the cache belongs to (weak reference, set by its user)
         self.items = {}
         jobs, self.max_frag = [], 0
         dev = None
@@ -693,8 +694,9 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     global _packs
     if WEIGHT_PACKS and torch.is_grad_enabled():
         pk = m.__dict__.get("_syn_weight_packs")
-        if pk is None or not pk.valid():
+        if pk is None or pk.owner() is not m or not pk.valid():          # (a deep copy of the model brings the original's cache along)
             pk = m.__dict__["_syn_weight_packs"] = WeightPacks([mod.weight for mod in m.modules() if isinstance(mod, nn.Linear)])
+            pk.owner = __import__("weakref").ref(m)
         pk.refresh()
         _packs = pk
     h3d = m.variant == "h3d"
