@@ -1756,6 +1756,17 @@ int launch_conv(const wav::CArgs& a, int n_clips, hipStream_t s) {
     return e == hipSuccess ? 0 : fail("k_conv launch", e);
 }
 
+template <int CINP, int KT, int RF>
+int launch_conv_train_ks(const wav::TArgs& a, int n_clips, hipStream_t s) {
+    constexpr int MW = RF * 16, lds = 2 * (MW + KT - 1) * (CINP * 2 + 16);
+    static_assert(lds <= 160 * 1024, "two bf16 planes of the input tile must fit the LDS");
+    static bool once = false;
+    if (!once) { allow_lds(wav::k_conv_train_ks<CINP, KT, RF>, lds); once = true; }
+    hipLaunchKernelGGL((wav::k_conv_train_ks<CINP, KT, RF>), dim3((a.L_out + MW - 1) / MW, n_clips), dim3(256), lds, s, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv_train_ks launch", e);
+}
+
 template <int CINP, int KT, int WN, int WM, int RF>
 int launch_conv_train(const wav::TArgs& a, int n_clips, hipStream_t s) {
     constexpr int MW = WM * RF * 16, lds = 2 * (MW + KT - 1) * (CINP * 2 + 16);
@@ -2527,8 +2538,12 @@ int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_i
     return 0;
 }
 
+// row fragments (16 positions) per tile of the K-split kernel: 3 = 48 positions, 78 KB of LDS, so two workgroups share a CU and
+// one's staging overlaps the other's MFMA phase (4 = 64 positions, 103 KB: one workgroup per CU)
+constexpr int kKsRf = 3;
 // positions per workgroup tile of syn_conv1d_train_fwd's kernel instance (0: not one of the encoder's layers)
 static int conv_train_tile(int cinp, int stride, int cout) {
+    if (cinp == 384 && stride == 6 && cout == 64 && !getenv("SYN_CONV_POS_SPLIT")) return 16 * kKsRf;
     if (cinp == 64 && stride == 1 && cout == 64) return 256;
     if (cinp == 128 && stride == 1 && cout == 128) return 128;
     if ((cinp == 256 && stride == 1 && cout == 256) || (cinp == 384 && (stride == 6 || stride == 3))) return 64;
@@ -2558,7 +2573,9 @@ int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
     if (cinp == 64 && stride == 1 && cout == 64) return launch_conv_train<64, 15, 1, 4, 4>(a, n_clips, s);
     if (cinp == 128 && stride == 1 && cout == 128) return launch_conv_train<128, 15, 2, 2, 4>(a, n_clips, s);
     if (cinp == 256 && stride == 1 && cout == 256) return launch_conv_train<256, 15, 4, 1, 4>(a, n_clips, s);
-    if (cinp == 384 && stride == 6 && cout == 64) return launch_conv_train<384, 3, 1, 4, 1>(a, n_clips, s);
+    static const bool pos_split = getenv("SYN_CONV_POS_SPLIT") != nullptr;      // diagnostics: the waves split positions (the first version)
+    if (cinp == 384 && stride == 6 && cout == 64)
+        return pos_split ? launch_conv_train<384, 3, 1, 4, 1>(a, n_clips, s) : launch_conv_train_ks<384, 3, kKsRf>(a, n_clips, s);
     if (cinp == 384 && stride == 6 && cout == 128) return launch_conv_train<384, 3, 2, 2, 2>(a, n_clips, s);
     if (cinp == 384 && stride == 3 && cout == 256) return launch_conv_train<384, 5, 4, 1, 4>(a, n_clips, s);
     return fail_msg("syn_conv1d_train_fwd: not one of the WavEncoder's convolutions (cin x stride -> cout: 64x1->64, 128x1->128, 256x1->256, 64x6->64, 64x6->128, 128x3->256)");
