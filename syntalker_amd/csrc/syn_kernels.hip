@@ -2531,7 +2531,7 @@ int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_i
         int rc;
         if (cout == 64 && kt == 3) rc = launch_conv_train<64, 3, 2, 2, 4>(a, n_clips, s);
         else if (cout == 128 && kt == 3) rc = launch_conv_train<128, 3, 2, 2, 4>(a, n_clips, s);
-        else if (cout == 256 && kt == 6) rc = launch_conv_train<256, 6, 2, 2, 4>(a, n_clips, s);
+        else if (cout == 256 && kt == 6) rc = launch_conv_train<256, 6, 2, 2, 2>(a, n_clips, s);     // (64 positions: 73 KB, two workgroups per CU)
         else return fail_msg("syn_conv1d_train_dgrad_strided: (cout, stride) must be (64, 6), (128, 6) or (256, 3)");
         if (rc) return rc;
     }
@@ -2546,7 +2546,8 @@ static int conv_train_tile(int cinp, int stride, int cout) {
     if (cinp == 384 && stride == 6 && cout == 64 && !getenv("SYN_CONV_POS_SPLIT")) return 16 * kKsRf;
     if (cinp == 64 && stride == 1 && cout == 64) return 256;
     if (cinp == 128 && stride == 1 && cout == 128) return 128;
-    if ((cinp == 256 && stride == 1 && cout == 256) || (cinp == 384 && (stride == 6 || stride == 3))) return 64;
+    if (cinp == 256 && stride == 1 && cout == 256) return 48;
+    if (cinp == 384 && (stride == 6 || stride == 3)) return 64;
     return 0;
 }
 
@@ -2572,7 +2573,7 @@ int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
     // of a 384-channel tile would not fit the LDS)
     if (cinp == 64 && stride == 1 && cout == 64) return launch_conv_train<64, 15, 1, 4, 4>(a, n_clips, s);
     if (cinp == 128 && stride == 1 && cout == 128) return launch_conv_train<128, 15, 2, 2, 4>(a, n_clips, s);
-    if (cinp == 256 && stride == 1 && cout == 256) return launch_conv_train<256, 15, 4, 1, 4>(a, n_clips, s);
+    if (cinp == 256 && stride == 1 && cout == 256) return launch_conv_train<256, 15, 4, 1, 3>(a, n_clips, s);   // (48 positions: 65 KB, two workgroups per CU)
     static const bool pos_split = getenv("SYN_CONV_POS_SPLIT") != nullptr;      // diagnostics: the waves split positions (the first version)
     if (cinp == 384 && stride == 6 && cout == 64)
         return pos_split ? launch_conv_train<384, 3, 1, 4, 1>(a, n_clips, s) : launch_conv_train_ks<384, 3, kKsRf>(a, n_clips, s);
