@@ -2547,7 +2547,8 @@ static int conv_train_tile(int cinp, int stride, int cout) {
     if (cinp == 64 && stride == 1 && cout == 64) return 256;
     if (cinp == 128 && stride == 1 && cout == 128) return 128;
     if (cinp == 256 && stride == 1 && cout == 256) return 48;
-    if (cinp == 384 && (stride == 6 || stride == 3)) return 64;
+    if (cinp == 384 && stride == 6) return 64;
+    if (cinp == 384 && stride == 3) return 32;
     return 0;
 }
 
@@ -2577,8 +2578,8 @@ int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
     static const bool pos_split = getenv("SYN_CONV_POS_SPLIT") != nullptr;      // diagnostics: the waves split positions (the first version)
     if (cinp == 384 && stride == 6 && cout == 64)
         return pos_split ? launch_conv_train<384, 3, 1, 4, 1>(a, n_clips, s) : launch_conv_train_ks<384, 3, kKsRf>(a, n_clips, s);
-    if (cinp == 384 && stride == 6 && cout == 128) return launch_conv_train<384, 3, 2, 2, 2>(a, n_clips, s);
-    if (cinp == 384 && stride == 3 && cout == 256) return launch_conv_train<384, 5, 4, 1, 4>(a, n_clips, s);
+    if (cinp == 384 && stride == 6 && cout == 128) return launch_conv_train<384, 3, 2, 2, 2>(a, n_clips, s);   // (32-position tiles, three workgroups per CU: 27 -> 30 us)
+    if (cinp == 384 && stride == 3 && cout == 256) return launch_conv_train<384, 5, 4, 1, 2>(a, n_clips, s);   // (32 positions: 56 KB, two per CU)
     return fail_msg("syn_conv1d_train_fwd: not one of the WavEncoder's convolutions (cin x stride -> cout: 64x1->64, 128x1->128, 256x1->256, 64x6->64, 64x6->128, 128x3->256)");
 }
 
