@@ -2542,10 +2542,11 @@ int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_i
 // one's staging overlaps the other's MFMA phase (4 = 64 positions, 103 KB: one workgroup per CU)
 constexpr int kKsRf = 3;
 // positions per workgroup tile of syn_conv1d_train_fwd's kernel instance (0: not one of the encoder's layers)
-static int conv_train_tile(int cinp, int stride, int cout) {
+static int conv_train_tile(int cinp, int stride, int cout, int n_clips, int l_out) {
     if (cinp == 384 && stride == 6 && cout == 64 && !getenv("SYN_CONV_POS_SPLIT")) return 16 * kKsRf;
-    if (cinp == 64 && stride == 1 && cout == 64) return 256;
-    if (cinp == 128 && stride == 1 && cout == 128) return 128;
+    const bool small = getenv("SYN_CONV_BIG_TILES") == nullptr;           // (diagnostics: the large tiles everywhere)
+    if (cinp == 64 && stride == 1 && cout == 64) return small && (long)n_clips * ((l_out + 255) / 256) < 2 * device_cus() ? 128 : 256;
+    if (cinp == 128 && stride == 1 && cout == 128) return small && (long)n_clips * ((l_out + 127) / 128) < 2 * device_cus() ? 64 : 128;
     if (cinp == 256 && stride == 1 && cout == 256) return 48;
     if (cinp == 384 && stride == 6) return 64;
     if (cinp == 384 && stride == 3) return 32;
@@ -2553,8 +2554,8 @@ static int conv_train_tile(int cinp, int stride, int cout) {
 }
 
 int32_t syn_conv1d_train_fwd_tiles(int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, int32_t cout) {
-    const int mw = conv_train_tile(stride * cin, stride, cout), l_out = (l_in + 2 * pad - 15) / stride + 1;
-    return mw && l_out > 0 && n_clips > 0 ? n_clips * ((l_out + mw - 1) / mw) : 0;
+    const int l_out = (l_in + 2 * pad - 15) / stride + 1, mw = l_out > 0 && n_clips > 0 ? conv_train_tile(stride * cin, stride, cout, n_clips, l_out) : 0;
+    return mw ? n_clips * ((l_out + mw - 1) / mw) : 0;
 }
 
 int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
@@ -2572,8 +2573,13 @@ int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
     const int cinp = stride * cin;
     // (rows of stride * cin floats, ceil(15 / stride) taps; tiles as the eval-mode encoder picks them, halved where two planes
     // of a 384-channel tile would not fit the LDS)
-    if (cinp == 64 && stride == 1 && cout == 64) return launch_conv_train<64, 15, 1, 4, 4>(a, n_clips, s);
-    if (cinp == 128 && stride == 1 && cout == 128) return launch_conv_train<128, 15, 2, 2, 4>(a, n_clips, s);
+    // (short layers: smaller tiles, so that the launch still fills the chip and the last tile of a clip wastes less)
+    if (cinp == 64 && stride == 1 && cout == 64)
+        return conv_train_tile(cinp, stride, cout, n_clips, l_out) == 256 ? launch_conv_train<64, 15, 1, 4, 4>(a, n_clips, s)
+                                                                          : launch_conv_train<64, 15, 1, 4, 2>(a, n_clips, s);
+    if (cinp == 128 && stride == 1 && cout == 128)
+        return conv_train_tile(cinp, stride, cout, n_clips, l_out) == 128 ? launch_conv_train<128, 15, 2, 2, 4>(a, n_clips, s)
+                                                                          : launch_conv_train<128, 15, 2, 2, 2>(a, n_clips, s);
     if (cinp == 256 && stride == 1 && cout == 256) return launch_conv_train<256, 15, 4, 1, 3>(a, n_clips, s);   // (48 positions: 65 KB, two workgroups per CU)
     static const bool pos_split = getenv("SYN_CONV_POS_SPLIT") != nullptr;      // diagnostics: the waves split positions (the first version)
     if (cinp == 384 && stride == 6 && cout == 64)
