@@ -2547,7 +2547,12 @@ static int conv_train_tile(int cinp, int stride, int cout, int n_clips, int l_ou
     const bool small = getenv("SYN_CONV_BIG_TILES") == nullptr;           // (diagnostics: the large tiles everywhere)
     if (cinp == 64 && stride == 1 && cout == 64) return small && (long)n_clips * ((l_out + 255) / 256) < 2 * device_cus() ? 128 : 256;
     if (cinp == 128 && stride == 1 && cout == 128) return small && (long)n_clips * ((l_out + 127) / 128) < 2 * device_cus() ? 64 : 128;
-    if (cinp == 256 && stride == 1 && cout == 256) return 48;
+    if (cinp == 256 && stride == 1 && cout == 256) {         // (32 clips x 128 positions: 155 us for forward + data gradient on 64-position tiles, 137 / 113 / 102 on 48 / 32 / 16)
+        if (!small) return 48;
+        for (int mw = 48; mw > 16; mw -= 16)
+            if ((long)n_clips * ((l_out + mw - 1) / mw) >= 2 * device_cus()) return mw;
+        return 16;
+    }
     if (cinp == 384 && stride == 6) return 64;
     if (cinp == 384 && stride == 3) return 32;
     return 0;
@@ -2580,7 +2585,11 @@ int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
     if (cinp == 128 && stride == 1 && cout == 128)
         return conv_train_tile(cinp, stride, cout, n_clips, l_out) == 128 ? launch_conv_train<128, 15, 2, 2, 4>(a, n_clips, s)
                                                                           : launch_conv_train<128, 15, 2, 2, 2>(a, n_clips, s);
-    if (cinp == 256 && stride == 1 && cout == 256) return launch_conv_train<256, 15, 4, 1, 3>(a, n_clips, s);   // (48 positions: 65 KB, two workgroups per CU)
+    if (cinp == 256 && stride == 1 && cout == 256) {
+        const int mw = conv_train_tile(cinp, stride, cout, n_clips, l_out);
+        return mw == 48 ? launch_conv_train<256, 15, 4, 1, 3>(a, n_clips, s)                                       // (48 positions: 65 KB, two workgroups per CU)
+             : mw == 32 ? launch_conv_train<256, 15, 4, 1, 2>(a, n_clips, s) : launch_conv_train<256, 15, 4, 1, 1>(a, n_clips, s);
+    }
     static const bool pos_split = getenv("SYN_CONV_POS_SPLIT") != nullptr;      // diagnostics: the waves split positions (the first version)
     if (cinp == 384 && stride == 6 && cout == 64)
         return pos_split ? launch_conv_train<384, 3, 1, 4, 1>(a, n_clips, s) : launch_conv_train_ks<384, 3, kKsRf>(a, n_clips, s);
