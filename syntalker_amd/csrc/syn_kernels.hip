@@ -2530,8 +2530,12 @@ int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_i
         a.Y = dx; a.y_clip_stride = (long)l_in * cin; a.y_pitch = np; a.y_col0 = c0; a.y_elems = (long)l_in * cin; a.bn_part = nullptr;
         int rc;
         if (cout == 64 && kt == 3) rc = launch_conv_train<64, 3, 2, 2, 4>(a, n_clips, s);
-        else if (cout == 128 && kt == 3) rc = launch_conv_train<128, 3, 2, 2, 4>(a, n_clips, s);
-        else if (cout == 256 && kt == 6) rc = launch_conv_train<256, 6, 2, 2, 2>(a, n_clips, s);     // (64 positions: 73 KB, two workgroups per CU)
+        // (a launch covers 128 of the stride x cin columns: tiles halved while it would not fill the chip twice - 32 clips: 45 -> 30 us and
+        // 76 -> 53 us for the three launches of the 128- / 256-channel layers)
+        else if (cout == 128 && kt == 3) rc = (long)n_clips * ((q_rows + 127) / 128) >= 2 * device_cus() ? launch_conv_train<128, 3, 2, 2, 4>(a, n_clips, s)
+                                                                                                           : launch_conv_train<128, 3, 2, 2, 2>(a, n_clips, s);
+        else if (cout == 256 && kt == 6) rc = (long)n_clips * ((q_rows + 63) / 64) >= 2 * device_cus() ? launch_conv_train<256, 6, 2, 2, 2>(a, n_clips, s)
+                                                                                                         : launch_conv_train<256, 6, 2, 2, 1>(a, n_clips, s);
         else return fail_msg("syn_conv1d_train_dgrad_strided: (cout, stride) must be (64, 6), (128, 6) or (256, 3)");
         if (rc) return rc;
     }
@@ -2554,7 +2558,7 @@ static int conv_train_tile(int cinp, int stride, int cout, int n_clips, int l_ou
         return 16;
     }
     if (cinp == 384 && stride == 6) return 64;
-    if (cinp == 384 && stride == 3) return 32;
+    if (cinp == 384 && stride == 3) return small && (long)n_clips * ((l_out + 31) / 32) < 2 * device_cus() ? 16 : 32;
     return 0;
 }
 
@@ -2594,7 +2598,9 @@ int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
     if (cinp == 384 && stride == 6 && cout == 64)
         return pos_split ? launch_conv_train<384, 3, 1, 4, 1>(a, n_clips, s) : launch_conv_train_ks<384, 3, kKsRf>(a, n_clips, s);
     if (cinp == 384 && stride == 6 && cout == 128) return launch_conv_train<384, 3, 2, 2, 2>(a, n_clips, s);   // (32-position tiles, three workgroups per CU: 27 -> 30 us)
-    if (cinp == 384 && stride == 3 && cout == 256) return launch_conv_train<384, 5, 4, 1, 2>(a, n_clips, s);   // (32 positions: 56 KB, two per CU)
+    if (cinp == 384 && stride == 3 && cout == 256)
+        return conv_train_tile(cinp, stride, cout, n_clips, l_out) == 32 ? launch_conv_train<384, 5, 4, 1, 2>(a, n_clips, s)
+                                                                         : launch_conv_train<384, 5, 4, 1, 1>(a, n_clips, s);
     return fail_msg("syn_conv1d_train_fwd: not one of the WavEncoder's convolutions (cin x stride -> cout: 64x1->64, 128x1->128, 256x1->256, 64x6->64, 64x6->128, 128x3->256)");
 }
 
