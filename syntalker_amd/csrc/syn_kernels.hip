@@ -2241,7 +2241,7 @@ int syn_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
     return e == hipSuccess ? 0 : fail("k_gelu_fwd launch", e);
 }
 
-int32_t syn_bn_chunks(int64_t rows) { return (int32_t)((rows + trn::kBnRows - 1) / trn::kBnRows); }
+int32_t syn_bn_chunks(int64_t rows) { const int cr = trn::bn_chunk_rows((long)rows); return (int32_t)((rows + cr - 1) / cr); }
 
 int syn_bn_act_fwd(const float* y, const float* shortcut, int64_t rows, int32_t channels, const float* gamma, const float* beta, float eps,
                    float momentum, float* run_mean, float* run_var, const float* conv_bias, int32_t act, float* ws, int32_t ws_chunks, float* stats,
