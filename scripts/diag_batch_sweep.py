@@ -26,5 +26,5 @@ for B in sizes:
     e1.record(); torch.cuda.synchronize(); sb.check_sync()
     us = e0.elapsed_time(e1) * 1e3 / (reps * 10)
     lib = engine._lib.load() if hasattr(engine, "_lib") else None
-    kern = "k_seq" if sb.fragment else ("k_lat" if B <= 8 else ("k_stack split x4" if B <= 64 else ("k_stack split x2" if B <= 128 else ("k_stack<32>" if B // 2 < 192 else "k_stack<64>"))))
+    kern = "k_seq" if sb.fragment else ("k_lat" if B <= 8 else ("k_stack split x4" if B <= 64 else ("k_stack split x2" if B <= 128 else ("k_stack<32>" if B <= 256 else "k_stack<64>"))))
     print(f"B={B:5d}: {us:8.1f} us  {B / us * 1e3:8.1f} k  {B * F_STEP / (us * 1e-6) / 2.5e15:.3f}  {kern}", flush=True)

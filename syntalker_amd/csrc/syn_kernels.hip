@@ -1849,6 +1849,9 @@ int pick_tile(int rows) {
     // enough workgroups to cover the 256 CUs first, then the larger tile (weight reuse per L2 byte).
     // 128-row tiles exist for the A/B paths only: with the 4-slot weight ring they exceed 256 VGPRs.
     if (rows / 64 >= 192) return 64;
+    // more 32-row tiles than CUs would mean a second, mostly empty round of workgroups (257..383 sequences: 0.84 ms per step against
+    // 0.52 ms on 64-row tiles, `profiles/r02_diag_batch_sweep.txt`); up to one tile per CU the smaller tile wins (0.41-0.46 against 0.52 ms)
+    if ((rows + 31) / 32 > device_cus()) return 64;
     return 32;
 }
 
