@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define SYN_ABI_VERSION 3     /* 3: training entry points reworked (syn_ln_bwd add, syn_bn_act_* ws_chunks / beta, syn_conv1d_train_fwd bn_part,
+#define SYN_ABI_VERSION 4     /* 4: syn_model.tape carries its first 4 chunks again behind the last (no wrap test in k_seq's weight stream);
+                                * 3: training entry points reworked (syn_ln_bwd add, syn_bn_act_* ws_chunks / beta, syn_conv1d_train_fwd bn_part,
                                 * syn_linear_bwd_prep colsum; new: syn_linear_pair / _and_pack, syn_pack_weights, syn_embedding_wgrad, syn_conv1d_first_*) */
 #define SYN_D        512   /* hidden width               (models/denoiser.py:19)  */
 #define SYN_T        32    /* latent frames per clip     (128 pose frames / 4)    */
@@ -64,7 +65,8 @@ typedef struct syn_model {
     const float* b_out;     /* (1536)                                                            */
     /* the same weights as ONE contiguous tape of 1 KB MFMA fragments in consumption order + per-block bias sets, for the
      * wave-per-sequence step kernel (large batches; host: syntalker_amd/tape.py).  NULL = that kernel is never chosen. */
-    const void*  tape;        /* bf16 [tape_chunks][16 fragments][64 lanes][8] (1 KB fragments)    */
+    const void*  tape;        /* bf16 [tape_chunks + 4][16 fragments][64 lanes][8] (1 KB fragments): the step's chunks followed by the
+                               * first 4 of them once more (ABI 4: the kernel's DMA look-ahead runs across the step boundary)      */
     const float* tape_bias;   /* [9][4096]                                                        */
     int32_t      tape_chunks; /* 2256 chunks of 16 fragments (36 096 fragments, 35.25 MB)           */
 } syn_model;

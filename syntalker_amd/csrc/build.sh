@@ -15,10 +15,10 @@ fi
 grep -v "remark:" "$LOG" >&2 || true
 # k_seq lives within a few registers of the 512 a wave has: an edit that tips hipcc's allocator over shows up
 # as hundreds of spilled registers and a 20-30 % slower step, not as an error.  Say so at build time.
-# (both instances: k_seq<false> plain, k_seq<true> guided batches)
+# (six instances: plain / guided batches x the noise term of the update - none, read, drawn in the epilogue)
 spills=$(grep -A12 "Function Name: .*k_seq" "$LOG" | grep "VGPRs Spill" | sed 's/.*VGPRs Spill: \([0-9]*\).*/\1/' | tr '\n' ' ' || true)
 rm -f "$LOG"
-echo "k_seq: ${spills:-?}spilled VGPRs (plain / guided instance)"
+echo "k_seq: ${spills:-?}spilled VGPRs (instances: {plain, guided} x noise {none, read, drawn})"
 for n in ${spills}; do
     if [ "${n}" -gt 80 ]; then
         echo "WARNING: k_seq spills ${n} VGPRs (60 with the step loop, none inside the block loops): the register allocation tipped over, expect a much slower step" >&2

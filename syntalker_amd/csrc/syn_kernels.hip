@@ -293,6 +293,12 @@ __device__ __forceinline__ void store_h_and_norm(const GArgs& a, f32x4 (&v)[4][M
     }
 }
 
+// Beside an MFMA a packed fp32 operation costs ~20 cycles MORE than the two plain ones it replaces (scripts/ubench/seq_issue.hip:
+// 35.4 cycles per MFMA with nothing in the gap, 38.2 with two v_fma_f32, 56.5 with one v_pk_fma_f32), and hipcc forms them wherever
+// two fp32 values meet in adjacent registers (vector-typed expressions, the SLP vectoriser).  Work that rides in an MFMA's
+// shadow is therefore written element by element, every result passed through this opaque no-op.
+__device__ __forceinline__ float nopk(float x) { asm("" : "+v"(x)); return x; }
+
 // Philox4x32-10 (Salmon et al. 2011), counter = (index/4, stream_id), key = seed; Box-Muller pairs.
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
@@ -316,8 +322,8 @@ __device__ __forceinline__ f32x4 randn4(uint64_t seed, uint64_t stream_id, uint6
         // hardware transcendentals as they are: v_log_f32 is log2 (u1 >= 2^-33 is a normal number, so none of the
         // library's denormal scaling is needed), v_sin/v_cos take their argument in revolutions
         const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
-        z[2 * p] = rad * __builtin_amdgcn_cosf(u2);
-        z[2 * p + 1] = rad * __builtin_amdgcn_sinf(u2);
+        z[2 * p] = nopk(rad * __builtin_amdgcn_cosf(u2));              // (the epilogues call this in the shadow of MFMAs)
+        z[2 * p + 1] = nopk(rad * __builtin_amdgcn_sinf(u2));
     }
     return z;
 }
@@ -1812,12 +1818,21 @@ int seq_grid(int n_clips, int n_variants) {
     return (n_clips + cpw - 1) / cpw;
 }
 
-int launch_seq(const seq::QArgs& a, hipStream_t s) {
+template <bool G, int NZ>
+void launch_seq_as(const seq::QArgs& a, const dim3 grid, hipStream_t s) {
     static bool once = false;
-    if (!once) { allow_lds(seq::k_seq<false>, seq::kLds); allow_lds(seq::k_seq<true>, seq::kLds); once = true; }
+    if (!once) { allow_lds(seq::k_seq<G, NZ>, seq::kLds); once = true; }
+    hipLaunchKernelGGL((seq::k_seq<G, NZ>), grid, dim3(seq::kThreads), seq::kLds, s, a);
+}
+
+int launch_seq(const seq::QArgs& a, hipStream_t s) {
     const dim3 grid(a.n_wg > 0 ? a.n_wg : seq_grid(a.R, a.V));
-    if (a.V == 1) hipLaunchKernelGGL(seq::k_seq<false>, grid, dim3(seq::kThreads), seq::kLds, s, a);
-    else hipLaunchKernelGGL(seq::k_seq<true>, grid, dim3(seq::kThreads), seq::kLds, s, a);
+    const int nz = a.noise ? 1 : a.rng ? 2 : 0;                    // (the noise term is part of the instance: no branch per quad)
+    if (a.V == 1) {
+        if (nz == 2) launch_seq_as<false, 2>(a, grid, s); else if (nz == 1) launch_seq_as<false, 1>(a, grid, s); else launch_seq_as<false, 0>(a, grid, s);
+    } else {
+        if (nz == 2) launch_seq_as<true, 2>(a, grid, s); else if (nz == 1) launch_seq_as<true, 1>(a, grid, s); else launch_seq_as<true, 0>(a, grid, s);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_seq launch", e);
 }

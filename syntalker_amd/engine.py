@@ -75,7 +75,7 @@ class PackedModel:
         m.b_out = hold(f32(sd["output_process.poseFinal.bias"]))
         # the same weights as one tape of MFMA fragments in consumption order: the wave-per-sequence kernel (large batches)
         tp, tb = _tape.build_tape(sd, folded["A"])
-        m.tape, m.tape_bias, m.tape_chunks = hold(tp), hold(tb), tp.shape[0] // _tape.CHUNK_FRAGS
+        m.tape, m.tape_bias, m.tape_chunks = hold(tp), hold(tb), _tape.TAPE_FRAGS // _tape.CHUNK_FRAGS   # (+ LOOK_CHUNKS repeated chunks behind them)
         self.c = m
         self.conditioner = ClipConditioner({k: (v.detach() if torch.is_tensor(v) else v) for k, v in sd.items()},
                                            folded, variant, use_style)

@@ -26,7 +26,10 @@ Tape order:
     block l, slice s  fc1[128s:128s+128] (128 x 512, LayerNorm-2 gain folded in)  pair  128          (8 slices)
                       fc2[:, 128s:128s+128] (512 x 128)                           wide  8 kc = 128
     output  Wout (1536 x 512)                                                pair  24 pairs x 32 kc x 2 = 1536
-  = 1536 + 8 * (4096 + 32) + 1536 = 36 096 fragments (35.25 MB).
+  = 1536 + 8 * (4096 + 32) + 1536 = 36 096 fragments (35.25 MB), followed by the first LOOK_CHUNKS chunks once more: the
+kernel's DMA runs LOOK_CHUNKS chunks ahead of the MFMAs, and in a multi-step launch the look-ahead of a step's tail is the
+next step's head - with the head repeated behind the tail the producer never tests for the wrap, it restarts behind the
+chunks the ring already holds when a step begins.
 
 Biases.  Those that start an accumulator (q, fc1, output) are read from LDS-resident sets (fp32, 2048 floats = 8 KB
 each, set l for block l, set 8 for the output stage):
@@ -45,6 +48,8 @@ import torch
 D, FF, C, HEADS, LAYERS = 512, 1024, 1536, 4, 8
 CHUNK_FRAGS = 16       # fragments per ring chunk of the kernel (syn_seq.inc SEQ_CHUNK); syn_model.tape_chunks counts these
 TAPE_FRAGS = 1536 + LAYERS * (4096 + 32) + 1536
+LOOK_CHUNKS = 4         # ring slots ahead of the one being consumed (syn_seq.inc kLook): the tape's head is repeated at its end
+TAPE_ALLOC_FRAGS = TAPE_FRAGS + LOOK_CHUNKS * CHUNK_FRAGS
 BIAS_SET = 2048
 N_BIAS_SETS = LAYERS + 1
 
@@ -101,7 +106,8 @@ def pair(w: torch.Tensor) -> torch.Tensor:
 
 
 def build_tape(sd: dict, A: torch.Tensor):
-    """-> (tape bf16 [TAPE_FRAGS][64][8], bias fp32 [9][2048]) on the device of the weights.
+    """-> (tape bf16 [TAPE_ALLOC_FRAGS][64][8]: the TAPE_FRAGS fragments of a step + its first LOOK_CHUNKS chunks again,
+    bias fp32 [9][2048]) on the device of the weights.
 
     sd: MDM state_dict view (mytimmblocks.*, output_process.poseFinal.*); A: folded input matrix (512 x 1536)."""
     dev = A.device
@@ -128,8 +134,9 @@ def build_tape(sd: dict, A: torch.Tensor):
     wout = f64(sd["output_process.poseFinal.weight"])
     pieces.append(pair(wout))
     bias[LAYERS, 0:C] = f64(sd["output_process.poseFinal.bias"])
-    tape = torch.cat(pieces, 0).contiguous()
+    tape = torch.cat(pieces, 0)
     assert tape.shape[0] == TAPE_FRAGS, tape.shape
+    tape = torch.cat([tape, tape[:LOOK_CHUNKS * CHUNK_FRAGS]], 0).contiguous()
     return tape, bias.float().contiguous()
 
 

@@ -40,7 +40,10 @@ def test_tape_through_the_lane_level_model_reproduces_the_oracle():
     sd = synth_state_dict("beatx")
     fw = dr.fold_weights(sd)
     t_tape, bias = tape.build_tape(sd, fw["A"])
-    assert t_tape.shape == (tape.TAPE_FRAGS, 64, 8) and bias.shape == (9, 2048)
+    assert t_tape.shape == (tape.TAPE_ALLOC_FRAGS, 64, 8) and bias.shape == (9, 2048)
+    # the head once more behind the tail: the kernel's DMA look-ahead across a step boundary (syn_seq.inc)
+    assert torch.equal(t_tape[tape.TAPE_FRAGS:], t_tape[:tape.LOOK_CHUNKS * tape.CHUNK_FRAGS])
+    t_tape = t_tape[:tape.TAPE_FRAGS]
     assert tape.TAPE_FRAGS == 36096 and tape.TAPE_FRAGS % tape.CHUNK_FRAGS == 0 and tape.TAPE_FRAGS // tape.CHUNK_FRAGS == 2256
     y, x = synth.synth_clip_inputs(1, seed=5), synth.synth_latent(1, seed=5)
     cond, te = dr.clip_conditioning(sd, y, fw), dr.time_table(sd, fw)
