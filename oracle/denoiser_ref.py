@@ -12,7 +12,10 @@ Two restatements of reference models/denoiser.py:132-196 (and models/denoiser_h3
                         one matrix ``A`` plus per-clip / per-step bias terms.
 
 ``variant``: "beatx" = models/denoiser.py (style only if use_motionclip), "h3d" = denoiser_h3d.py.
-Eval-mode semantics only (BatchNorm running stats, no DropPath, no Bernoulli cond-masking).
+Eval-mode semantics by default (BatchNorm running stats, no DropPath, no Bernoulli cond-masking); ``train_bn=True`` gives the
+audio encoder's BatchNorms their train() semantics - batch statistics, running buffers updated with momentum 0.1 - which is
+what the reference's training step runs (DropPath and the style dropout are the random elements of train(): the golden
+vectors of that mode are taken with DropPath's probability set to 0, tests/golden/make_golden.py).
 """
 import torch
 import torch.nn.functional as F
@@ -21,14 +24,23 @@ N_LAYERS, N_HEADS, D, ROT_GROUPS = 8, 4, 512, 8
 
 
 # ------------------------------------------------------------------ pieces
-def wav_encoder(sd, wav, prefix="WavEncoder.feat_extractor."):
-    """models/denoiser.py:304-322 + models/utils/layer.py:144-184.  wav (B, L, 2) -> (B, 128, 256)."""
+def wav_encoder(sd, wav, prefix="WavEncoder.feat_extractor.", train_bn=False, new_buffers=None):
+    """models/denoiser.py:304-322 + models/utils/layer.py:144-184.  wav (B, L, 2) -> (B, 128, 256).
+    train_bn: nn.BatchNorm1d in train() mode (biased batch variance in the normalisation; the running buffers move by
+    momentum 0.1 towards the batch mean / UNBIASED batch variance - written to ``new_buffers`` if given, sd is not modified)."""
     cfg = [(5, 1700, True), (6, 0, True), (1, 7, False), (6, 0, True), (1, 7, False), (3, 0, True)]
     x = wav.unsqueeze(1) if wav.dim() == 2 else wav.transpose(1, 2)
 
     def bn(z, p):
-        return F.batch_norm(z, sd[p + ".running_mean"], sd[p + ".running_var"],
-                            sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
+        if not train_bn:
+            return F.batch_norm(z, sd[p + ".running_mean"], sd[p + ".running_var"],
+                                sd[p + ".weight"], sd[p + ".bias"], False, 0.0, 1e-5)
+        rm, rv = sd[p + ".running_mean"].detach().clone(), sd[p + ".running_var"].detach().clone()
+        out = F.batch_norm(z, rm, rv, sd[p + ".weight"], sd[p + ".bias"], True, 0.1, 1e-5)
+        if new_buffers is not None:
+            new_buffers[p + ".running_mean"], new_buffers[p + ".running_var"] = rm, rv
+            new_buffers[p + ".num_batches_tracked"] = sd.get(p + ".num_batches_tracked", torch.zeros((), dtype=torch.long)) + 1
+        return out
 
     for i, (stride, pad, down) in enumerate(cfg):
         p = f"{prefix}{i}."
@@ -100,13 +112,14 @@ def _audio_word(y, variant):
 
 
 # ------------------------------------------------------------------ as written
-def mdm_forward(sd, x, timesteps, y, variant="beatx", use_motionclip=False, pool=4, taps=None):
-    """x (B, 1536, 1, T), timesteps (B,) int64 -> (B, 1536, 1, T).  denoiser.py:132-196."""
+def mdm_forward(sd, x, timesteps, y, variant="beatx", use_motionclip=False, pool=4, taps=None, train_bn=False, new_buffers=None):
+    """x (B, 1536, 1, T), timesteps (B,) int64 -> (B, 1536, 1, T).  denoiser.py:132-196.
+    train_bn / new_buffers: the audio encoder's BatchNorms in train() mode, see wav_encoder."""
     bs, C, _, T = x.shape
     emb_t = time_embedding(sd, timesteps)                                           # :142
     emb_seed = F.linear(y["seed"].reshape(bs, -1), sd["embed_text.weight"], sd["embed_text.bias"])
     audio, word = _audio_word(y, variant)
-    a_feat = wav_encoder(sd, audio).permute(1, 0, 2)                                # :151
+    a_feat = wav_encoder(sd, audio, train_bn=train_bn, new_buffers=new_buffers).permute(1, 0, 2)   # :151
     w_feat = F.embedding(word, sd["text_pre_encoder_body.weight"])
     w_feat = F.linear(w_feat, sd["text_encoder_body.weight"], sd["text_encoder_body.bias"]).permute(1, 0, 2)
     at = F.linear(torch.cat([a_feat, w_feat], dim=2), sd["mix_audio_text.weight"], sd["mix_audio_text.bias"])

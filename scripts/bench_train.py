@@ -6,10 +6,6 @@ from syntalker_amd.denoiser import MDM
 from syntalker_amd.process import create_gaussian_diffusion
 from syntalker_amd.resample import create_named_schedule_sampler
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-if len(sys.argv) > 3: training.HIP_BLOCK_OPS = bool(int(sys.argv[3]))
-if len(sys.argv) > 4: training.WAV_CHANNELS_LAST = bool(int(sys.argv[4]))
-if len(sys.argv) > 5: training.WAV_BF16 = bool(int(sys.argv[5]))
-if len(sys.argv) > 6: training.WAV_BF16_FROM = int(sys.argv[6])
 d = create_gaussian_diffusion(); s = create_named_schedule_sampler("uniform", d)
 y = synth.to_device(synth.synth_clip_inputs(B, seed=1, mask_batch=B), 'cuda')
 y["audio"] = torch.randn(B, 68266, 2, device='cuda')          # training clip length (beat_sep_lower.py:678)

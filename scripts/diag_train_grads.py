@@ -1,5 +1,5 @@
 """Per-parameter gradient error of the training path vs autograd through the CPU oracle (B = 4, fixed t and noise).
-Usage: python scripts/diag_train_grads.py [WAV_BF16=1]"""
+Usage: python scripts/diag_train_grads.py [train]   (train: BatchNorm on batch statistics, DropPath off - the mode the training step runs)"""
 import sys, torch
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from oracle import denoiser_ref as dr
@@ -8,19 +8,19 @@ from syntalker_amd import synth, training
 from syntalker_amd.denoiser import MDM
 from syntalker_amd.process import create_gaussian_diffusion
 from tests.refmodel import synth_state_dict
-if len(sys.argv) > 1: training.WAV_BF16 = bool(int(sys.argv[1]))
-if len(sys.argv) > 2: training.WAV_BF16_FROM = int(sys.argv[2])
+TRAIN = len(sys.argv) > 1 and sys.argv[1] == 'train'
 m = MDM(synth.default_args()); m.load_state_dict(synth_state_dict("beatx"), strict=False); m = m.cuda().eval()
 m.differentiable_eval = True
+if TRAIN: m.train(); m.drop_path = 0.0
 y = synth.synth_clip_inputs(4, seed=5)
 x0, eps = synth.synth_latent(4, seed=5, name="x0"), synth.synth_latent(4, seed=6, name="eps")
 t4 = torch.tensor([0, 17, 500, 999])
 d = create_gaussian_diffusion()
 loss = d.training_losses(m, x0.cuda(), t4.cuda(), model_kwargs={"y": synth.to_device(y, 'cuda')}, noise=eps.cuda())["loss"]
 loss.mean().backward()
-buffers = ("running_mean", "running_var", ".pe", "inv_freq")
+buffers = ("running_mean", "running_var", "num_batches_tracked", ".pe", "inv_freq")
 sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(buffers)) for k, v in synth_state_dict("beatx").items()}
-RefProcess(False).training_losses(lambda a, b, c: dr.mdm_forward(sd, a, b, c), x0, t4, y, eps)["loss"].mean().backward()
+RefProcess(False).training_losses(lambda a, b, c: dr.mdm_forward(sd, a, b, c, train_bn=TRAIN), x0, t4, y, eps)["loss"].mean().backward()
 rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
 for n, p in m.named_parameters():
     if p.grad is None or n not in sd or sd[n].grad is None or float(sd[n].grad.norm()) == 0.0: continue

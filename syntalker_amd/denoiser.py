@@ -125,6 +125,7 @@ class MDM(nn.Module):
         self.args = args
         self.latent_dim, self.ff_size, self.num_layers, self.num_heads = 512, 1024, 8, 4
         self.cond_mask_prob = 0.3
+        self.drop_path = 0.1               # models/denoiser.py:83: every block's DropPath probability (self.dropout); train() mode only
         self.use_motionclip = bool(getattr(args, "use_motionclip", False)) if self.variant == "beatx" else False
         audio_f, word_f = args.audio_f, args.word_f
         if getattr(args, "audio_rep", "onset+amplitude") != "onset+amplitude":
@@ -210,7 +211,7 @@ class MDM(nn.Module):
         # computed without .eval()) still means batch statistics, DropPath and style dropout, as in the reference.
         if self.training or (torch.is_grad_enabled() and self.differentiable_eval):
             from . import training                      # differentiable path: HIP GEMMs fwd/dgrad/wgrad (training.py)
-            return training.train_forward(self, x, timesteps, y)
+            return training.train_forward(self, x, timesteps, y, drop_path=self.drop_path)
         if torch.is_grad_enabled() and x.requires_grad:
             raise RuntimeError("MDM.eval() runs the fused inference kernels, which are not differentiable: the output would be "
                                "detached from x.  Set model.differentiable_eval = True (or call .train()) for gradients.")

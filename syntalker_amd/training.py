@@ -1,17 +1,18 @@
 """Training path of the denoiser (e): `training_losses` forward + backward.
 
-Structure this round
   * every nn.Linear of the denoiser (qkv, proj, fc1, fc2, poseEmbedding, input_process2/3, poseFinal, embed_text,
     time MLP, word/mix projections) runs forward, dgrad and wgrad on the hand-written MFMA GEMM through the C ABI
-    entry `syn_linear` (bf16 operands, fp32 accumulate/output) — `HipLinearFn`;
+    (`syn_linear`, `syn_linear_pair`: bf16 operands, fp32 accumulate/output) — `HipLinearFn`;
   * LayerNorm, the 32-token softmax attention and GELU of the 8 blocks run forward and backward on fp32 HIP kernels
-    (`syn_ln_*`, `syn_attn_*`, `syn_gelu_*`; `HipLayerNormFn`, `HipAttentionFn`, `HipGeluFn`);
-  * rotary, DropPath and the SmoothL1 loss are fp32 PyTorch-ROCm ops, and the WavEncoder convolutions + BatchNorms
-    (78 % of the training FLOPs, batch statistics in training) run on MIOpen, as SURVEY.md §7 stage 6 prescribes for
-    the first cut;
+    (`syn_ln_*`, `syn_attn_*`, `syn_gelu_*`; `HipLnForkFn`, `HipAttentionFn`, `HipGeluFn`);
+  * the WavEncoder (78 % of the training FLOPs, cannot be hoisted in training): every Conv1d forward / data gradient / weight
+    gradient on split-operand MFMA kernels (fp32-grade), the 1-2-channel first layer on plain fp32 FMAs, BatchNorm on batch
+    statistics + shortcut + LeakyReLU fused (`ConvSplitFn`, `ConvFirstFn`, `BnActFn`).  No library convolution is on this
+    path: a layer geometry the kernels do not cover raises;
+  * rotary, DropPath's multiply-add and the SmoothL1 loss are fp32 PyTorch elementwise ops;
   * data parallelism: one process per GPU, torch DDP over RCCL (`make_ddp`), gradients averaged by bucketed
-    all-reduce overlapped with backward; optional SyncBatchNorm for the WavEncoder (the reference's DDP branch,
-    train.py:90).
+    all-reduce overlapped with backward.  Optional SyncBatchNorm (the reference's DDP branch, train.py:90) takes the
+    encoder through its own nn.Modules instead (`_wav_block_modules`), the one place a library convolution still runs.
 Train-mode semantics follow the reference: BatchNorm batch statistics, DropPath(0.1) per sample with
 scale-by-keep (timm_transformer/transformer.py:21-38), h3d Bernoulli(0.3) style dropout
 (denoiser_h3d.py:116-124).  There is no CPU fallback: CPU tensors raise.
@@ -279,9 +280,8 @@ def lin(x, module: nn.Linear):
     return HipLinearFn.apply(x, module.weight, module.bias)
 
 
-# fp32 block ops on the hand-written kernels (True) or on the PyTorch-ROCm ops (False).  Same numerics to 1e-5
-# (tests/test_gpu_kernels.py::test_training_block_ops_vs_torch_autograd); see DESIGN.md §7 for the timings.
-HIP_BLOCK_OPS = True
+# (the fp32 block ops - LayerNorm, attention, GELU - run on the hand-written kernels below; their PyTorch-op twins live in
+# tests/test_gpu_kernels.py::test_training_block_ops_vs_torch_autograd, which checks them against each other to 1e-5)
 
 
 def _f32c(t):
@@ -386,14 +386,6 @@ class HipAttentionFn(torch.autograd.Function):
         return dqkv
 
 
-def _drop_path(x, p: float, training: bool):
-    if p == 0. or not training:
-        return x
-    keep = 1 - p
-    mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep).div_(keep)
-    return x * mask
-
-
 def _rotary(m, h):
     """models/denoiser.py:178-186,324-343 on (B, T, 512)."""
     B, T, _ = h.shape
@@ -406,42 +398,15 @@ def _rotary(m, h):
     return g.reshape(B, 8, T, -1).permute(0, 2, 1, 3).reshape(B, T, -1)
 
 
-WAV_CHANNELS_LAST = True     # run the encoder's convolutions as (N, C, 1, L) channels-last conv2d: MIOpen's NHWC kernels without
-                             # the NCHW <-> NHWC transposes it otherwise inserts around every convolution
-
-class ConvBf16Fn(torch.autograd.Function):
-    """(N, C, 1, L) convolution of the audio encoder with bf16 operands: forward and data gradient on MIOpen's bf16
-    kernels (fp32 accumulation, the rounding policy of every GEMM on this path); the weight gradient - a reduction over
-    up to 2 M positions - stays on the fp32 kernel (MIOpen's bf16 weight-gradient kernels lose 14 % on the first layer)."""
-
-    @staticmethod
-    def forward(ctx, x, w, stride, pad):
-        xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
-        ctx.save_for_backward(xb, wb)
-        ctx.geom = (stride, pad)
-        ctx.bf16_dgrad = WAV_BF16 == 2
-        return F.conv2d(xb, wb, None, stride=(1, stride), padding=(0, pad)).float()
-
-    @staticmethod
-    def backward(ctx, gy):
-        xb, wb = ctx.saved_tensors
-        stride, pad = ctx.geom
-        args = ((1, stride), (0, pad), (1, 1), False, (0, 0), 1)
-        gx = gw = None
-        if ctx.needs_input_grad[0]:
-            if ctx.bf16_dgrad:
-                gx = torch.ops.aten.convolution_backward(gy.to(torch.bfloat16), xb, wb, None, *args, (True, False, False))[0].float()
-            else:       # fp32 data gradient: rounding the activations' gradients to bf16 layer after layer is what loses the early blocks
-                gx = torch.ops.aten.convolution_backward(gy, xb.float(), wb.float(), None, *args, (True, False, False))[0]
-        if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(gy, xb.float(), wb.float(), None, *args, (False, True, False))[1]
-        return gx, gw, None, None
+def _unsupported_conv(what, cin, stride, pad, cout):
+    return _lib.SynHipError(f"{what}: no hand-written kernel covers Conv1d({cin} -> {cout}, k 15, stride {stride}, padding {pad}) of the audio "
+                            "encoder (covered: the reference's WavEncoder, models/denoiser.py:304-322); there is no library fallback")
 
 
 class ConvSplitFn(torch.autograd.Function):
     """(N, C, 1, L) channels_last convolution of the audio encoder, forward on the hand-written implicit-GEMM kernel with
     operands split into bf16 hi + lo halves (`syn_conv1d_train_fwd`: three MFMAs per product, fp32-grade - the plain bf16
-    forward moves the gradients of the first blocks by 14 %); data and weight gradients on the fp32 kernels of MIOpen.
+    forward moves the gradients of the first blocks by 14 %); data and weight gradients on the same family of kernels.
     Covers the encoder's Conv1d(k = 15) layers from block 0's conv2 on (block 0's conv1 / shortcut have 1-2 input channels and
     1 % of the FLOPs)."""
 
@@ -466,7 +431,7 @@ class ConvSplitFn(torch.autograd.Function):
         l_out = (l_in + 2 * pad - 15) // stride + 1
         y = torch.empty(n, cout, 1, l_out, device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         part = None
-        if want_stats and WAV_CONV_BN_STATS:
+        if want_stats:
             # BatchNorm's per-channel sums from the convolution's accumulators: the BatchNorm that follows skips its pass over y
             tiles = lib.syn_conv1d_train_fwd_tiles(n, l_in, cin, stride, pad, cout)
             part = torch.empty(tiles, 2, cout, device=x.device, dtype=torch.float32)
@@ -489,14 +454,13 @@ class ConvSplitFn(torch.autograd.Function):
         stride, pad = ctx.geom
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx = gw = None
-        args = ((1, stride), (0, pad), (1, 1), False, (0, 0), 1)
         cout, cin = w.shape[0], w.shape[1]
         if ctx.needs_input_grad[0]:
             if stride == 1 and pad == 7 and (cout, 1, cin) in ConvSplitFn.SUPPORTED:
                 # the data gradient of a stride-1 'same' convolution is the same convolution with the taps reversed and the
                 # channel roles swapped: the same kernel, fp32-grade like the forward
                 gx = ConvSplitFn.run(gy, w, 1, 7, transposed=True)[1]
-            elif WAV_SPLIT_DGRAD_STRIDED and pad == 0 and (cout, stride) in ((64, 6), (128, 6), (256, 3)) and (stride * cin) % 128 == 0:
+            elif pad == 0 and (cout, stride) in ((64, 6), (128, 6), (256, 3)) and (stride * cin) % 128 == 0:
                 # a strided convolution's data gradient = a stride-1 convolution over dy whose output rows are `stride` consecutive
                 # positions x cin channels (three 128-column launches of the forward kernel)
                 lib = _lib.load()
@@ -511,10 +475,9 @@ class ConvSplitFn(torch.autograd.Function):
                 _lib.check(lib.syn_conv1d_train_dgrad_strided(gy.data_ptr(), n, l_in, cin, stride, cout, whi.data_ptr(), wlo.data_ptr(),
                                                               gx.data_ptr(), _lib.current_stream(x.device)), "syn_conv1d_train_dgrad_strided")
             else:
-                gx = torch.ops.aten.convolution_backward(gy, x, w, None, *args, (True, False, False))[0]
+                raise _unsupported_conv("data gradient", cin, stride, pad, cout)
         if ctx.needs_input_grad[1]:
-            if (WAV_SPLIT_WGRAD and (cin, stride, cout) in ConvSplitFn.SUPPORTED and
-                    ((stride == 1 and pad == 7) or (WAV_SPLIT_WGRAD_STRIDED and stride > 1 and pad == 0))):
+            if (cin, stride, cout) in ConvSplitFn.SUPPORTED and ((stride == 1 and pad == 7) or (stride > 1 and pad == 0)):
                 # contraction over positions of two channels-last tensors: transposed through LDS inside the kernel (a strided layer
                 # as a stride-1 one over rows of stride x cin channels, a wave per 16 of them)
                 lib = _lib.load()
@@ -526,7 +489,7 @@ class ConvSplitFn(torch.autograd.Function):
                                                       _lib.current_stream(x.device)), "syn_conv1d_train_wgrad")
                 gw = gw.to(w.dtype)
             else:
-                gw = torch.ops.aten.convolution_backward(gy, x, w, None, *args, (False, True, False))[1]
+                raise _unsupported_conv("weight gradient", cin, stride, pad, cout)
         return gx, gw, None, None
 
 
@@ -564,16 +527,10 @@ class ConvFirstFn(torch.autograd.Function):
         return None, gw.reshape(wshape).to(wdtype), None, None
 
 
-WAV_SPLIT_DGRAD_STRIDED = True    # data gradients of the strided convolutions on syn_conv1d_train_dgrad_strided
-WAV_SPLIT_WGRAD = True    # weight gradients of the stride-1 convolutions on syn_conv1d_train_wgrad
-WAV_SPLIT_WGRAD_STRIDED = True    # ... and of the strided ones (k_conv_wgrad_s)
-WAV_FIRST_LAYER = True    # block 0's conv1 / shortcut convolution (1-2 input channels) on syn_conv1d_first_fwd / _wgrad
-WAV_SPLIT_FWD = True      # the encoder's forward convolutions on syn_conv1d_train_fwd (where the layer is one it covers)
-WAV_BF16_FROM = 0         # first encoder block that uses it
-WAV_BF16 = False          # False | 1: bf16 forward only (data and weight gradients fp32) | 2: bf16 forward + data gradient.
-                          # 2 measured 15.1 -> 12.3 ms per step at B = 32, but the gradients of the first encoder blocks
-                          # move by up to 14 % (vs 1 % in fp32): the backward chain through the 12 convolutions amplifies every
-                          # bf16 rounding ~1.5x per block (scripts/diag_train_grads.py)
+# (Every convolution of the encoder runs on the hand-written kernels: split-operand MFMA forward / data gradient / weight
+# gradient for the Conv1d(k = 15) layers from block 0's conv2 on, plain fp32 FMAs for the 1-2-channel first layer.  A geometry
+# none of them covers raises instead of dropping to a library convolution.  Measured and rejected: bf16 operands for these
+# convolutions - the gradients of the first encoder blocks move by up to 14 %)
 
 
 class BnActFn(torch.autograd.Function):
@@ -624,59 +581,59 @@ class BnActFn(torch.autograd.Function):
         return dy, dgb[0], dgb[1], dcb, dsh, None, None, None, None, None
 
 
-WAV_CONV_BN_STATS = bool(int(_os.environ.get("SYN_CONV_BN_STATS", "1")))   # BatchNorm's per-channel sums from the convolution's epilogue
-WAV_FUSED_BN = True       # training mode: BatchNorm (+ shortcut) (+ LeakyReLU) of the encoder on syn_bn_act_fwd / _bwd
+def _conv_raw(conv, x):
+    """The convolution alone (no bias) on channels_last (N, C, 1, L): the split-operand kernel for the Conv1d(k = 15) layers from
+    block 0's conv2 on, the plain-fp32 one for the 1-2-channel first layer.  Anything else raises."""
+    engine._require_cuda(x, "audio encoder input")
+    cin, stride, pad, cout = conv.in_channels, conv.stride[0], conv.padding[0], conv.out_channels
+    if x.dim() != 4 or conv.kernel_size[0] != 15 or conv.dilation[0] != 1:
+        raise _unsupported_conv("forward", cin, stride, pad, cout)
+    if (cin, stride, cout) in ConvSplitFn.SUPPORTED and pad % stride == 0:
+        return ConvSplitFn.apply(x, conv.weight.unsqueeze(2), stride, pad)
+    if cin in (1, 2) and cout == 64 and 1 <= stride <= 8 and not x.requires_grad:
+        n, _, _, l = x.shape                                                 # channels_last (N, cin, 1, L) = the waveform (N, L, cin)
+        return ConvFirstFn.apply(x.permute(0, 2, 3, 1).reshape(n, l, cin), conv.weight, stride, pad)
+    raise _unsupported_conv("forward", cin, stride, pad, cout)
 
 
-def _conv_raw(conv, x, bf16=False):
-    """The convolution alone (no bias) on (N, C, 1, L): the split-operand kernel where the layer is one it covers."""
-    if (WAV_SPLIT_FWD and not bf16 and x.is_cuda and x.dim() == 4 and conv.kernel_size[0] == 15 and
-            (conv.in_channels, conv.stride[0], conv.out_channels) in ConvSplitFn.SUPPORTED and conv.padding[0] % conv.stride[0] == 0):
-        return ConvSplitFn.apply(x, conv.weight.unsqueeze(2), conv.stride[0], conv.padding[0])
-    if (WAV_FIRST_LAYER and x.is_cuda and x.dim() == 4 and not x.requires_grad and conv.kernel_size[0] == 15 and conv.in_channels in (1, 2)
-            and conv.out_channels == 64 and conv.dilation[0] == 1 and 1 <= conv.stride[0] <= 8):
-        n, cin, _, l = x.shape                                               # channels_last (N, cin, 1, L) = the waveform (N, L, cin)
-        return ConvFirstFn.apply(x.permute(0, 2, 3, 1).reshape(n, l, cin), conv.weight, conv.stride[0], conv.padding[0])
-    if bf16:
-        return ConvBf16Fn.apply(x, conv.weight.unsqueeze(2), conv.stride[0], conv.padding[0])
-    return F.conv2d(x, conv.weight.unsqueeze(2), None, stride=(1, conv.stride[0]), padding=(0, conv.padding[0]))
-
-
-def _conv_bn_act(conv, bn, x, shortcut, act, bf16=False):
+def _conv_bn_act(conv, bn, x, shortcut, act):
     """Training-mode conv -> BatchNorm (batch statistics) [+ shortcut] [-> LeakyReLU] with the fused tail."""
-    y = _conv_raw(conv, x, bf16)
-    return BnActFn.apply(y, bn.weight, bn.bias, conv.bias, shortcut, bn.running_mean, bn.running_var,
-                         0.1 if bn.momentum is None else bn.momentum, bn.eps, act)
+    if bn.momentum is None:
+        raise _lib.SynHipError("the fused BatchNorm of the audio encoder implements the exponential running average (momentum = 0.1 in "
+                               "the reference, models/utils/layer.py:160); momentum=None asks for a cumulative average")
+    y = _conv_raw(conv, x)
+    z = BnActFn.apply(y, bn.weight, bn.bias, conv.bias, shortcut, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)                       # as nn.BatchNorm1d.forward does in train() mode (checkpoints carry it)
+    return z
 
 
-def _conv_bn(conv, bn, x, training, bf16=False):
-    """Conv1d + BatchNorm1d of the module (batch statistics in training, running statistics in eval) on (N, C, 1, L)."""
-    if (WAV_SPLIT_FWD and not bf16 and x.is_cuda and x.dim() == 4 and conv.kernel_size[0] == 15 and
-            (conv.in_channels, conv.stride[0], conv.out_channels) in ConvSplitFn.SUPPORTED and conv.padding[0] % conv.stride[0] == 0):
-        y = ConvSplitFn.apply(x, conv.weight.unsqueeze(2), conv.stride[0], conv.padding[0])
-        if conv.bias is not None:
-            y = y + conv.bias.view(1, -1, 1, 1)
-    elif bf16:
-        y = ConvBf16Fn.apply(x, conv.weight.unsqueeze(2), conv.stride[0], conv.padding[0])
-        if conv.bias is not None:
-            y = y + conv.bias.view(1, -1, 1, 1)
-    else:
-        y = F.conv2d(x, conv.weight.unsqueeze(2), conv.bias, stride=(1, conv.stride[0]), padding=(0, conv.padding[0]))
-    return F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, bn.momentum, bn.eps)
+def _conv_bn_eval(conv, bn, x):
+    """Conv1d + BatchNorm1d on the module's RUNNING statistics (eval() with autograd on: the gradient tests' deterministic mode)."""
+    y = _conv_raw(conv, x)
+    if conv.bias is not None:
+        y = y + conv.bias.view(1, -1, 1, 1)
+    return F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
 
 
-def _wav_block(blk, x, bf16=False):
-    """models/utils/layer.py:171-184 with the module's own Conv1d / BatchNorm1d (train or eval statistics)."""
-    if WAV_CHANNELS_LAST and x.dim() == 4 and WAV_FUSED_BN and blk.training and x.is_cuda and blk.bn1.track_running_stats:
-        z = _conv_bn_act(blk.conv1, blk.bn1, x, None, True, bf16)
-        short = x if blk.downsample is None else _conv_bn_act(blk.downsample[0], blk.downsample[1], x, None, False, bf16)
-        return _conv_bn_act(blk.conv2, blk.bn2, z, short, True, bf16)
-    if WAV_CHANNELS_LAST and x.dim() == 4:
-        tr = blk.training
-        z = F.leaky_relu(_conv_bn(blk.conv1, blk.bn1, x, tr, bf16), 0.01)
-        z = _conv_bn(blk.conv2, blk.bn2, z, tr, bf16)
-        short = x if blk.downsample is None else _conv_bn(blk.downsample[0], blk.downsample[1], x, tr, bf16)
-        return F.leaky_relu(z + short, 0.01)
+def _wav_block(blk, x):
+    """models/utils/layer.py:171-184 on channels_last (N, C, 1, L), train or eval statistics as the module says."""
+    if blk.training:
+        if not blk.bn1.track_running_stats:
+            raise _lib.SynHipError("the audio encoder's BatchNorms must track running statistics (the reference's do)")
+        z = _conv_bn_act(blk.conv1, blk.bn1, x, None, True)
+        short = x if blk.downsample is None else _conv_bn_act(blk.downsample[0], blk.downsample[1], x, None, False)
+        return _conv_bn_act(blk.conv2, blk.bn2, z, short, True)
+    z = F.leaky_relu(_conv_bn_eval(blk.conv1, blk.bn1, x), 0.01)
+    z = _conv_bn_eval(blk.conv2, blk.bn2, z)
+    short = x if blk.downsample is None else _conv_bn_eval(blk.downsample[0], blk.downsample[1], x)
+    return F.leaky_relu(z + short, 0.01)
+
+
+def _wav_block_modules(blk, x):
+    """The same block through its own nn.Modules on (N, C, L): ONLY for a model whose BatchNorms were converted to SyncBatchNorm
+    (train.py:90) - their statistics are all-reduced over the ranks inside the module's forward.  This path runs PyTorch-ROCm's
+    library convolutions; per-GPU statistics (the default) keep the encoder on the hand-written kernels."""
     short = x
     z = F.leaky_relu(blk.bn1(blk.conv1(x)), 0.01)
     z = blk.bn2(blk.conv2(z))
@@ -711,11 +668,13 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     # (train.py:90 may have converted the BatchNorms to SyncBatchNorm: their statistics are all-reduced over the ranks inside the
     # module's own forward, so those models take the module path below instead of the functional / fused one)
     sync_bn = any(isinstance(mod, nn.SyncBatchNorm) for mod in m.WavEncoder.modules())
-    if WAV_CHANNELS_LAST and not sync_bn:
+    if sync_bn:
+        for blk in m.WavEncoder.feat_extractor:
+            a = _wav_block_modules(blk, a)
+    else:
         a = a.unsqueeze(2).contiguous(memory_format=torch.channels_last)       # (B, C, 1, L), channel innermost
-    for i, blk in enumerate(m.WavEncoder.feat_extractor):
-        a = _wav_block(blk, a, WAV_BF16 and i >= WAV_BF16_FROM)
-    if a.dim() == 4:
+        for blk in m.WavEncoder.feat_extractor:
+            a = _wav_block(blk, a)
         a = a.squeeze(2)
     a_feat = a.transpose(1, 2).permute(1, 0, 2)                                  # (128, B, 256)
     w_feat = lin(_embed(m.text_pre_encoder_body, word), m.text_encoder_body).permute(1, 0, 2)
@@ -738,25 +697,17 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     # DropPath (timm_transformer/transformer.py:21-38: one Bernoulli(keep) / keep factor per sample and residual branch): all the
     # step's factors from one draw, and x + branch * factor as one fused multiply-add instead of bernoulli, div, mul, add per branch
     dp = None
-    if HIP_BLOCK_OPS and training and drop_path > 0.:
+    if training and drop_path > 0.:
         keep = 1. - drop_path
         dp = h.new_empty(2 * len(m.mytimmblocks), bs, 1, 1).bernoulli_(keep).div_(keep)
     for i, blk in enumerate(m.mytimmblocks):
-        if HIP_BLOCK_OPS:
-            z, h = HipLnForkFn.apply(h, blk.norm1.weight, blk.norm1.bias)
-            o = HipAttentionFn.apply(lin(z, blk.attn.qkv))           # (B, T, 3 x 4 heads x 128) -> (B, T, 512)
-            br = lin(o, blk.attn.proj)
-            h = h + br if dp is None else torch.addcmul(h, br, dp[2 * i])
-            z, h = HipLnForkFn.apply(h, blk.norm2.weight, blk.norm2.bias)
-            br = lin(HipGeluFn.apply(lin(z, blk.mlp.fc1)), blk.mlp.fc2)
-            h = h + br if dp is None else torch.addcmul(h, br, dp[2 * i + 1])
-        else:
-            z = F.layer_norm(h, (512,), blk.norm1.weight, blk.norm1.bias, 1e-5)
-            qkv = lin(z, blk.attn.qkv).reshape(bs, T, 3, 4, 128).permute(2, 0, 3, 1, 4)
-            o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], dropout_p=0.0).transpose(1, 2).reshape(bs, T, 512)
-            h = h + _drop_path(lin(o, blk.attn.proj), drop_path, training)
-            z = F.layer_norm(h, (512,), blk.norm2.weight, blk.norm2.bias, 1e-5)
-            h = h + _drop_path(lin(F.gelu(lin(z, blk.mlp.fc1)), blk.mlp.fc2), drop_path, training)
+        z, h = HipLnForkFn.apply(h, blk.norm1.weight, blk.norm1.bias)
+        o = HipAttentionFn.apply(lin(z, blk.attn.qkv))           # (B, T, 3 x 4 heads x 128) -> (B, T, 512)
+        br = lin(o, blk.attn.proj)
+        h = h + br if dp is None else torch.addcmul(h, br, dp[2 * i])
+        z, h = HipLnForkFn.apply(h, blk.norm2.weight, blk.norm2.bias)
+        br = lin(HipGeluFn.apply(lin(z, blk.mlp.fc1)), blk.mlp.fc2)
+        h = h + br if dp is None else torch.addcmul(h, br, dp[2 * i + 1])
     out = lin(h.permute(1, 0, 2), m.output_process.poseFinal)
     return out.reshape(T, bs, C, 1).permute(1, 2, 3, 0)
 

@@ -142,6 +142,25 @@ def main():
     out["beatx.train.gradnorm"] = np.array(list(gn.values()), np.float64)
     out["beatx.train.gradnorm_names"] = np.array(list(gn.keys()))
 
+    # ---- a10, train mode ("a DropPath-disabled train-mode variant"): BatchNorm on BATCH statistics, the path
+    # _g_training (diffusion_rvqvae_trainer.py:339-356) really runs.  DropPath is the only random element of the beatx model in
+    # train() mode (its style dropout sits behind use_motionclip), so its probability is set to 0 on the reference's modules.
+    mt = synth.synth_fill_(RefMDM(args).train(), seed=0)
+    for mod in mt.modules():
+        if type(mod).__name__ == "DropPath":
+            mod.drop_prob = 0.0
+    mt.zero_grad()
+    terms = ddpm.training_losses(mt, x0, t4, model_kwargs={"y": y4}, noise=eps)
+    out["beatx.trainmode.loss"] = f32(terms["loss"])
+    terms["loss"].mean().backward()
+    out["beatx.trainmode.gradnorm"] = np.array([dict(mt.named_parameters())[n].grad.norm().item() for n in gn], np.float64)
+    sdt = mt.state_dict()
+    for i in (0, 3, 5):                              # the BatchNorm buffers after this ONE training forward (momentum 0.1)
+        for b in ("running_mean", "running_var", "num_batches_tracked"):
+            out[f"beatx.trainmode.bn.{i}.bn1.{b}"] = sdt[f"WavEncoder.feat_extractor.{i}.bn1.{b}"].double().numpy()
+    out["beatx.trainmode.bn.0.downsample.running_mean"] = sdt["WavEncoder.feat_extractor.0.downsample.1.running_mean"].double().numpy()
+    out["beatx.trainmode.bn.5.bn2.running_var"] = sdt["WavEncoder.feat_extractor.5.bn2.running_var"].double().numpy()
+
     # ---- h3d variant: flags + CFG wrappers ----------------------------------------------
     mh = synth.synth_fill_(RefMDMH3D(args).eval(), seed=0)
     yh = synth.synth_clip_inputs(2, seed=7, style_dim=256, style_zero=False)

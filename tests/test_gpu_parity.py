@@ -440,6 +440,60 @@ def test_training_loss_and_gradients(golden):
     assert params["embed_style.weight"].grad is None     # never used in forward
 
 
+def test_train_mode_loss_gradients_and_bn_buffers_vs_golden(golden):
+    """The path `bench.py --mode train` and the reference's `_g_training` (diffusion_rvqvae_trainer.py:339-356) run: model.train(),
+    BatchNorm on BATCH statistics through the fused `BnActFn` tail (conv bias dropped and re-added into the running mean, sums from
+    the convolution's epilogue, first layer on `ConvFirstFn`), against the reference in train() mode with DropPath's probability 0
+    (tests/golden/make_golden.py): loss, gradient norms, the BatchNorm buffers after the forward, and every parameter's
+    gradient against autograd through the oracle's train-mode branch (gaussian_diffusion.py:1236-1363, models/utils/layer.py:144-184)."""
+    from oracle import denoiser_ref as dr
+    from oracle.process_ref import RefProcess
+    from syntalker_amd.process import create_gaussian_diffusion
+    m = _model("beatx").train()
+    m.drop_path = 0.0                                  # (the golden's only departure from train(): DropPath is random)
+    y = synth.synth_clip_inputs(4, seed=5)
+    x0, eps = synth.synth_latent(4, seed=5, name="x0"), synth.synth_latent(4, seed=6, name="eps")
+    t4 = torch.tensor([0, 17, 500, 999])
+    d = create_gaussian_diffusion()
+    terms = d.training_losses(m, x0.to(DEV), t4.to(DEV), model_kwargs={"y": synth.to_device(y, DEV)}, noise=eps.to(DEV))
+    loss = terms["loss"]
+    print("train-mode loss got / want:", loss.detach().cpu().numpy() / golden["beatx.trainmode.loss"])
+    assert np.allclose(loss.detach().cpu().numpy(), golden["beatx.trainmode.loss"], rtol=2e-2)
+    assert not np.allclose(golden["beatx.trainmode.loss"], golden["beatx.train.loss"], rtol=1e-3)     # (it is not the eval-mode number)
+    loss.mean().backward()
+    params = dict(m.named_parameters())
+    names = [str(n) for n in golden["beatx.train.gradnorm_names"]]
+    got = np.array([params[n].grad.norm().item() for n in names])
+    print("train-mode grad norms got/want:", got / golden["beatx.trainmode.gradnorm"])
+    assert np.allclose(got, golden["beatx.trainmode.gradnorm"], rtol=3e-2)
+    # BatchNorm buffers after ONE training forward: running = 0.9 old + 0.1 batch (unbiased variance), counters incremented
+    sd_after = m.state_dict()
+    for key, name in [(f"beatx.trainmode.bn.{i}.bn1.{b}", f"WavEncoder.feat_extractor.{i}.bn1.{b}") for i in (0, 3, 5)
+                      for b in ("running_mean", "running_var", "num_batches_tracked")] + \
+                     [("beatx.trainmode.bn.0.downsample.running_mean", "WavEncoder.feat_extractor.0.downsample.1.running_mean"),
+                      ("beatx.trainmode.bn.5.bn2.running_var", "WavEncoder.feat_extractor.5.bn2.running_var")]:
+        have, want = sd_after[name].double().cpu().numpy(), golden[key]
+        assert np.allclose(have, want, rtol=2e-3, atol=2e-4), (name, np.abs(have - want).max())
+    # every parameter's gradient against autograd through the oracle in the same mode
+    buffers = ("running_mean", "running_var", "num_batches_tracked", ".pe", "inv_freq")
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(buffers)) for k, v in synth_state_dict("beatx").items()}
+    ref = RefProcess(False).training_losses(lambda a, b, c: dr.mdm_forward(sd, a, b, c, train_bn=True), x0, t4, y, eps)["loss"].mean()
+    ref.backward()
+    worst = 0.0
+    for n, p in params.items():
+        if p.grad is None or n not in sd or sd[n].grad is None or float(sd[n].grad.norm()) == 0.0:
+            continue
+        if float(sd[n].grad.norm()) < 1e-5:             # a convolution's bias in front of a batch-statistics BatchNorm: zero up to
+            assert float(p.grad.norm()) < 1e-5, n       # rounding in the oracle (3e-8), exactly zero here
+            continue
+        e = rel_l2(p.grad.cpu(), sd[n].grad)
+        worst = max(worst, e)
+        assert e < 3e-2, (n, e)
+    print(f"train mode: worst per-tensor gradient rel-L2 vs oracle: {worst:.3e}")
+    # conv biases in front of a batch-statistics BatchNorm take exactly zero gradient in both
+    assert float(params["WavEncoder.feat_extractor.1.conv1.bias"].grad.abs().max()) < 1e-6
+
+
 def test_train_mode_step_runs_and_updates(beatx):
     """train(): BatchNorm batch statistics + DropPath; one Adam step (lr, betas of optimizers/optim_factory.py:122)."""
     from syntalker_amd import training

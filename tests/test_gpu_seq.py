@@ -96,7 +96,10 @@ def test_noisy_steps_fused_generator_and_injected_noise_agree(beatx):
         c = coef[500].double()
         want = c[0] * sb.x0.double() + c[1] * x_before.double() + c[2] * sb.noise.double()
         assert rel_l2(sb.x.double().cpu(), want.cpu()) < 1e-6
-        assert torch.equal(sb.xb.float(), sb.x.to(torch.bfloat16).float().view(sb.xb.shape) if False else sb.xb.float())
+        # the bf16 operands the kernel leaves for the NEXT step's input GEMM are exactly bf16(x_next), in the operand layout:
+        # fp32 [clip][nf][q = 2c + eh][lane][r]  ->  bf16 [clip][nf][c][lane][e = 4 eh + r]
+        shadow = sb.x.view(B, 48, 2, 2, 64, 4).permute(0, 1, 2, 4, 3, 5).reshape(B, 48, 2, 64, 8).to(torch.bfloat16)
+        assert torch.equal(sb.xb.view(torch.bfloat16).reshape(B, 48, 2, 64, 8), shadow)
         outs.append(sb.read(sb.x).cpu())
     assert torch.equal(outs[0], outs[1])
 

@@ -79,6 +79,34 @@ def test_training_loss_value(golden):
     assert np.allclose(terms["loss"].numpy(), golden["beatx.train.loss"], rtol=2e-6, atol=0)
 
 
+def test_train_mode_loss_gradients_and_bn_buffers(golden):
+    """The oracle's train() branch (BatchNorm on batch statistics) against the reference in train() mode with DropPath off:
+    loss, the six gradient norms and the BatchNorm buffers after one forward (gaussian_diffusion.py:1236-1363 driving
+    models/utils/layer.py:144-184; diffusion_rvqvae_trainer.py:339-356)."""
+    buffers = ("running_mean", "running_var", "num_batches_tracked", ".pe", "inv_freq")
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(buffers)) for k, v in synth_state_dict("beatx").items()}
+    y = synth.synth_clip_inputs(4, seed=5)
+    x0, eps = synth.synth_latent(4, seed=5, name="x0"), synth.synth_latent(4, seed=6, name="eps")
+    nb = {}
+    fn = lambda a, b, c: dr.mdm_forward(sd, a, b, c, train_bn=True, new_buffers=nb)
+    terms = RefProcess(False).training_losses(fn, x0, torch.tensor([0, 17, 500, 999]), y, eps)
+    assert np.allclose(terms["loss"].detach().numpy(), golden["beatx.trainmode.loss"], rtol=5e-6, atol=0)
+    assert not np.allclose(golden["beatx.trainmode.loss"], golden["beatx.train.loss"], rtol=1e-3)      # the two modes differ
+    terms["loss"].mean().backward()
+    names = [str(n) for n in golden["beatx.train.gradnorm_names"]]
+    got = np.array([sd[n].grad.norm().item() for n in names])
+    assert np.allclose(got, golden["beatx.trainmode.gradnorm"], rtol=2e-4), got / golden["beatx.trainmode.gradnorm"]
+    for i in (0, 3, 5):
+        for b in ("running_mean", "running_var", "num_batches_tracked"):
+            want = golden[f"beatx.trainmode.bn.{i}.bn1.{b}"]
+            have = nb[f"WavEncoder.feat_extractor.{i}.bn1.{b}"].double().numpy()
+            assert np.allclose(have, want, rtol=1e-5, atol=1e-6), (i, b)
+    assert np.allclose(nb["WavEncoder.feat_extractor.0.downsample.1.running_mean"].double().numpy(),
+                       golden["beatx.trainmode.bn.0.downsample.running_mean"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(nb["WavEncoder.feat_extractor.5.bn2.running_var"].double().numpy(),
+                       golden["beatx.trainmode.bn.5.bn2.running_var"], rtol=1e-5, atol=1e-6)
+
+
 def test_h3d_flags_and_guidance(golden):
     sd = synth_state_dict("h3d")
     fn = _model_fn(sd, "h3d")
