@@ -166,6 +166,13 @@ def ptr(t):
 
 
 def current_stream(device=None):
-    """Raw hipStream_t of torch's current stream on `device` (a tensor's device; default: the current device)."""
+    """Raw hipStream_t of torch's current stream on `device` (a tensor's device; default: the current device).
+    The library launches on the CURRENT HIP device (kernel attributes, device queries): a tensor that lives on another GPU than
+    the one the calling thread has selected is refused here instead of being launched onto a stream that is not current."""
     import torch
+    if device is not None:
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+            raise SynHipError(f"tensors on {dev} but the current device is cuda:{torch.cuda.current_device()}: select the device first "
+                              "(torch.cuda.set_device / `with torch.cuda.device(...)`, as nn.DataParallel and DDP do)")
     return torch.cuda.current_stream(device).cuda_stream

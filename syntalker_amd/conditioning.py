@@ -269,6 +269,21 @@ class ClipConditioner:
         style = None if style is None else style.detach().float().contiguous()
         seed = y["seed"].detach().reshape(bs, -1).float().contiguous()
         word = word.detach().to(torch.int64).contiguous()
+        # the kernels index these buffers by their nominal shapes: refuse anything else before the launch (a wrong shape would be
+        # read out of bounds on the device; an out-of-range word id raises in the reference's nn.Embedding)
+        if tuple(word.shape) != (bs, 128):
+            raise _lib.SynHipError(f"y['word'] must be ({bs}, 128) word ids per 128-pose-frame clip, got {tuple(word.shape)}")
+        if seed.shape[1] != w.seed_dim:
+            raise _lib.SynHipError(f"y['seed'] must flatten to {w.seed_dim} values per clip (4 x 1536 seed latents), got {seed.shape[1]}")
+        if style is not None and tuple(style.shape) != (bs, w.style_dim):
+            raise _lib.SynHipError(f"style_feature must be ({bs}, {w.style_dim}) (or (1, {w.style_dim}) to broadcast), got {tuple(style.shape)}")
+        if (style is None) != (w.style_dim == 0):
+            raise _lib.SynHipError("style_feature given to a model without a style input (or missing for one that has it)")
+        if feat.shape[0] != bs or word.device != dev or seed.device != dev or (style is not None and style.device != dev):
+            raise _lib.SynHipError("conditioning inputs disagree on batch size or device")
+        lo, hi = int(word.min()), int(word.max())
+        if lo < 0 or hi >= w.vocab:
+            raise IndexError(f"word id out of range: [{lo}, {hi}] for a vocabulary of {w.vocab} (nn.Embedding would raise too)")
         out = torch.empty(bs, 32, D, dtype=torch.float32, device=dev)
         d = torch.empty(bs, D, dtype=torch.float32, device=dev)
         _lib.check(_lib.load().syn_cond_encode(C.byref(w.c_struct()), feat.data_ptr(), word.data_ptr(), seed.data_ptr(), _lib.ptr(style),

@@ -1655,12 +1655,25 @@ void allow_lds(K kernel, int bytes) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// One-time, PER-DEVICE launch setup (hipFuncSetAttribute applies to the current device's copy of the kernel): a process that
+// drives several GPUs (nn.DataParallel replicas, one thread each) raises the LDS limit on every one of them.
+constexpr int kMaxDevices = 64;
+struct OncePerDevice {
+    bool done[kMaxDevices] = {};
+    bool first() {                                         // true exactly once per device (callers are serialised per device by their stream)
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return true;
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 int launch_attn_block(const AArgs& a, int mt, hipStream_t s) {
-    static bool once = false;
-    if (!once) {
+    static OncePerDevice once;
+    if (once.first()) {
         allow_lds(k_attn_block<128>, 2 * 128 * 128 + 2 * 128 * 256 + 4 * 128 * 72);
         allow_lds(k_attn_block<64>, 2 * 64 * 128 + 2 * 64 * 256 + 2 * 128 * 72);
-        once = true;
     }
     dim3 grid((a.M + mt - 1) / mt), block(kThreads);
     switch (mt) {
@@ -1674,11 +1687,10 @@ int launch_attn_block(const AArgs& a, int mt, hipStream_t s) {
 }
 
 int launch_mlp_block(const BArgs& a, int mt, hipStream_t s) {
-    static bool once = false;
-    if (!once) {
+    static OncePerDevice once;
+    if (once.first()) {
         allow_lds(k_mlp_block<64>, 64 * 2304);
         allow_lds(k_mlp_block<32>, 32 * 2304);
-        once = true;
     }
     dim3 grid((a.M + mt - 1) / mt), block(kThreads);
     switch (mt) {
@@ -1691,11 +1703,10 @@ int launch_mlp_block(const BArgs& a, int mt, hipStream_t s) {
 }
 
 int launch_stack(const SArgs& a, int mt, hipStream_t s) {
-    static bool once = false;
-    if (!once) {
+    static OncePerDevice once;
+    if (once.first()) {
         allow_lds(k_stack<64>, 64 * 2048 + 4096);
         allow_lds(k_stack<32>, 32 * 2048 + 4096);
-        once = true;
     }
     dim3 grid((a.M + mt - 1) / mt), block(kThreads);
     if (a.tp > 1) {
@@ -1704,8 +1715,8 @@ int launch_stack(const SArgs& a, int mt, hipStream_t s) {
         if (grid.x > 256) return fail_msg("stack: the tensor-parallel mode needs all its workgroups resident (<= 256)");
     }
     if (a.tp > 1) {
-        static bool once_tp = false;
-        if (!once_tp) { allow_lds(k_stack<32, 2>, 32 * 2048 + 4096); allow_lds(k_stack<32, 4>, 32 * 2048 + 4096); once_tp = true; }
+        static OncePerDevice once_tp;
+        if (once_tp.first()) { allow_lds(k_stack<32, 2>, 32 * 2048 + 4096); allow_lds(k_stack<32, 4>, 32 * 2048 + 4096); }
         if (a.tp == 4) hipLaunchKernelGGL((k_stack<32, 4>), grid, block, 32 * 2048 + 4096, s, a);
         else if (a.tp == 2) hipLaunchKernelGGL((k_stack<32, 2>), grid, block, 32 * 2048 + 4096, s, a);
         else return fail_msg("stack: tile split over 2 or 4 workgroups only");
@@ -1755,8 +1766,8 @@ WavPlan wav_plan(int L) {
 template <int CINP, int KT, int WN, int WM, int RF, int EPI>
 int launch_conv(const wav::CArgs& a, int n_clips, hipStream_t s) {
     constexpr int MW = WM * RF * 16, lds = (MW + KT - 1) * (CINP * 2 + 16);
-    static bool once = false;
-    if (!once) { allow_lds(wav::k_conv<CINP, KT, WN, WM, RF, EPI>, lds); once = true; }
+    static OncePerDevice once;
+    if (once.first()) { allow_lds(wav::k_conv<CINP, KT, WN, WM, RF, EPI>, lds); }
     hipLaunchKernelGGL((wav::k_conv<CINP, KT, WN, WM, RF, EPI>), dim3((a.L_out + MW - 1) / MW, n_clips), dim3(WN * WM * 64), lds, s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv launch", e);
@@ -1766,8 +1777,8 @@ template <int CINP, int KT, int RF>
 int launch_conv_train_ks(const wav::TArgs& a, int n_clips, hipStream_t s) {
     constexpr int MW = RF * 16, lds = 2 * (MW + KT - 1) * (CINP * 2 + 16);
     static_assert(lds <= 160 * 1024, "two bf16 planes of the input tile must fit the LDS");
-    static bool once = false;
-    if (!once) { allow_lds(wav::k_conv_train_ks<CINP, KT, RF>, lds); once = true; }
+    static OncePerDevice once;
+    if (once.first()) { allow_lds(wav::k_conv_train_ks<CINP, KT, RF>, lds); }
     hipLaunchKernelGGL((wav::k_conv_train_ks<CINP, KT, RF>), dim3((a.L_out + MW - 1) / MW, n_clips), dim3(256), lds, s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_train_ks launch", e);
@@ -1777,8 +1788,8 @@ template <int CINP, int KT, int WN, int WM, int RF>
 int launch_conv_train(const wav::TArgs& a, int n_clips, hipStream_t s) {
     constexpr int MW = WM * RF * 16, lds = 2 * (MW + KT - 1) * (CINP * 2 + 16);
     static_assert(lds <= 160 * 1024, "two bf16 planes of the input tile must fit the LDS");
-    static bool once = false;
-    if (!once) { allow_lds(wav::k_conv_train<CINP, KT, WN, WM, RF>, lds); once = true; }
+    static OncePerDevice once;
+    if (once.first()) { allow_lds(wav::k_conv_train<CINP, KT, WN, WM, RF>, lds); }
     hipLaunchKernelGGL((wav::k_conv_train<CINP, KT, WN, WM, RF>), dim3((a.L_out + MW - 1) / MW, n_clips), dim3(WN * WM * 64), lds, s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_train launch", e);
@@ -1787,8 +1798,8 @@ int launch_conv_train(const wav::TArgs& a, int n_clips, hipStream_t s) {
 template <int CO_T, int TAPS>
 int launch_wgrad_s(const wav::WArgs& a, hipStream_t s) {
     static_assert(wav::wgrad_s_lds(CO_T) <= 160 * 1024, "dy and x' tiles must fit the LDS");
-    static bool once = false;
-    if (!once) { allow_lds(wav::k_conv_wgrad_s<CO_T, TAPS>, wav::wgrad_s_lds(CO_T)); once = true; }
+    static OncePerDevice once;
+    if (once.first()) { allow_lds(wav::k_conv_wgrad_s<CO_T, TAPS>, wav::wgrad_s_lds(CO_T)); }
     hipLaunchKernelGGL((wav::k_conv_wgrad_s<CO_T, TAPS>), dim3(a.cin / wav::kWsJ, a.shares, a.co_n / CO_T), dim3(512), wav::wgrad_s_lds(CO_T), s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_wgrad_s launch", e);
@@ -1796,17 +1807,17 @@ int launch_wgrad_s(const wav::WArgs& a, hipStream_t s) {
 
 template <int CO, int TAPS>
 int launch_wgrad(const wav::WArgs& a, hipStream_t s) {
-    static bool once = false;
+    static OncePerDevice once;
     constexpr int CB = wav::wgrad_cb(CO);
-    if (!once) { allow_lds(wav::k_conv_wgrad<CO, TAPS, CB>, wav::wgrad_lds(CO)); once = true; }
+    if (once.first()) { allow_lds(wav::k_conv_wgrad<CO, TAPS, CB>, wav::wgrad_lds(CO)); }
     hipLaunchKernelGGL((wav::k_conv_wgrad<CO, TAPS, CB>), dim3(a.cin / (16 * CB), a.shares), dim3(512), wav::wgrad_lds(CO), s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_wgrad launch", e);
 }
 
 int launch_latency(const lat::LArgs& a, hipStream_t s) {
-    static bool once = false;
-    if (!once) { allow_lds(lat::k_lat, lat::kLds); once = true; }
+    static OncePerDevice once;
+    if (once.first()) { allow_lds(lat::k_lat, lat::kLds); }
     hipLaunchKernelGGL(lat::k_lat, dim3(lat::kGroups * lat::kP), dim3(kThreads), lat::kLds, s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_lat launch", e);
@@ -1820,8 +1831,8 @@ int seq_grid(int n_clips, int n_variants) {
 
 template <bool G, int NZ>
 void launch_seq_as(const seq::QArgs& a, const dim3 grid, hipStream_t s) {
-    static bool once = false;
-    if (!once) { allow_lds(seq::k_seq<G, NZ>, seq::kLds); once = true; }
+    static OncePerDevice once;
+    if (once.first()) { allow_lds(seq::k_seq<G, NZ>, seq::kLds); }
     hipLaunchKernelGGL((seq::k_seq<G, NZ>), grid, dim3(seq::kThreads), seq::kLds, s, a);
 }
 
@@ -1983,8 +1994,8 @@ int syn_vq_conv1d(const syn_vq_conv* cv, const void* x_bf16, const float* resid,
     const int rows = (((mt - 1) * cv->stride + (cv->taps - 1) * cv->dil) >> cv->up) + 2;
     const int lds = rows * (cv->cin * 2 + 16);
     if (lds > 160 * 1024) return fail_msg("syn_vq_conv1d: input window does not fit LDS");
-    static bool once = false;
-    if (!once) { allow_lds(rvq::k_conv1d<2>, 160 * 1024); once = true; }
+    static OncePerDevice once;
+    if (once.first()) { allow_lds(rvq::k_conv1d<2>, 160 * 1024); }
     const dim3 grid((t_out + mt - 1) / mt, cv->cout / 128, clips);
     hipLaunchKernelGGL(rvq::k_conv1d<mf>, grid, dim3(rvq::kCvThreads), lds, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
@@ -2214,8 +2225,8 @@ int syn_test_handoff(uint32_t* sync_320_zeroed, uint32_t* buf_8x4096, const floa
     if (!sync_320_zeroed || !buf_8x4096 || !stale_9_zeroed || words <= 0 || words > 4096 || rounds <= 0 || mode < 0 || mode > 4)
         return fail_msg("syn_test_handoff: bad arguments");
     if (!latency_path_ok()) return fail_msg("syn_test_handoff: needs a 256-CU (8 XCD x 32) device");
-    static bool once = false;
-    if (!once) { allow_lds(lat::k_handoff_stress, 96 * 1024); once = true; }
+    static OncePerDevice once;
+    if (once.first()) { allow_lds(lat::k_handoff_stress, 96 * 1024); }
     lat::HArgs a;
     a.sync = sync_320_zeroed; a.buf = buf_8x4096; a.stream = stream; a.stream_n = stream_n; a.stale = stale_9_zeroed;
     a.words = words; a.rounds = rounds; a.mode = mode;
@@ -2333,9 +2344,9 @@ int syn_attn_fwd(const float* qkv, float* o, int32_t n_seq, void* stream) {
 
 int syn_attn_bwd(const float* qkv, const float* d_o, float* dqkv, int32_t n_seq, void* stream) {
     if (!qkv || !d_o || !dqkv || n_seq <= 0) return fail_msg("syn_attn_bwd: bad arguments");
-    static bool once = false;
+    static OncePerDevice once;
     static const bool v1 = getenv("SYN_ATTN_BWD_V1") != nullptr;    // diagnostics: the first version of the kernel (one LDS float per FMA)
-    if (!once) { allow_lds(trn::k_attn_bwd, trn::kAttnBwdLds); allow_lds(trn::k_attn_bwd2, trn::kAttnBwd2Lds); once = true; }
+    if (once.first()) { allow_lds(trn::k_attn_bwd, trn::kAttnBwdLds); allow_lds(trn::k_attn_bwd2, trn::kAttnBwd2Lds); }
     if (v1) hipLaunchKernelGGL(trn::k_attn_bwd, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnBwdLds, (hipStream_t)stream, qkv, d_o, dqkv);
     else hipLaunchKernelGGL(trn::k_attn_bwd2, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnBwd2Lds, (hipStream_t)stream, qkv, d_o, dqkv);
     hipError_t e = hipGetLastError();
@@ -2375,8 +2386,8 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, 
     const long cs = p.per_clip;
     int rc;
     {   // block 0 in one kernel: conv1 recomputed into the LDS tile, shortcut as the accumulators' initial value
-        static bool once = false;
-        if (!once) { allow_lds(wav::k_block0, wav::kB0Lds); once = true; }
+        static OncePerDevice once;
+        if (once.first()) { allow_lds(wav::k_block0, wav::kB0Lds); }
         wav::B0Args b;
         b.wav = wav_in; b.wav_clip_stride = (long)n_samples * enc->cin; b.L = n_samples; b.cin = enc->cin; b.L1 = p.L1;
         b.w_first = enc->w_first; b.W2 = (const uint4*)enc->conv[0].w; b.bias2 = enc->conv[0].bias;

@@ -156,6 +156,7 @@ class GaussianDiffusion:
             noise = torch.randn_like(x_start)
         assert noise.shape == x_start.shape
         if (x_start.is_cuda and x_start.dtype is torch.float32 and noise.dtype is torch.float32
+                and torch.is_tensor(t) and t.device == x_start.device and noise.device == x_start.device
                 and not (torch.is_grad_enabled() and (x_start.requires_grad or noise.requires_grad))
                 and x_start.dim() > 1 and (x_start.numel() // x_start.shape[0]) % 4 == 0):
             from . import _lib
@@ -164,9 +165,11 @@ class GaussianDiffusion:
                 np.stack([self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod], 1), dtype=torch.float32, device=dev))
             xs, nz = x_start.contiguous(), noise.contiguous()
             out = torch.empty_like(xs)
-            _lib.check(_lib.load().syn_axpby_rows(xs.data_ptr(), nz.data_ptr(), ab.data_ptr(), t.to(torch.int32).contiguous().data_ptr(),
+            t32 = t.to(torch.int32).contiguous()             # (held in a local until the launch is enqueued)
+            _lib.check(_lib.load().syn_axpby_rows(xs.data_ptr(), nz.data_ptr(), ab.data_ptr(), t32.data_ptr(),
                                                   xs.shape[0], xs.numel() // xs.shape[0], out.data_ptr(), _lib.current_stream(dev)),
                        "syn_axpby_rows")
+            del t32
             return out
         return self._tab("sqrt_alphas_cumprod", t, x_start) * x_start + \
             self._tab("sqrt_one_minus_alphas_cumprod", t, x_start) * noise

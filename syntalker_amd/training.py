@@ -715,6 +715,13 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
 UNUSED_IN_FORWARD = ("embed_style", "uncon_audio_embeddings", "uncon_text_embeddings")
 
 
+DDP_BUCKET_MB = 32      # 118 MB of fp32 gradients -> 4 all-reduces (+ PyTorch's small first bucket, which starts the stream of collectives
+                        # as soon as the output projection's gradients exist).  xGMI is point-to-point, a ring all-reduce is per-link
+                        # bound (7 links x ~153 GB/s per GPU): at 8 GPUs a 32 MB bucket is ~0.4 ms on the wire, short enough to overlap
+                        # with a ~5 ms backward in four pieces, long enough that RCCL's launch latency (tens of us) stays below 10 %.
+                        # (round 2 used 64 MB = two buckets: the second all-reduce could only start when backward was nearly over.)
+
+
 def make_ddp(model, local_rank: int | None = None, sync_bn: bool = False, capturable: bool = False):
     """One process per GPU, gradients all-reduced over RCCL (backend "nccl"); `embed_style` and the h3d
     `uncon_*_embeddings` never receive gradients (unused in forward), hence find_unused_parameters.
@@ -730,7 +737,19 @@ def make_ddp(model, local_rank: int | None = None, sync_bn: bool = False, captur
                 p.requires_grad_(False)
     dev_ids = None if local_rank is None else [local_rank]
     return DDP(model, device_ids=dev_ids, broadcast_buffers=False, find_unused_parameters=not capturable,
-               gradient_as_bucket_view=True, bucket_cap_mb=64)
+               gradient_as_bucket_view=True, bucket_cap_mb=DDP_BUCKET_MB)
+
+
+def ddp_bucket_sizes(ddp) -> list[int]:
+    """Bytes of gradient per all-reduce bucket of a DDP wrapper (tests, bench report).  Without the unused-parameter search DDP
+    runs its FIRST iteration on a single bucket and re-buckets by `bucket_cap_mb` in the order the gradients really arrived;
+    this returns the rebuilt plan once it exists (i.e. after the first backward)."""
+    try:
+        d = ddp._get_ddp_logging_data()
+        txt = d.get("rebuilt_bucket_sizes") or d.get("bucket_sizes", "")
+        return [int(b) for b in str(txt).split(",") if b.strip()]
+    except Exception:
+        return []
 
 
 def train_step(model, diffusion, sampler, optimizer, x0, model_kwargs, grad_norm: float = 0.99):
@@ -801,7 +820,7 @@ class GraphedTrainStep:
         self.graph.replay()
         if self.sync:
             torch.cuda.current_stream(self.x0.device).synchronize()
-        return self.loss
+        return self.loss.clone()        # (stream-ordered copy: the static tensor is overwritten by the next replay)
 
     def close(self):
         if getattr(self, "graph", None) is not None:

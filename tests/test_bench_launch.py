@@ -21,13 +21,31 @@ def _run(*extra, env=None):
     return r, lines
 
 
-@pytest.mark.parametrize("mode", ["sample", "train"])
+@pytest.mark.parametrize("mode", ["sample", "train", "guided"])
 def test_bench_starts_its_own_ranks(mode):
     r, lines = _run("--gpus", "2", "--mode", mode)
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1, r.stdout                      # rank 0 only
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["gloo_ranks"] == 2 and out["steps"] == 4 and out["dry_run"] is True and out["mode"] == mode
+    assert out["n_gpus"] == 2 and out["gloo_ranks"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and out["dry_run"] is True and out["mode"] == mode
+    if mode == "train":
+        # what the real run builds before its first step: the product MDM under make_ddp, eager by default with several ranks
+        assert out["parameters"] == 29_607_012 and out["graph_replayed"] is False
+        assert out["ddp"]["find_unused_parameters"] is True and out["ddp"]["frozen"] == [] and out["ddp"]["bucket_cap_mb"] == 32
+    if mode == "guided":
+        # BASELINE configs[3]: cond + uncond = 2 variants; configs[4]: the body-part wrapper's 9 evaluations de-duplicate to 4
+        assert out["plans"]["cfg"]["variants"] == 2 and out["plans"]["bodypart_twocfg"]["variants"] == 4
+        for plan in out["plans"].values():
+            assert all(abs(sum(row) - 1.0) < 1e-6 for row in plan["weights"])          # a guidance formula's weights sum to 1 per block
+
+
+def test_bench_train_dry_run_with_the_captured_step_wiring():
+    """--train-graph with several ranks: the wrapper is built for capture (unused parameters frozen, no search)."""
+    r, lines = _run("--gpus", "2", "--mode", "train", "--train-graph")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert out["graph_replayed"] is True and out["ddp"]["find_unused_parameters"] is False
+    assert out["ddp"]["frozen"] == ["embed_style.bias", "embed_style.weight"]
 
 
 def test_bench_single_rank_and_launcher_mismatch():

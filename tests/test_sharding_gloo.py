@@ -1,5 +1,7 @@
-"""world_size-2 gloo test (CPU) of the clip-sharded sampling path: slices, first_clip bookkeeping, ragged
-gather.  The denoiser is a stand-in module (the HIP MDM needs a GPU); the sharding code is the product's."""
+"""world_size-2 gloo tests (CPU) of the multi-GPU paths: clip-sharded sampling (slices, first_clip bookkeeping, ragged gather)
+and data-parallel training (DDP wiring of `training.make_ddp`).  First with toy modules (the sharding / DDP code alone), then
+with the PRODUCT's `MDM` - 29.6 M parameters, its packed() / buffers() / variant_conds() plumbing, `process._fused` - over the CPU
+stand-ins of the device engine in tests/cpu_engine.py (the HIP kernels need a GPU; the stand-ins run the oracle's arithmetic)."""
 import os
 import socket
 
@@ -164,3 +166,144 @@ def test_two_rank_ddp_prepared_for_graph_capture(tmp_path):
     (b(torch.tanh(a(data))) ** 2).mean().backward()
     for k, ref in (("a.weight", a.weight.grad), ("b.weight", b.weight.grad), ("b.bias", b.bias.grad)):
         assert torch.allclose(got["grads"][k], ref, atol=1e-6), k
+
+
+# ---- the product MDM through process._fused, clip-sharded over 2 ranks (engine = tests/cpu_engine.py) -------------------------
+def _mdm_case(variant):
+    from syntalker_amd import synth
+    n = 5
+    if variant == "h3d":
+        y = synth.synth_clip_inputs(n, seed=21, style_dim=256, style_zero=False)
+        y["scale"] = torch.ones(1) * 2.5
+    else:
+        y = synth.synth_clip_inputs(n, seed=21)
+    return (n, 1536, 1, 32), y
+
+
+def _mdm_model(variant):
+    from syntalker_amd import guidance, synth
+    if variant == "h3d":
+        from syntalker_amd.denoiser_h3d import MDM
+        return guidance.ClassifierFreeSampleModel(synth.synth_fill_(MDM(synth.default_args()).eval(), seed=0))
+    from syntalker_amd.denoiser import MDM
+    return synth.synth_fill_(MDM(synth.default_args()).eval(), seed=0)
+
+
+def _mdm_sample(variant, sharded):
+    """24 DDPM steps with the noise drawn per (seed, step, global clip): two 10-step replays + four single steps."""
+    from tests import cpu_engine
+    cpu_engine.install_plain()
+    d = process.create_gaussian_diffusion()
+    shape, y = _mdm_case(variant)
+    model = _mdm_model(variant)
+    kw = dict(noise=None, seed=11, clip_denoised=False, skip_timesteps=976)
+    if sharded:
+        return sample_sharded(d, model, shape, {"y": dict(y)}, **kw)
+    from syntalker_amd.sharding import draw_x_T
+    return d.p_sample_loop(model, shape, noise=draw_x_T(shape[0], shape[1:], 11, 0, "cpu"), clip_denoised=False,
+                           model_kwargs={"y": dict(y)}, skip_timesteps=976, seed=11)
+
+
+def _mdm_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(4)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = {v: _mdm_sample(v, True) for v in ("beatx", "h3d")}
+        if rank == 0:
+            torch.save(res, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_sampling_of_the_product_mdm(tmp_path):
+    """sample_sharded -> p_sample_loop -> process._fused -> MDM.packed / buffers / variant_conds -> StepGraph schedule hand-over,
+    with the plain BEAT-X model and with ClassifierFreeSampleModel over the h3d one (V = 2 fused variants, cfg weights): the 2-rank
+    result equals the single-process one - x_T and the step noise follow the GLOBAL clip index (first_clip), not the local one."""
+    out = str(tmp_path / "mdm.pt")
+    mp.spawn(_mdm_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    for v in ("beatx", "h3d"):
+        want = _mdm_sample(v, False)
+        assert got[v].shape == want.shape == (5, 1536, 1, 32) and torch.isfinite(want).all()
+        err = float((got[v] - want).norm() / want.norm())
+        assert err < 1e-5, (v, err)                    # (CPU GEMMs of 2 / 3 clips against 5: fp32 re-association only)
+        # the wrong bookkeeping (local clip index on rank 1) would give clip 3 the noise of clip 0
+        assert float((got[v][3] - got[v][0]).abs().max()) > 1e-3
+
+
+# ---- DDP over the product's real parameter set (training.make_ddp, capturable: frozen unused parameters, no search) ---------
+def _oracle_train_forward(m, x, timesteps, y, drop_path=0.0):
+    """CPU stand-in for training.train_forward: the oracle's functional forward over the MODULE's own parameters (train-mode
+    BatchNorm), so autograd reaches every parameter the product's forward reaches."""
+    from oracle import denoiser_ref as dr
+    sd = dict(m.state_dict(keep_vars=True))          # (the live Parameters; shared buffers under every name the reference uses)
+    return dr.mdm_forward(sd, x, timesteps, y, variant=m.variant, train_bn=m.training)
+
+
+def _mdm_ddp_step(model, lo, hi):
+    from syntalker_amd import synth
+    d = process.create_gaussian_diffusion()
+    y = synth.synth_clip_inputs(4, seed=5)
+    x0, eps = synth.synth_latent(4, seed=5, name="x0"), synth.synth_latent(4, seed=6, name="eps")
+    t4 = torch.tensor([0, 17, 500, 999])
+    from syntalker_amd.sharding import shard_kwargs
+    loss = d.training_losses(model, x0[lo:hi], t4[lo:hi], model_kwargs={"y": shard_kwargs(y, lo, hi, 4)}, noise=eps[lo:hi])["loss"].mean()
+    loss.backward()
+    return float(loss)
+
+
+def _mdm_ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(4)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from syntalker_amd import synth, training
+        from syntalker_amd.denoiser import MDM
+        training.train_forward = _oracle_train_forward
+        model = synth.synth_fill_(MDM(synth.default_args()).eval(), seed=0)     # eval(): running-statistics BatchNorm, so that the
+        model.differentiable_eval = True                                         # rank-mean of shard gradients IS the full-batch gradient
+        w = training.make_ddp(model, capturable=True)
+        losses = []
+        for _ in range(3):                      # (a second iteration raises if a trainable parameter was left without a gradient; the
+                                                # bucket plan is rebuilt after the first and reported from the third on)
+            w.zero_grad()
+            lo, hi = shard_range(4, rank, world)
+            losses.append(_mdm_ddp_step(w, lo, hi))
+        if rank == 0:
+            names = ["mytimmblocks.0.attn.qkv.weight", "mytimmblocks.7.mlp.fc2.weight", "WavEncoder.feat_extractor.0.conv1.weight",
+                     "text_pre_encoder_body.weight", "output_process.poseFinal.bias"]
+            params = dict(w.module.named_parameters())
+            torch.save({"grads": {n: params[n].grad.clone() for n in names},
+                        "frozen": sorted(k for k, p in params.items() if not p.requires_grad),
+                        "n_params": sum(p.numel() for p in params.values()),
+                        "buckets": training.ddp_bucket_sizes(w), "find_unused": w.find_unused_parameters}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_ddp_over_the_real_parameter_set(tmp_path):
+    """make_ddp(capturable=True) around the product MDM (29.6 M parameters): the parameters the forward never reaches are frozen,
+    no unused-parameter search, the bucket plan covers the 118 MB of gradients in several all-reduces, and the rank-averaged
+    gradients of two half batches equal the single-process gradient of the whole batch (reference seam: train.py:87-94)."""
+    out = str(tmp_path / "ddp.pt")
+    mp.spawn(_mdm_ddp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["find_unused"] is False and got["n_params"] == 29_607_012
+    assert got["frozen"] == ["embed_style.bias", "embed_style.weight"]
+    mb = [b / 2 ** 20 for b in got["buckets"]]
+    assert len(mb) >= 4 and max(mb) <= 40 and abs(sum(mb) - 29_607_012 * 4 / 2 ** 20 + (6 * 64 + 64) * 4 / 2 ** 20) < 1.0, mb
+    from syntalker_amd import synth, training
+    from syntalker_amd.denoiser import MDM
+    orig = training.train_forward
+    training.train_forward = _oracle_train_forward
+    try:
+        model = synth.synth_fill_(MDM(synth.default_args()).eval(), seed=0)
+        model.differentiable_eval = True
+        _mdm_ddp_step(model, 0, 4)
+    finally:
+        training.train_forward = orig
+    params = dict(model.named_parameters())
+    for n, g in got["grads"].items():
+        err = float((g - params[n].grad).norm() / params[n].grad.norm())
+        assert err < 1e-4, (n, err)
