@@ -13,9 +13,11 @@ same permutation to the weights' K index (a contraction does not care in which o
 
 Fragment orders inside a piece (every piece is a multiple of 16 fragments = one 16 KB ring chunk):
   "wide16" [kc][tile 0..15]       all 16 tiles of the residual stream are live accumulators (input stage)
-  "wide"   [kc][tile 0..11], then tiles 12..15 in pair order: inside the blocks the wave keeps residual tiles 12..15 in
-                                  a private LDS slab (512 registers do not hold the residual stream, the LayerNorm output
-                                  and the working set at once); they are accumulated two at a time after the first twelve
+  "wide"   [kc][tile 0..15], the last k chunk as [tile 12..15][tile 0..11]: inside the blocks the wave keeps residual tiles
+                                  12..15 in a private LDS slab between the pieces (the accumulator file holds 256 registers: twelve
+                                  residual tiles + the q / k / v / fc1 accumulators); a wide piece loads them early and, with
+                                  them first in its last k chunk, stores them in the shadow of its last twelve MFMAs.  fc2 pieces
+                                  (split = 4) defer the slab tiles of their first four k chunks: [kc < 4][0..11], [kc < 4][12..15], ...
   "pair"   [pair][kc][u = 0, 1]   two tiles in flight, each finished tile is consumed at once (q, k, v, fc1, output)
 Tape order:
     input   A (512 x 1536)                                                   wide16  96 kc x 16 = 1536
@@ -42,6 +44,8 @@ rank-1 update h += bias (x) 1 (the "bias" pieces of the tape): no accumulator ro
 (reference: models/timm_transformer/transformer.py:83-104,145-151,195-198; models/denoiser.py:188-195.)
 """
 from __future__ import annotations
+
+import os as _os
 
 import torch
 
@@ -73,18 +77,30 @@ def wide16(w: torch.Tensor) -> torch.Tensor:
 REG_TILES = 12        # residual tiles the kernel keeps in registers; tiles 12..15 live in the wave's LDS slab (syn_seq.inc kRegTiles)
 
 
-def _split_order(f: torch.Tensor) -> torch.Tensor:
-    """fragments [kc][16 tiles] -> [kc][register tiles] followed by the slab tiles in pair order."""
+def _wide_order(f: torch.Tensor, split: int = 0) -> torch.Tensor:
+    """fragments [kc][16 tiles] -> the order `wide<KC, SPLIT>` of the kernel consumes: [kc < split][register tiles 0..11], then
+    [kc < split][slab tiles 12..15], then whole k chunks [tile 0..15] - the last one slab tiles first (their stores ride in the gaps of
+    the twelve MFMAs that follow)."""
     kc = f.shape[0]
-    head = f[:, :REG_TILES].reshape(-1, 64, 8)
-    tail = f[:, REG_TILES:].reshape(kc, (16 - REG_TILES) // 2, 2, 64, 8).permute(1, 0, 2, 3, 4).reshape(-1, 64, 8)
-    return torch.cat([head, tail], 0)
+    if _os.environ.get("SYN_TAPE_LEGACY_WIDE"):      # A/B only: the order an older libsyn_hip.so (kernel variants) consumes
+        head = f[:, :REG_TILES].reshape(-1, 64, 8)
+        tail = f[:, REG_TILES:].reshape(kc, (16 - REG_TILES) // 2, 2, 64, 8).permute(1, 0, 2, 3, 4).reshape(-1, 64, 8)
+        return torch.cat([head, tail], 0)
+    out = []
+    if split:
+        out += [f[:split, :REG_TILES].reshape(-1, 64, 8), f[:split, REG_TILES:].reshape(-1, 64, 8)]
+    for k in range(split, kc):
+        if kc > 1 and k == kc - 1:
+            out += [f[k, REG_TILES:], f[k, :REG_TILES]]
+        else:
+            out.append(f[k])
+    return torch.cat(out, 0)
 
 
-def wide(w: torch.Tensor) -> torch.Tensor:
+def wide(w: torch.Tensor, split: int = 0) -> torch.Tensor:
     """512-row weight slice accumulated into the residual stream."""
     assert w.shape[0] == 512
-    return _split_order(frag_tiles(w))
+    return _wide_order(frag_tiles(w), split)
 
 
 def bias_piece(b: torch.Tensor) -> torch.Tensor:
@@ -95,7 +111,7 @@ def bias_piece(b: torch.Tensor) -> torch.Tensor:
     f = torch.zeros(1, 16, 64, 8, dtype=torch.bfloat16, device=b.device)
     f[0, :, :32, 0] = hi.reshape(16, 32)
     f[0, :, :32, 1] = lo.reshape(16, 32)
-    return _split_order(f)
+    return _wide_order(f)
 
 
 def pair(w: torch.Tensor) -> torch.Tensor:
@@ -128,7 +144,7 @@ def build_tape(sd: dict, A: torch.Tensor):
         pieces.append(bias_piece(f64(sd[p + "mlp.fc2.bias"])))
         for c in range(FF // 128):
             r = slice(128 * c, 128 * c + 128)
-            pieces += [pair(w1[r] * g2[None, :]), wide(w2[:, r])]
+            pieces += [pair(w1[r] * g2[None, :]), wide(w2[:, r], split=4)]
         bias[l, 0:512] = wq @ b1n
         bias[l, 512:1536] = f64(sd[p + "mlp.fc1.bias"]) + w1 @ b2n
     wout = f64(sd["output_process.poseFinal.weight"])

@@ -67,17 +67,22 @@ class Wave:
             for t in range(16):
                 acc[t] = mfma32(self.frag(), b, acc[t])
 
-    def wide(self, acc, bfrag, n_kc):
-        """The same inside the blocks: tiles 0..11 [kc][tile], then tiles 12..15 (the LDS-resident ones) two at a time."""
-        for kc in range(n_kc):
+    def wide(self, acc, bfrag, n_kc, split=0):
+        """The same inside the blocks, in the fragment order of the kernel's `wide<KC, SPLIT>` (tape._wide_order): tiles 12..15 are
+        the LDS-resident ones; [kc < split][0..11], [kc < split][12..15], whole k chunks, the last one with tiles 12..15 first."""
+        def run(kc, tiles):
             b = bfrag(kc)
-            for t in range(12):
+            for t in tiles:
                 acc[t] = mfma32(self.frag(), b, acc[t])
-        for p in (12, 14):
-            for kc in range(n_kc):
-                b = bfrag(kc)
-                for u in range(2):
-                    acc[p + u] = mfma32(self.frag(), b, acc[p + u])
+        for kc in range(split):
+            run(kc, range(12))
+        for kc in range(split):
+            run(kc, range(12, 16))
+        for kc in range(split, n_kc):
+            if n_kc > 1 and kc == n_kc - 1:
+                run(kc, range(12, 16)); run(kc, range(12))
+            else:
+                run(kc, range(16))
 
     def pairs(self, init, bfrag, n_pairs, n_kc, done, swap=False):
         """Two tiles in flight, tape order [pair][kc][u]; done(tile index, tile) consumes each finished tile.
@@ -166,7 +171,7 @@ class Wave:
                     g = gelu(tile)
                     hb[(t, 0)], hb[(t, 1)] = d_pair_as_operand(g, 0), d_pair_as_operand(g, 1)
                 self.pairs(lambda t: self.bias_tile(l, 512 + 128 * sl, t), lambda kc: xn[kc], 2, 32, f_done)
-                self.wide(h, lambda kc: hb[(kc >> 1, kc & 1)], 8)
+                self.wide(h, lambda kc: hb[(kc >> 1, kc & 1)], 8, split=4)
         # ---- output stage ---------------------------------------------------------------------------------------
         out = np.zeros((48, 4, LANES, 4), np.float32)
         hbf = [d_pair_as_operand(h[kc >> 1], kc & 1) for kc in range(32)]
