@@ -282,7 +282,9 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav, int32_t n_clips, int
  *   gt [256][512] = (W2c Wm_a)^T        tw [vocab][512] = word_embedding (W2c Wm_w Wt)^T      (the word path is a lookup)
  *   st [seed_dim + style_dim][512] = [W2a W_embed_text | W3s]^T        c0 [512] = all constant terms
  * audio_feat [n_clips][128][256] fp32 (syn_wav_encode), word [n_clips][128] int64, seed [n_clips][seed_dim], style
- * [n_clips][style_dim] or NULL, d_scratch [n_clips][512] -> cond [n_clips][32][512].  Two launches, fp32 arithmetic. */
+ * [n_clips][style_dim] or NULL, d_scratch [SYN_COND_SCRATCH_ROWS][n_clips][512] (ABI 4: the seed / style GEMM is split over K,
+ * its partial sums are added in a fixed order) -> cond [n_clips][32][512].  Two launches, fp32 arithmetic. */
+#define SYN_COND_SCRATCH_ROWS 8
 typedef struct syn_cond_weights {
     const float* gt; const float* tw; const float* st; const float* c0;
     int32_t vocab, seed_dim, style_dim, reserved;

@@ -285,7 +285,7 @@ class ClipConditioner:
         if lo < 0 or hi >= w.vocab:
             raise IndexError(f"word id out of range: [{lo}, {hi}] for a vocabulary of {w.vocab} (nn.Embedding would raise too)")
         out = torch.empty(bs, 32, D, dtype=torch.float32, device=dev)
-        d = torch.empty(bs, D, dtype=torch.float32, device=dev)
+        d = torch.empty(8, bs, D, dtype=torch.float32, device=dev)        # SYN_COND_SCRATCH_ROWS partial sums per clip (include/syn_hip.h)
         _lib.check(_lib.load().syn_cond_encode(C.byref(w.c_struct()), feat.data_ptr(), word.data_ptr(), seed.data_ptr(), _lib.ptr(style),
                                                bs, d.data_ptr(), out.data_ptr(), _lib.current_stream(dev)), "syn_cond_encode")
         return out

@@ -2360,10 +2360,11 @@ int syn_cond_encode(const syn_cond_weights* w, const float* audio_feat, const in
     if (w->seed_dim <= 0 || w->style_dim < 0 || w->vocab <= 0 || (w->style_dim > 0 && !style))
         return fail_msg("syn_cond_encode: bad dimensions (a model with a style projection needs the style vectors)");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(cnd::k_cond_clip, dim3(SYN_D / 64, (n_clips + 15) / 16), dim3(256), 0, s, seed, w->seed_dim, style, w->style_dim,
-                       w->st, w->c0, n_clips, d_scratch);
+    static_assert(cnd::kClipSplit == SYN_COND_SCRATCH_ROWS, "include/syn_hip.h: d_scratch rows per clip");
+    hipLaunchKernelGGL(cnd::k_cond_clip, dim3(SYN_D / 64, (n_clips + 31) / 32, cnd::kClipSplit), dim3(256), 0, s, seed, w->seed_dim, style,
+                       w->style_dim, w->st, n_clips, d_scratch);
     hipLaunchKernelGGL(cnd::k_cond_frames, dim3(SYN_D / 128, n_clips), dim3(256), 0, s, audio_feat, (const long long*)word, w->gt, w->tw,
-                       w->vocab, d_scratch, cond);
+                       w->vocab, d_scratch, w->c0, n_clips, cond);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("syn_cond_encode", e);
 }
@@ -2392,7 +2393,7 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, 
         b.wav = wav_in; b.wav_clip_stride = (long)n_samples * enc->cin; b.L = n_samples; b.cin = enc->cin; b.L1 = p.L1;
         b.w_first = enc->w_first; b.W2 = (const uint4*)enc->conv[0].w; b.bias2 = enc->conv[0].bias;
         b.X1 = ws + p.x1; b.x1_clip_stride = cs;
-        hipLaunchKernelGGL(wav::k_block0, dim3((p.L1 + 511) / 512, n_clips), dim3(kThreads), wav::kB0Lds, s, b);
+        hipLaunchKernelGGL(wav::k_block0, dim3((p.L1 + wav::kB0Tile - 1) / wav::kB0Tile, n_clips), dim3(wav::kB0Waves * 64), wav::kB0Lds, s, b);
     }
     auto base = [&](int i) {
         wav::CArgs a;

@@ -292,7 +292,7 @@ def test_conditioning_kernels_vs_oracle(variant):
         st = cc.style_of(yd, flags[0], B)
         st = None if st is None else st.float().contiguous()     # (operands stay referenced until the launch is enqueued)
         word_d, seed_d = word.cuda().contiguous(), yd["seed"].reshape(B, -1).contiguous()
-        out, d = torch.empty(B, 32, 512, device="cuda"), torch.empty(B, 512, device="cuda")
+        out, d = torch.empty(B, 32, 512, device="cuda"), torch.empty(8, B, 512, device="cuda")   # SYN_COND_SCRATCH_ROWS partial sums per clip
         _lib.check(_lib.load().syn_cond_encode(C.byref(cc.weights.c_struct()), feat.data_ptr(), word_d.data_ptr(), seed_d.data_ptr(),
                                                _lib.ptr(st), B, d.data_ptr(), out.data_ptr(), _lib.current_stream()), "syn_cond_encode")
         e = rel_l2(out.cpu(), want)
