@@ -352,7 +352,12 @@ def run_guided(args, rank, local, world, dev, dist):
 
     def one(tag, wrapper, B, y_extra, coef, noisy, evals, want_steady):
         """one guided workload -> dict of its numbers (rank 0) or None"""
+        only = os.environ.get("SYN_BENCH_ONLY")
+        if only and only not in tag:
+            return {"workload": tag, "guided_clip_steps_per_s": 0.0, "ms_per_step": 0.0, "variants": 0, "reference_evaluation_equivalents_per_s": 0.0, "roofline": None}
         mdm, plan_fn = guidance.resolve(wrapper)
+        if os.environ.get("SYN_BENCH_TRACE"):
+            print(f"[guided] {tag[:40]} B={B}", file=sys.stderr, flush=True)
         chunk = 128
         plan = sb = None
         for b0 in range(0, B, chunk):                               # conditioning of all variants, once per clip, in chunks
@@ -368,6 +373,8 @@ def run_guided(args, rank, local, world, dev, dist):
         V = len(plan.variants)
         sb.load_x(torch.randn(B, 1536, 1, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(rank)))
         sb.set_rng(4321, first_clip=rank * B)
+        if os.environ.get("SYN_BENCH_TRACE"):
+            torch.cuda.synchronize(); print("[guided] conditioning done", file=sys.stderr, flush=True)
         dt, replay_ms, launch_ms, steady_ms = timed_loop(pm, sb, coef, noisy, K, W, args.prime, world, dist, dev, want_steady and rank == 0)
         sb.check_sync()
         if rank != 0:
@@ -485,13 +492,15 @@ def timed_loop(pm, sb, coef, noisy, K, W, prime, world, dist, dev, want_steady):
         LOOP_CH-step replay, per-step ms of 200 further steps - the steady state of a long loop - or None)"""
     from syntalker_amd import engine
     CH, MAXS = LOOP_CH, engine.StepGraph.MAX_STEPS
-    ts = [999 - (i % 1000) for i in range(MAXS)]            # t = 999, 998, ... (wraps: any t is a valid step to time)
+    n_rows = int(coef.shape[0])                             # 1000 (DDPM) or 50 (DDIM-50): rows of the coefficient table = steps of the loop
+    tc = [n_rows - 1 - (i % n_rows) for i in range(MAXS)]   # step index K-1, K-2, ... (wraps: any step is a valid one to time)
+    tm = [t * (1000 // n_rows) for t in tc]                 # its original timestep (respace.py: range(0, 1000, 20) for ddim50)
     g10 = engine.StepGraph(pm, sb, coef, noisy, fused_rng=noisy, scheduled=True, steps=CH)
-    g10.set_schedule(ts, ts)
+    g10.set_schedule(tc, tm)
     g1 = None                                               # captured only when K or W is not a multiple of CH
     if K % CH or W % CH:
         g1 = engine.StepGraph(pm, sb, coef, noisy, fused_rng=noisy, scheduled=True)
-        g1.set_schedule(ts, ts)
+        g1.set_schedule(tc, tm)
     state = {"pos": 0, "last": None}
 
     def run_steps(n, events=None):

@@ -205,6 +205,11 @@ class StepGraph:
         if steps > 1:
             self.tm_rows = torch.zeros(steps, sb.t_model.numel(), dtype=torch.int32, device=pm.device)
             self.tc_rows = torch.zeros(steps, sb.t_coef.numel(), dtype=torch.int32, device=pm.device)
+        if scheduled:
+            # The warm-up launch below reads the timestep vectors as they stand, and a cached StepBuffers may carry the indices of
+            # an earlier loop over a LONGER coefficient table (p_sample_loop's 1000 rows, then ddim_sample_loop's 50: row 999 of a
+            # 50-row table is an out-of-bounds read).  A scheduled graph overwrites them from its schedule before every step anyway.
+            sb.t_model.zero_(); sb.t_coef.zero_()
         side = torch.cuda.Stream(device=pm.device)
         side.wait_stream(torch.cuda.current_stream(pm.device))
         with torch.cuda.stream(side):          # warm-up launch outside capture (module load, etc.), the same launch(es) as captured

@@ -405,6 +405,24 @@ def test_full_size_properties(beatx, B):
 
 # ---------------------------------------------------------------------------------------------------------
 # training path: loss value, gradient norms vs the reference goldens, full gradients vs the oracle
+def test_ddim_loop_after_a_ddpm_loop_on_the_same_buffers(beatx):
+    """A model's StepBuffers are cached per batch size: a DDIM-50 loop (50-row coefficient table) that follows a DDPM loop (1000
+    rows, timestep vectors left at indices up to 999) must not launch with the stale indices (regression: the scheduled graph's
+    warm-up launch read row 999 of the 50-row table - an out-of-bounds read that faulted in `bench.py --mode guided`)."""
+    from syntalker_amd.process import create_gaussian_diffusion
+    y = synth.to_device(synth.synth_clip_inputs(3, seed=61), DEV)
+    xT = synth.synth_latent(3, seed=61).to(DEV)
+    ddim = create_gaussian_diffusion(use_ddim=True)
+    fresh = _model("beatx")
+    want = ddim.ddim_sample_loop(fresh, (3, 1536, 1, 32), noise=xT, clip_denoised=False, model_kwargs={"y": y})
+    create_gaussian_diffusion().p_sample_loop(beatx, (3, 1536, 1, 32), noise=xT, clip_denoised=False, model_kwargs={"y": y},
+                                              skip_timesteps=0, seed=5)          # leaves t_coef = 0 after the last step ...
+    sb = beatx.buffers(3, 1)
+    sb.t_coef.fill_(999); sb.t_model.fill_(999)                                # ... so put the worst case there explicitly
+    got = ddim.ddim_sample_loop(beatx, (3, 1536, 1, 32), noise=xT, clip_denoised=False, model_kwargs={"y": y})
+    assert torch.isfinite(got).all() and torch.equal(got, want)
+
+
 def test_training_loss_and_gradients(golden):
     from oracle import denoiser_ref as dr
     from oracle.process_ref import RefProcess
