@@ -687,14 +687,23 @@ def test_seeded_20_step_ddpm_vs_oracle(beatx, mode, B):
 
 def test_full_1000_step_p_sample_loop_vs_oracle(beatx):
     """One whole p_sample_loop as the reference's sampler runs it (1000 DDPM steps, noise drawn in the step kernel, 10-step
-    graph replays, the library's own kernel choice at B = 8) against the oracle over the same 1000 regenerated noise tensors."""
+    graph replays) against the oracle over the same 1000 regenerated noise tensors - once with the library's own kernel choice at
+    B = 8 (the small-batch kernel) and once pinned to the wave-per-sequence kernel `k_seq`, the one `bench.py` times (100 persistent
+    10-step launches).  The oracle's loop runs once."""
     from oracle import denoiser_ref as dr
     from oracle.process_ref import RefProcess
     from syntalker_amd.process import create_gaussian_diffusion
     B, seed = 8, 2024
     y, xT = synth.synth_clip_inputs(B, seed=61), synth.synth_latent(B, seed=61)
-    got = create_gaussian_diffusion().p_sample_loop(beatx, (B, 1536, 1, 32), noise=xT.to(DEV), clip_denoised=False,
-                                                    model_kwargs={"y": synth.to_device(y, DEV)}, seed=seed).cpu()
+    got = {}
+    for mode, name in ((0, "library's choice"), (5, "k_seq")):
+        beatx.layer_mode = mode
+        try:
+            got[name] = create_gaussian_diffusion().p_sample_loop(beatx, (B, 1536, 1, 32), noise=xT.to(DEV), clip_denoised=False,
+                                                                  model_kwargs={"y": synth.to_device(y, DEV)}, seed=seed).cpu()
+        finally:
+            beatx.layer_mode = 0
+    assert beatx.buffers(B, 1).fragment is False
     sd = synth_state_dict("beatx")
     fw = dr.fold_weights(sd)
     with torch.no_grad():
@@ -702,6 +711,7 @@ def test_full_1000_step_p_sample_loop_vs_oracle(beatx):
         model_fn = lambda a, b, c: dr.mdm_forward_folded(sd, fw, cond, te, a, b)
         want = RefProcess(False).p_sample_loop(model_fn, (B, 1536, 1, 32), y, noise=xT.clone(),
                                                step_noise=_regenerated_step_noise(B, range(999, -1, -1), seed))
-    e = rel_l2(got, want)
-    print(f"1000-step p_sample_loop rel-L2 vs oracle {e:.3e}")
-    assert torch.isfinite(got).all() and e < LOOP_TOL
+    for name, g in got.items():
+        e = rel_l2(g, want)
+        print(f"1000-step p_sample_loop rel-L2 vs oracle {e:.3e}  ({name})")
+        assert torch.isfinite(g).all() and e < LOOP_TOL, name
