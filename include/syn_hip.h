@@ -236,6 +236,20 @@ int syn_bn_act_fwd(const float* y, const float* shortcut, int64_t rows, int32_t 
                    float* z, void* stream);
 int syn_bn_act_bwd(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, const float* beta, int64_t rows,
                    int32_t channels, int32_t act, float* ws, float* dgamma_dbeta, float* dy, float* dshortcut, void* stream);
+/* The same with the statistics reduced over several ranks - nn.SyncBatchNorm, which the reference's DDP branch converts every BatchNorm to
+ * (train.py:90; torch/nn/modules/_functions.py SyncBatchNorm).  The library reduces to per-channel sums in fp64 ([2][channels]: forward
+ * sum y, sum y^2; backward sum d, sum d * xhat), the CALLER all-reduces them over its process group (RCCL) together with the row count, and the
+ * second call finalises with the global numbers: normalisation and the data gradient use the global sums, dgamma / dbeta stay this rank's own
+ * (DDP averages parameter gradients), the running statistics move towards the GLOBAL batch statistics.  scratch: 2 * channels floats. */
+int syn_bn_sums(const float* y, int64_t rows, int32_t channels, float* ws, int32_t ws_chunks, double* sums, void* stream);
+int syn_bn_act_apply(const float* y, const float* shortcut, int64_t rows, int64_t rows_total, int32_t channels, const float* gamma, const float* beta,
+                     float eps, float momentum, float* run_mean, float* run_var, const float* conv_bias, int32_t act, const double* sums_total,
+                     float* stats, float* z, void* stream);
+int syn_bn_bwd_sums(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, const float* beta, int64_t rows,
+                    int32_t channels, int32_t act, float* ws, double* sums, void* stream);
+int syn_bn_act_bwd_apply(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, const float* beta,
+                         const double* sums_local, const double* sums_total, int64_t rows, int64_t rows_total, int32_t channels, int32_t act,
+                         float* dgamma_dbeta, float* scratch, float* dy, float* dshortcut, void* stream);
 
 /* Gradient of an nn.Embedding table (models/denoiser.py:72, the word embedding in front of text_encoder_body): dw [vocab][dim] =
  * sum over the positions p with ids[p] == v of dy[p][:], added in increasing p (no atomics on the result; every row written).

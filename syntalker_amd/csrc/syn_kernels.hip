@@ -2306,6 +2306,61 @@ int syn_bn_act_bwd(const float* dz, const float* z, const float* y, const float*
     return e == hipSuccess ? 0 : fail("syn_bn_act_bwd", e);
 }
 
+/* ---- nn.SyncBatchNorm on the same kernels: sums -> (the caller's all-reduce) -> apply ---- */
+int syn_bn_sums(const float* y, int64_t rows, int32_t channels, float* ws, int32_t ws_chunks, double* sums, void* stream) {
+    if (!ws || !sums || rows <= 0 || channels <= 0 || channels % 4 || 256 % (channels / 4) || channels > 1024 || (ws_chunks <= 0 && !y))
+        return fail_msg("syn_bn_sums: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = ws_chunks > 0 ? ws_chunks : syn_bn_chunks(rows);
+    if (ws_chunks <= 0) hipLaunchKernelGGL(trn::k_bn_stats, dim3(chunks), dim3(256), 0, s, y, (long)rows, channels, ws);
+    hipLaunchKernelGGL(trn::k_bn_sums64, dim3(channels), dim3(256), 0, s, (const float*)ws, chunks, channels, sums);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_bn_sums", e);
+}
+
+int syn_bn_act_apply(const float* y, const float* shortcut, int64_t rows, int64_t rows_total, int32_t channels, const float* gamma, const float* beta,
+                     float eps, float momentum, float* run_mean, float* run_var, const float* conv_bias, int32_t act, const double* sums_total,
+                     float* stats, float* z, void* stream) {
+    if (!y || !gamma || !beta || !sums_total || !stats || !z || rows <= 0 || rows_total < rows || channels <= 0 || channels % 4)
+        return fail_msg("syn_bn_act_apply: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(trn::k_bn_finalize64, dim3((channels + 255) / 256), dim3(256), 0, s, sums_total, channels, (long)rows_total, eps, momentum, stats,
+                       run_mean, run_var, conv_bias);
+    const long n4 = rows * channels / 4;
+    hipLaunchKernelGGL(trn::k_bn_apply, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, y, shortcut, (const float*)stats, gamma, beta, channels, n4,
+                       act, z);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_bn_act_apply", e);
+}
+
+int syn_bn_bwd_sums(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, const float* beta, int64_t rows,
+                    int32_t channels, int32_t act, float* ws, double* sums, void* stream) {
+    if (!dz || !y || !stats || !gamma || !ws || !sums || rows <= 0 || channels % 4 || 256 % (channels / 4))
+        return fail_msg("syn_bn_bwd_sums: bad arguments");
+    if (act && !z && !beta) return fail_msg("syn_bn_bwd_sums: z may only be omitted with beta given");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = syn_bn_chunks(rows);
+    hipLaunchKernelGGL(trn::k_bn_bwd_stats, dim3(chunks), dim3(256), 0, s, dz, z, y, stats, gamma, beta, (long)rows, channels, act, ws);
+    hipLaunchKernelGGL(trn::k_bn_sums64, dim3(channels), dim3(256), 0, s, (const float*)ws, chunks, channels, sums);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_bn_bwd_sums", e);
+}
+
+int syn_bn_act_bwd_apply(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, const float* beta,
+                         const double* sums_local, const double* sums_total, int64_t rows, int64_t rows_total, int32_t channels, int32_t act,
+                         float* dgamma_dbeta, float* scratch, float* dy, float* dshortcut, void* stream) {
+    if (!dz || !y || !stats || !gamma || !sums_local || !sums_total || !dgamma_dbeta || !scratch || !dy || rows <= 0 || rows_total < rows || channels % 4)
+        return fail_msg("syn_bn_act_bwd_apply: bad arguments");
+    if (act && !z && (dshortcut || !beta)) return fail_msg("syn_bn_act_bwd_apply: z may only be omitted (with beta given) when no shortcut entered the activation");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(trn::k_bn_bwd_unpack64, dim3((channels + 255) / 256), dim3(256), 0, s, sums_local, sums_total, channels, dgamma_dbeta, scratch);
+    const long n4 = rows * channels / 4;
+    hipLaunchKernelGGL(trn::k_bn_bwd_apply, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dz, z, y, stats, gamma, beta, (const float*)scratch,
+                       channels, n4, (long)rows_total, act, dy, dshortcut);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_bn_act_bwd_apply", e);
+}
+
 int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, void* dy_bf16, void* dy_bf16_t, float* colsum_part, int32_t* counters,
                         float* colsum, void* stream) {
     if (!dy || !dy_bf16 || !dy_bf16_t || m_rows <= 0 || n <= 0 || m_rows % 64 || n % 64)

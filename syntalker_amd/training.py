@@ -11,8 +11,8 @@
     path: a layer geometry the kernels do not cover raises;
   * rotary, DropPath's multiply-add and the SmoothL1 loss are fp32 PyTorch elementwise ops;
   * data parallelism: one process per GPU, torch DDP over RCCL (`make_ddp`), gradients averaged by bucketed
-    all-reduce overlapped with backward.  Optional SyncBatchNorm (the reference's DDP branch, train.py:90) takes the
-    encoder through its own nn.Modules instead (`_wav_block_modules`), the one place a library convolution still runs.
+    all-reduce overlapped with backward.  SyncBatchNorm (the reference's DDP branch converts every BatchNorm, train.py:90) runs on the
+    same kernels: per-channel fp64 sums -> one small all-reduce -> finalise (`SyncBnActFn`, `syn_bn_sums` / `syn_bn_act_apply` / ...).
 Train-mode semantics follow the reference: BatchNorm batch statistics, DropPath(0.1) per sample with
 scale-by-keep (timm_transformer/transformer.py:21-38), h3d Bernoulli(0.3) style dropout
 (denoiser_h3d.py:116-124).  There is no CPU fallback: CPU tensors raise.
@@ -581,6 +581,79 @@ class BnActFn(torch.autograd.Function):
         return dy, dgb[0], dgb[1], dcb, dsh, None, None, None, None, None
 
 
+SYNC_BN_RAGGED = False      # True: ranks may bring different numbers of rows to a SyncBatchNorm (costs a host synchronisation per BatchNorm)
+
+
+def _all_reduce_sum(t, group, tag=None):
+    """SUM all-reduce of a small device tensor over `group` (RCCL).  A module-level function so that single-GPU tests can stand in for
+    the other ranks (tests/test_gpu_kernels.py); `tag` = (the BatchNorm's `_syn_test_key`, "fwd" | "bwd") identifies the call for them."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+class SyncBnActFn(torch.autograd.Function):
+    """`BnActFn` with the batch statistics reduced over the ranks of a process group = nn.SyncBatchNorm, which the reference's DDP branch
+    converts every BatchNorm of the model to (train.py:90).  Same kernels; the per-channel sums (fp64) make a round trip through one
+    small all-reduce in each direction: forward [sum y, sum y^2, rows], backward [sum d, sum d xhat] (torch/nn/modules/_functions.py:
+    weight / bias gradients stay local - DDP averages them -, the data gradient and the running statistics use the global numbers)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, conv_bias, shortcut, run_mean, run_var, momentum, eps, act, group, key):
+        lib = _lib.load()
+        n, c, _, l = y.shape
+        yc = y.contiguous(memory_format=torch.channels_last)
+        sc = None if shortcut is None else shortcut.contiguous(memory_format=torch.channels_last)
+        rows = n * l
+        part = getattr(y, "_syn_bn_part", None)
+        if part is not None and part.shape[2] == c and part.device == y.device:
+            ws, ws_chunks = part, part.shape[0]
+        else:
+            ws, ws_chunks = torch.empty(2 * lib.syn_bn_chunks(rows) * c, device=y.device, dtype=torch.float32), 0
+        sums = torch.empty(2 * c + 1, device=y.device, dtype=torch.float64)          # [sum y | sum y^2 | rows]
+        sums[2 * c] = rows
+        _lib.check(lib.syn_bn_sums(yc.data_ptr(), rows, c, ws.data_ptr(), ws_chunks, sums.data_ptr(), _lib.current_stream(y.device)), "syn_bn_sums")
+        total = _all_reduce_sum(sums.clone(), group, (key, "fwd"))
+        if SYNC_BN_RAGGED or key is not None:
+            rows_total = int(round(float(total[2 * c])))    # ranks with different numbers of rows: the all-reduced count (a host read)
+        else:                                               # DDP's case, equal batches per rank: no host read, so the step stays graph-capturable
+            import torch.distributed as dist
+            rows_total = rows * (dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1)
+        stats = torch.empty(2, c, device=y.device, dtype=torch.float32)
+        z = torch.empty_like(yc, memory_format=torch.channels_last)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        cb = None if conv_bias is None else conv_bias.detach().float().contiguous()
+        _lib.check(lib.syn_bn_act_apply(yc.data_ptr(), _lib.ptr(sc), rows, rows_total, c, g.data_ptr(), b.data_ptr(), float(eps), float(momentum),
+                                        _lib.ptr(run_mean), _lib.ptr(run_var), _lib.ptr(cb), int(act), total.data_ptr(), stats.data_ptr(), z.data_ptr(),
+                                        _lib.current_stream(y.device)), "syn_bn_act_apply")
+        ctx.save_for_backward(yc, z if (act and shortcut is not None) else None, stats, g, b)
+        ctx.act, ctx.has_short, ctx.has_cb, ctx.group, ctx.rows_total, ctx.key = bool(act), shortcut is not None, conv_bias is not None, group, rows_total, key
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        yc, z, stats, g, b = ctx.saved_tensors
+        n, c, _, l = yc.shape
+        rows = n * l
+        dzc = dz.contiguous(memory_format=torch.channels_last)
+        ws = torch.empty(2 * lib.syn_bn_chunks(rows) * c, device=dz.device, dtype=torch.float32)
+        local = torch.empty(2 * c, device=dz.device, dtype=torch.float64)
+        _lib.check(lib.syn_bn_bwd_sums(dzc.data_ptr(), _lib.ptr(z), yc.data_ptr(), stats.data_ptr(), g.data_ptr(), b.data_ptr(), rows, c, int(ctx.act),
+                                       ws.data_ptr(), local.data_ptr(), _lib.current_stream(dz.device)), "syn_bn_bwd_sums")
+        total = _all_reduce_sum(local.clone(), ctx.group, (ctx.key, "bwd"))
+        dgb = torch.empty(2, c, device=dz.device, dtype=torch.float32)
+        scratch = torch.empty(2, c, device=dz.device, dtype=torch.float32)
+        dy = torch.empty_like(yc, memory_format=torch.channels_last)
+        dsh = torch.empty_like(yc, memory_format=torch.channels_last) if ctx.has_short else None
+        _lib.check(lib.syn_bn_act_bwd_apply(dzc.data_ptr(), _lib.ptr(z), yc.data_ptr(), stats.data_ptr(), g.data_ptr(), b.data_ptr(), local.data_ptr(),
+                                            total.data_ptr(), rows, ctx.rows_total, c, int(ctx.act), dgb.data_ptr(), scratch.data_ptr(), dy.data_ptr(),
+                                            _lib.ptr(dsh), _lib.current_stream(dz.device)), "syn_bn_act_bwd_apply")
+        dcb = torch.zeros(c, device=dz.device, dtype=torch.float32) if ctx.has_cb else None
+        return dy, dgb[0], dgb[1], dcb, dsh, None, None, None, None, None, None, None
+
+
 def _conv_raw(conv, x):
     """The convolution alone (no bias) on channels_last (N, C, 1, L): the split-operand kernel for the Conv1d(k = 15) layers from
     block 0's conv2 on, the plain-fp32 one for the 1-2-channel first layer.  Anything else raises."""
@@ -602,7 +675,11 @@ def _conv_bn_act(conv, bn, x, shortcut, act):
         raise _lib.SynHipError("the fused BatchNorm of the audio encoder implements the exponential running average (momentum = 0.1 in "
                                "the reference, models/utils/layer.py:160); momentum=None asks for a cumulative average")
     y = _conv_raw(conv, x)
-    z = BnActFn.apply(y, bn.weight, bn.bias, conv.bias, shortcut, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act)
+    if isinstance(bn, nn.SyncBatchNorm):                     # train.py:90: statistics over all ranks of the module's process group
+        z = SyncBnActFn.apply(y, bn.weight, bn.bias, conv.bias, shortcut, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act,
+                              bn.process_group, getattr(bn, "_syn_test_key", None))
+    else:
+        z = BnActFn.apply(y, bn.weight, bn.bias, conv.bias, shortcut, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act)
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)                       # as nn.BatchNorm1d.forward does in train() mode (checkpoints carry it)
     return z
@@ -630,18 +707,6 @@ def _wav_block(blk, x):
     return F.leaky_relu(z + short, 0.01)
 
 
-def _wav_block_modules(blk, x):
-    """The same block through its own nn.Modules on (N, C, L): ONLY for a model whose BatchNorms were converted to SyncBatchNorm
-    (train.py:90) - their statistics are all-reduced over the ranks inside the module's forward.  This path runs PyTorch-ROCm's
-    library convolutions; per-GPU statistics (the default) keep the encoder on the hand-written kernels."""
-    short = x
-    z = F.leaky_relu(blk.bn1(blk.conv1(x)), 0.01)
-    z = blk.bn2(blk.conv2(z))
-    if blk.downsample is not None:
-        short = blk.downsample(short)
-    return F.leaky_relu(z + short, 0.01)
-
-
 def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     """Differentiable MDM.forward, op-for-op with models/denoiser.py:132-196 (denoiser_h3d.py:148-221), with the
     module's current train()/eval() semantics.  x (B,1536,1,T) -> (B,1536,1,T)."""
@@ -665,17 +730,12 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     if h3d and y.get("uncond_audio", False):
         audio, word = torch.zeros_like(audio), torch.zeros_like(word)
     a = audio.unsqueeze(1) if audio.dim() == 2 else audio.transpose(1, 2)
-    # (train.py:90 may have converted the BatchNorms to SyncBatchNorm: their statistics are all-reduced over the ranks inside the
-    # module's own forward, so those models take the module path below instead of the functional / fused one)
-    sync_bn = any(isinstance(mod, nn.SyncBatchNorm) for mod in m.WavEncoder.modules())
-    if sync_bn:
-        for blk in m.WavEncoder.feat_extractor:
-            a = _wav_block_modules(blk, a)
-    else:
-        a = a.unsqueeze(2).contiguous(memory_format=torch.channels_last)       # (B, C, 1, L), channel innermost
-        for blk in m.WavEncoder.feat_extractor:
-            a = _wav_block(blk, a)
-        a = a.squeeze(2)
+    # (train.py:90 may have converted the BatchNorms to SyncBatchNorm: `_conv_bn_act` then reduces the statistics over the module's
+    # process group - the same kernels, one small all-reduce per BatchNorm and direction)
+    a = a.unsqueeze(2).contiguous(memory_format=torch.channels_last)       # (B, C, 1, L), channel innermost
+    for blk in m.WavEncoder.feat_extractor:
+        a = _wav_block(blk, a)
+    a = a.squeeze(2)
     a_feat = a.transpose(1, 2).permute(1, 0, 2)                                  # (128, B, 256)
     w_feat = lin(_embed(m.text_pre_encoder_body, word), m.text_encoder_body).permute(1, 0, 2)
     at = lin(torch.cat([a_feat, w_feat], dim=2), m.mix_audio_text)

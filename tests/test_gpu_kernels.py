@@ -466,3 +466,62 @@ def test_fused_batchnorm_shortcut_leakyrelu_vs_torch_autograd(C, L, short, act):
     assert float(cb.grad.abs().max()) == 0.0 and float(cb2.grad.abs().max()) < 1e-3 * float(dz.abs().sum() / C)
     if short:
         assert rel_l2(sc.grad.cpu(), sc2.grad.cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("C,L,short,act", [(64, 700, False, True), (128, 333, True, True), (256, 130, False, False)])
+def test_sync_batchnorm_over_two_emulated_ranks_vs_torch_autograd(C, L, short, act, monkeypatch):
+    """`SyncBnActFn` (nn.SyncBatchNorm on the fused kernels, reference train.py:90): a batch of 4 split over two "ranks" of 3 and 1 clips
+    - ragged on purpose - whose all-reduce is played by the test (first the ranks' local sums are recorded, then every rank is re-run
+    with the totals handed to it) against PyTorch's batch_norm over the WHOLE batch and its autograd: every rank's outputs and data
+    gradients are its slice of the full-batch ones, the weight / bias gradients are each rank's own contribution (they add up to the
+    full-batch gradients; DDP would average them), the running statistics move towards the global batch statistics."""
+    from syntalker_amd import training
+    DEV = "cuda"
+    g = torch.Generator().manual_seed(C + L)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    y = (mk(4, C, 1, L) * 2 + 0.5).contiguous(memory_format=torch.channels_last)
+    sc = mk(4, C, 1, L).contiguous(memory_format=torch.channels_last) if short else None
+    gamma, beta, cb = mk(C) * 0.5 + 1, mk(C), mk(C)
+    rm0, rv0 = mk(C), mk(C).abs() + 0.5
+    dz = mk(4, C, 1, L).contiguous(memory_format=torch.channels_last)
+    # the whole batch through PyTorch
+    y2, g2, b2 = (t.detach().clone().requires_grad_(True) for t in (y, gamma, beta))
+    sc2 = sc.detach().clone().requires_grad_(True) if short else None
+    rm2, rv2 = rm0.clone(), rv0.clone()
+    p = torch.nn.functional.batch_norm(y2 + cb.view(1, -1, 1, 1), rm2, rv2, g2, b2, True, 0.1, 1e-5)
+    if short:
+        p = p + sc2
+    want = torch.nn.functional.leaky_relu(p, 0.01) if act else p
+    want.backward(dz)
+    ranks = [slice(0, 3), slice(3, 4)]
+    rec, state = {}, {"mode": "record", "rank": 0}
+
+    def fake_all_reduce(t, group, tag=None):
+        if state["mode"] == "record" or tag[1] not in state["replay"]:
+            rec.setdefault(tag, {})[state["rank"]] = t.clone()
+            return t
+        return rec[tag][0] + rec[tag][1]
+    monkeypatch.setattr(training, "_all_reduce_sum", fake_all_reduce)
+
+    def run(r):
+        state["rank"] = r
+        sl = ranks[r]
+        yy, gg, bb, cc = (t.detach().clone().requires_grad_(True) for t in (y[sl].contiguous(memory_format=torch.channels_last), gamma, beta, cb))
+        ss = sc[sl].detach().clone().contiguous(memory_format=torch.channels_last).requires_grad_(True) if short else None
+        rm, rv = rm0.clone(), rv0.clone()
+        z = training.SyncBnActFn.apply(yy, gg, bb, cc, ss, rm, rv, 0.1, 1e-5, act, None, "op")
+        z.backward(dz[sl].contiguous(memory_format=torch.channels_last))
+        return z.detach(), yy.grad, gg.grad, bb.grad, (ss.grad if short else None), rm, rv, cc.grad
+    for mode, replay in (("record", ()), ("replay", ("fwd",)), ("replay", ("fwd", "bwd"))):    # forward sums, then backward sums, then the real run
+        state["mode"], state["replay"] = mode, replay
+        outs = [run(0), run(1)]
+    dg, db = outs[0][2] + outs[1][2], outs[0][3] + outs[1][3]
+    for r, sl in enumerate(ranks):
+        z, dy, _, _, dsh, rm, rv, dcb = outs[r]
+        assert rel_l2(z.cpu(), want[sl].detach().cpu()) < 1e-5
+        assert rel_l2(dy.cpu(), y2.grad[sl].cpu()) < 1e-4
+        if short:
+            assert rel_l2(dsh.cpu(), sc2.grad[sl].cpu()) < 1e-6
+        assert torch.allclose(rm, rm2, rtol=1e-5, atol=1e-6) and torch.allclose(rv, rv2, rtol=1e-4, atol=1e-6)      # global statistics on every rank
+        assert float(dcb.abs().max()) == 0.0
+    assert rel_l2(dg.cpu(), g2.grad.cpu()) < 1e-4 and rel_l2(db.cpu(), b2.grad.cpu()) < 1e-4

@@ -512,6 +512,42 @@ def test_train_mode_loss_gradients_and_bn_buffers_vs_golden(golden):
     assert float(params["WavEncoder.feat_extractor.1.conv1.bias"].grad.abs().max()) < 1e-6
 
 
+def test_sync_batchnorm_model_on_the_native_path(golden):
+    """train.py:90 converts every BatchNorm of the model to nn.SyncBatchNorm before DDP: the converted model keeps the audio encoder on
+    the hand-written kernels (`SyncBnActFn`: fp64 sums -> all-reduce -> finalise) and, with a one-rank process group, reproduces the
+    train-mode golden of the reference like the unconverted one (the two-rank arithmetic is the kernel-level test's)."""
+    import torch.distributed as dist
+    from syntalker_amd.process import create_gaussian_diffusion
+    created = False
+    if not dist.is_initialized():
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        created = True
+    try:
+        m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(_model("beatx")).train()
+        assert sum(isinstance(x, torch.nn.SyncBatchNorm) for x in m.modules()) == 16 and m.variant == "beatx"
+        m.drop_path = 0.0
+        y = synth.synth_clip_inputs(4, seed=5)
+        x0, eps = synth.synth_latent(4, seed=5, name="x0"), synth.synth_latent(4, seed=6, name="eps")
+        t4 = torch.tensor([0, 17, 500, 999])
+        loss = create_gaussian_diffusion().training_losses(m, x0.to(DEV), t4.to(DEV), model_kwargs={"y": synth.to_device(y, DEV)}, noise=eps.to(DEV))["loss"]
+        assert np.allclose(loss.detach().cpu().numpy(), golden["beatx.trainmode.loss"], rtol=2e-2)
+        loss.mean().backward()
+        params = dict(m.named_parameters())
+        names = [str(n) for n in golden["beatx.train.gradnorm_names"]]
+        got = np.array([params[n].grad.norm().item() for n in names])
+        assert np.allclose(got, golden["beatx.trainmode.gradnorm"], rtol=3e-2), got / golden["beatx.trainmode.gradnorm"]
+        sd_after = m.state_dict()
+        assert np.allclose(sd_after["WavEncoder.feat_extractor.3.bn1.running_var"].double().cpu().numpy(), golden["beatx.trainmode.bn.3.bn1.running_var"],
+                           rtol=2e-3, atol=2e-4)
+        assert int(sd_after["WavEncoder.feat_extractor.3.bn1.num_batches_tracked"]) == 1
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_train_mode_step_runs_and_updates(beatx):
     """train(): BatchNorm batch statistics + DropPath; one Adam step (lr, betas of optimizers/optim_factory.py:122)."""
     from syntalker_amd import training
