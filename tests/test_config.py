@@ -1,6 +1,6 @@
 """configuration / checkpoint compatibility of the hot path.
 
-CPU part: the reference's own YAML files (read in the build container, where /root/reference exists) select the denoiser class and
+CPU part: the reference's own YAML files (read in the build container, where the reference tree exists) select the denoiser class and
 the body-part widths their trainers build; the StepLR policy; the checkpoint format.  GPU part: the `train.py -c <yaml>` loop of
 scripts/train_from_config.py (epochs, per-epoch StepLR, save_checkpoints, resume from a `module.`-prefixed checkpoint) and the
 sampler built from the h3d configuration."""
