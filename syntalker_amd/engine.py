@@ -31,6 +31,31 @@ def _require_cuda(t: torch.Tensor, what: str):
             "(no CPU fallback). Move the model and inputs to a cuda device.")
 
 
+def seq_pass_clips(n_variants: int, device) -> int:
+    """Clips one full pass of the wave-per-sequence kernel takes: a workgroup per CU, its four waves = the variants of
+    4 // V clips (V = 3 leaves a wave idle).  0 where that kernel does not apply."""
+    device = torch.device(device)
+    if device.type != "cuda" or not 1 <= n_variants <= 4:
+        return 0
+    return torch.cuda.get_device_properties(device).multi_processor_count * (4 // n_variants)
+
+
+def plan_slices(n_clips: int, n_variants: int, device) -> list[tuple[int, int]]:
+    """Contiguous clip ranges a batch is run as, one after the other (sequences never interact, noise is keyed by the
+    global clip index: the result is the unsliced one).  Both whole-step kernels quantise to passes over the CUs - `k_seq`
+    to passes of P = 1024 / V clips, `k_stack` to passes of 512 sequences - and `k_seq`'s pass is the cheaper per clip only
+    when it is more than half full, so the library picks `k_stack` for q P + r clips with 0 < r <= P / 2 (1025-1536, ...):
+    three `k_stack` passes where one `k_seq` pass and the best kernel for the r clips left do
+    (1536 clips: 1.95 ms per step as one batch, 1.13 + 0.64 ms as 1024 + 512; `profiles/r03_diag_batch_sweep.txt`)."""
+    P = seq_pass_clips(n_variants, device)
+    if P == 0 or n_clips <= P or n_variants == 3:
+        return [(0, n_clips)]
+    r = n_clips % P
+    if r == 0 or 2 * r > P:
+        return [(0, n_clips)]
+    return [(0, n_clips - r), (n_clips - r, n_clips)]
+
+
 def pack_weight(w: torch.Tensor) -> torch.Tensor:
     """fp32 (n, k) nn.Linear weight -> packed bf16 MFMA fragments (uint8 view of n*k*2 bytes)."""
     _require_cuda(w, "weight")

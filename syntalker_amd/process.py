@@ -257,7 +257,37 @@ class GaussianDiffusion:
 
     def _fused(self, kind, mdm, plan_fn, shape, noise, model_kwargs, eta, skip_timesteps, init_image, step_noise,
                seed, progress, each=None, first_clip=0):
-        """x stays on the device in token-major layout for the whole loop; one graph replay per step."""
+        """The whole loop on the device.  A batch between two pass sizes of the wave-per-sequence kernel runs as two
+        slices, one after the other (`engine.plan_slices`): clips are independent and every random draw is keyed by the
+        global clip index, so the slices' results are the batch's."""
+        from .sharding import shard_kwargs
+        dev = next(mdm.parameters()).device
+        B = shape[0]
+        slices = [(0, B)]
+        if each is None and not progress:
+            with torch.no_grad():
+                slices = engine.plan_slices(B, len(plan_fn(model_kwargs["y"]).variants), dev)
+        if len(slices) == 1:
+            return self._fused_slice(kind, mdm, plan_fn, shape, noise, model_kwargs, eta, skip_timesteps, init_image,
+                                     step_noise, seed, progress, each, first_clip)
+        if seed is None and step_noise is None and (kind == "ddpm" or eta != 0.0):
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())                  # one seed for all slices
+        if noise is None:
+            noise = torch.randn(*shape, device=dev)                             # (the single draw `_start` would make)
+        cut = lambda t, lo, hi: None if t is None else t[lo:hi]
+        outs = []
+        for lo, hi in slices:
+            kw = dict(model_kwargs, y=shard_kwargs(model_kwargs["y"], lo, hi, B))
+            outs.append(self._fused_slice(kind, mdm, plan_fn, (hi - lo,) + tuple(shape[1:]), cut(noise, lo, hi), kw, eta,
+                                          skip_timesteps, cut(init_image, lo, hi),
+                                          None if step_noise is None else step_noise[:, lo:hi], seed, False, None,
+                                          first_clip + lo))
+        return torch.cat(outs, 0)
+
+    def _fused_slice(self, kind, mdm, plan_fn, shape, noise, model_kwargs, eta, skip_timesteps, init_image, step_noise,
+                     seed, progress, each=None, first_clip=0):
+        """x stays on the device in the step kernel's layout for the whole loop; one graph replay per step (ten steps per
+        replay where nothing happens in between)."""
         dev = next(mdm.parameters()).device
         y = model_kwargs["y"]
         B = shape[0]

@@ -721,6 +721,44 @@ def test_seeded_20_step_ddpm_vs_oracle(beatx, mode, B):
     assert e < LOOP_TOL
 
 
+def test_batch_between_two_pass_sizes_runs_as_two_slices_vs_oracle(beatx, monkeypatch):
+    """1030 clips = one full pass of the wave-per-sequence kernel (1024) + 6: `engine.plan_slices` runs them as two slices (`k_seq`, then
+    the small-batch kernel) instead of three passes of `k_stack`.  12 seeded DDPM steps; the 8 clips that straddle the cut (1022..1029)
+    against the oracle with the noise regenerated for their GLOBAL clip indices, and the whole batch against the unsliced run."""
+    from oracle import denoiser_ref as dr
+    from oracle.process_ref import RefProcess
+    from syntalker_amd import engine
+    from syntalker_amd.process import create_gaussian_diffusion
+    B, K, seed, lo = 1030, 12, 77, 1022
+    assert engine.plan_slices(B, 1, DEV) == [(0, 1024), (1024, 1030)] and engine.plan_slices(1024, 1, DEV) == [(0, 1024)]
+    assert engine.plan_slices(1536, 1, DEV) == [(0, 1024), (1024, 1536)] and engine.plan_slices(1537, 1, DEV) == [(0, 1537)]
+    y8, x8 = synth.synth_clip_inputs(8, seed=61), synth.synth_latent(8, seed=61)
+    rep = lambda t: t.repeat((129,) + (1,) * (t.dim() - 1))[:B] if torch.is_tensor(t) and t.dim() and t.shape[0] == 8 else t
+    y = {k: rep(v) for k, v in y8.items()}                        # clip i = copy of clip i % 8 (its step noise is its own)
+    xT = rep(x8)
+    d = create_gaussian_diffusion()
+    run = lambda: d.p_sample_loop(beatx, (B, 1536, 1, 32), noise=xT.to(DEV), clip_denoised=False, model_kwargs={"y": synth.to_device(y, DEV)},
+                                  skip_timesteps=1000 - K, seed=seed).cpu()
+    got = run()
+    monkeypatch.setattr(engine, "plan_slices", lambda n, V, dev: [(0, n)])
+    whole = run()
+    monkeypatch.undo()
+    assert got.shape == whole.shape == (B, 1536, 1, 32) and torch.isfinite(got).all()
+    e_whole = rel_l2(got, whole)
+    ys = {k: (v[lo:B] if torch.is_tensor(v) and v.dim() and v.shape[0] == B else v) for k, v in y.items()}
+    sd = synth_state_dict("beatx")
+    fw = dr.fold_weights(sd)
+    with torch.no_grad():
+        cond, te = dr.clip_conditioning(sd, ys, fw), dr.time_table(sd, fw)
+        model_fn = lambda a, b, c: dr.mdm_forward_folded(sd, fw, cond, te, a, b)
+        want = RefProcess(False).p_sample_loop(model_fn, (B - lo, 1536, 1, 32), ys, noise=xT[lo:B].clone(),
+                                               step_noise=_regenerated_step_noise(B - lo, range(K - 1, -1, -1), seed, first_clip=lo),
+                                               skip_timesteps=1000 - K)
+    e = rel_l2(got[lo:B], want)
+    print(f"1030 clips as 1024 + 6: rel-L2 vs oracle over the cut {e:.3e}, vs the unsliced run (k_stack) {e_whole:.3e}")
+    assert e < LOOP_TOL and e_whole < LOOP_TOL
+
+
 def test_full_1000_step_p_sample_loop_vs_oracle(beatx):
     """One whole p_sample_loop as the reference's sampler runs it (1000 DDPM steps, noise drawn in the step kernel, 10-step
     graph replays) against the oracle over the same 1000 regenerated noise tensors - once with the library's own kernel choice at

@@ -232,6 +232,38 @@ def test_two_rank_sharded_sampling_of_the_product_mdm(tmp_path):
         assert float((got[v][3] - got[v][0]).abs().max()) > 1e-3
 
 
+def test_batch_between_two_pass_sizes_runs_as_slices(monkeypatch):
+    """engine.plan_slices: q P + r clips with 0 < r <= P / 2 (P = clips of one full wave-per-sequence pass) run as the first q P clips
+    and the rest, and `process._fused` over the slices gives the unsliced batch's result - x_T is the single draw, the step noise
+    follows the global clip index (first_clip + lo), guided y entries are sliced with the clips."""
+    from syntalker_amd import engine
+    from tests import cpu_engine
+    monkeypatch.setattr(engine, "seq_pass_clips", lambda V, dev: 0 if not 1 <= V <= 4 else 256 * (4 // V))
+    ps = lambda n, V=1: engine.plan_slices(n, V, "cpu")
+    assert ps(1024) == [(0, 1024)] and ps(700) == [(0, 700)] and ps(1537) == [(0, 1537)] and ps(2048) == [(0, 2048)]
+    assert ps(1025) == [(0, 1024), (1024, 1025)] and ps(1536) == [(0, 1024), (1024, 1536)] and ps(2560) == [(0, 2048), (2048, 2560)]
+    assert ps(768, 2) == [(0, 512), (512, 768)] and ps(300, 4) == [(0, 256), (256, 300)] and ps(400, 4) == [(0, 400)]
+    assert ps(700, 3) == [(0, 700)] and ps(5000, 5) == [(0, 5000)]
+    monkeypatch.undo()
+    assert engine.plan_slices(1536, 1, "cpu") == [(0, 1536)]            # (no device, no kernel: nothing to plan)
+
+    cpu_engine.install(monkeypatch)
+    d = process.create_gaussian_diffusion()
+    for variant in ("beatx", "h3d"):
+        shape, y = _mdm_case(variant)
+        model = _mdm_model(variant)
+        x_T = torch.randn(*shape, generator=torch.Generator().manual_seed(3))
+        run = lambda: d.p_sample_loop(model, shape, noise=x_T, clip_denoised=False, model_kwargs={"y": dict(y)}, skip_timesteps=988, seed=11)
+        whole = run()
+        calls = []
+        monkeypatch.setattr(engine, "plan_slices", lambda n, V, dev: calls.append((n, V)) or [(0, 3), (3, n)])
+        sliced = run()
+        monkeypatch.setattr(engine, "plan_slices", lambda n, V, dev: [(0, n)])
+        assert calls == [(5, 2 if variant == "h3d" else 1)]
+        assert sliced.shape == whole.shape and float((sliced - whole).norm() / whole.norm()) < 1e-5, variant
+        assert float((sliced[3] - sliced[0]).abs().max()) > 1e-3       # (local clip index in the second slice would repeat clip 0's noise)
+
+
 # ---- DDP over the product's real parameter set (training.make_ddp, capturable: frozen unused parameters, no search) ---------
 def _oracle_train_forward(m, x, timesteps, y, drop_path=0.0):
     """CPU stand-in for training.train_forward: the oracle's functional forward over the MODULE's own parameters (train-mode
