@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define SYN_ABI_VERSION 4     /* 4: syn_model.tape carries its first 4 chunks again behind the last (no wrap test in k_seq's weight stream);
+#define SYN_ABI_VERSION 5     /* 5: training block entry points - bf16 outputs of syn_ln_fwd / syn_gelu_fwd / syn_attn_fwd, syn_linear_res (residual + DropPath factor
+                                * in the GEMM's epilogue), syn_linear_bwd_prep row_scale, syn_linear_pair bias_grad;
+                                * 4: syn_model.tape carries its first 4 chunks again behind the last (no wrap test in k_seq's weight stream);
                                 * 3: training entry points reworked (syn_ln_bwd add, syn_bn_act_* ws_chunks / beta, syn_conv1d_train_fwd bn_part,
                                 * syn_linear_bwd_prep colsum; new: syn_linear_pair / _and_pack, syn_pack_weights, syn_embedding_wgrad, syn_conv1d_first_*) */
 #define SYN_D        512   /* hidden width               (models/denoiser.py:19)  */
@@ -217,11 +219,15 @@ int syn_pack_weights(const syn_pack_job* jobs_dev, int32_t n_jobs, int64_t max_f
  * LayerNorm(512, eps 1e-5) of `rows` rows (models/timm_transformer/transformer.py:160,162,183,193); the backward
  * needs scratch of ceil(rows/16)*1024 floats and writes dgamma[512], dbeta[512] (deterministic two-stage sums); `add` (NULL or
  * [rows][512]) is added to dx: the gradient that reaches x along the block's residual connection (transformer.py:195-198). */
-int syn_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int32_t rows, void* stream);
+/* (ABI 5) y fp32 and / or y_bf16 [rows][512] (either may be NULL): the Linear that follows takes bf16 operands, and nothing else
+ * reads a pre-LN block's normalised rows - the training step asks for the bf16 copy only. */
+int syn_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, void* y_bf16, float* mean, float* rstd, int32_t rows,
+               void* stream);
 int syn_ln_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* add, float* dx,
                float* dgamma, float* dbeta, float* scratch, int32_t rows, void* stream);
 /* nn.GELU() (exact erf form, transformer.py:117-151), n % 4 == 0 elements. */
-int syn_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+/* (ABI 5) y fp32 and / or y_bf16 (either may be NULL), as syn_ln_fwd. */
+int syn_gelu_fwd(const float* x, float* y, void* y_bf16, int64_t n, void* stream);
 int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
 /* nn.BatchNorm1d in training mode (batch statistics, running statistics updated as PyTorch does) [+ shortcut] [+ LeakyReLU(0.01)]
  * of the audio encoder's BasicBlock (models/utils/layer.py:171-184) on channels-last fp32 [rows][channels], rows = clips x
@@ -258,12 +264,15 @@ int syn_embedding_wgrad(const int64_t* ids, const float* dy, int32_t n_pos, int3
 /* Backward of an nn.Linear, the operand preparation in one pass over dy [m_rows][n] fp32: its bf16 copy (data-gradient GEMM),
  * the bf16 transpose [n][m_rows] (weight-gradient GEMM) and colsum_part [m_rows / 64][n] = column sums of every 64-row block
  * (NULL to skip; the bias gradient is their sum over the first index).  With colsum [n] (and counters: n / 64 ints, zero before the
- * first use, left zero by every launch) the launch also adds the partial sums up, in row-block order: the bias gradient itself. */
-int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, void* dy_bf16, void* dy_bf16_t, float* colsum_part, int32_t* counters,
-                        float* colsum, void* stream);
+ * first use, left zero by every launch) the launch also adds the partial sums up, in row-block order: the bias gradient itself.
+ * (ABI 5) row_scale (NULL or one float per rows_per_scale rows): dy is multiplied by its row's factor first - the backward of
+ * syn_linear_res's `residual + row_scale * (x W^T + b)`, i.e. of x + DropPath(branch) (timm_transformer/transformer.py:21-38,195-198). */
+int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, const float* row_scale, int32_t rows_per_scale, void* dy_bf16,
+                        void* dy_bf16_t, float* colsum_part, int32_t* counters, float* colsum, void* stream);
 /* Attention core (transformer.py:83-104, 4 heads x 128, 32 tokens, no mask, no dropout) on the packed output of the
  * qkv Linear: qkv [n_seq][32][3][4][128] -> o [n_seq][32][512]; backward recomputes the probabilities. */
-int syn_attn_fwd(const float* qkv, float* o, int32_t n_seq, void* stream);
+/* (ABI 5) o fp32 and / or o_bf16 (either may be NULL), as syn_ln_fwd. */
+int syn_attn_fwd(const float* qkv, float* o, void* o_bf16, int32_t n_seq, void* stream);
 int syn_attn_bwd(const float* qkv, const float* d_o, float* dqkv, int32_t n_seq, void* stream);
 
 /* ---- per-clip conditioning: audio encoder -------------------------------------
@@ -400,8 +409,17 @@ int syn_linear_and_pack(const void* x_bf16, const void* w_packed, const float* b
                         void* xt_packed, void* stream);
 /* Two independent syn_linear calls (no bias) as ONE launch: the data-gradient GEMM dy . W and the weight-gradient GEMM dy^T . x of
  * an nn.Linear's backward fill half the chip each and do not depend on each other.  Same result as two calls, bitwise. */
+/* (ABI 5) bias_grad [part_n] (NULL to skip) = sum over i < part_rows of bias_parts [i][part_n], added in order by the same launch: the
+ * Linear's bias gradient from syn_linear_bwd_prep's colsum_part without a reduction launch of its own. */
 int syn_linear_pair(const void* x1_bf16, const void* w1_packed, int32_t m1, int32_t n1, int32_t k1, float* y1,
-                    const void* x2_bf16, const void* w2_packed, int32_t m2, int32_t n2, int32_t k2, float* y2, void* stream);
+                    const void* x2_bf16, const void* w2_packed, int32_t m2, int32_t n2, int32_t k2, float* y2,
+                    const float* bias_parts, int32_t part_rows, int32_t part_n, float* bias_grad, void* stream);
+/* (ABI 5) The last Linear of a pre-LN residual branch with the branch's tail in its epilogue (transformer.py:195-198,
+ * x = x + drop_path(attn(norm1(x))) / x + drop_path(mlp(norm2(x)))): y = residual + row_scale[m / rows_per_scale] * (x W^T + bias),
+ * residual and y fp32 [m_rows][n] (may alias), row_scale NULL = 1 (DropPath off), one factor per sample = rows_per_scale rows.
+ * xt_packed (NULL to skip): as syn_linear_and_pack. */
+int syn_linear_res(const void* x_bf16, const void* w_packed, const float* bias, const float* residual, const float* row_scale,
+                   int32_t rows_per_scale, int32_t m_rows, int32_t n, int32_t k, float* y, void* xt_packed, void* stream);
 
 /* ---- single stages, exported for unit tests and bisecting ----------------------------------- */
 /* Y[m][n] = sum_k X[m][k] * W[n][k] (+ bias[n]); X bf16 [m_rows][k], W packed, Y fp32 [m_rows][n]. n % 512 == 0. */

@@ -69,6 +69,9 @@ struct GArgs {
     // plain fp32 output (unit tests)
     float* Yf; int ldyf;
     int ablate;   // diagnostics (syn_test_gemm only): 1 = weights loaded once, 2 = activations staged once, 4 = no store
+    int mt128;    // row tile of the 128-column plain GEMM (16 / 32 / 64), chosen by the host per shape
+    // plain epilogue of a residual branch's last Linear: Yf = res + rscale[m / rows_per_scale] * (acc + bias) (rscale NULL: factor 1)
+    const float* res; const float* rscale; int rows_per_scale;
 };
 
 // Rotary pair (models/denoiser.py:178-186) with its roundings pinned: u' = fma(u, cos, -(w sin)), w' = fma(w, cos, u sin), the
@@ -219,6 +222,70 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[NF][MT / 16], const _
     }
 }
 
+// The training step's Linear GEMMs have 512 - 1536 rows: 16-row tiles, 32 - 96 x (n / 512) workgroups, a wave or two per SIMD.  In the
+// loop above a k-step is 4 MFMAs of 8 cycles behind weight loads issued 3 k-steps earlier, so at that occupancy every k-step waits for a
+// third of an L2 round trip (~350 cycles per k-step: 48 k-steps of a K = 1536 data gradient = 8 us).  Here the workgroup's 16 x K
+// activation block goes into the LDS ONCE (K <= 2048: <= 64 KB, the same swizzled 64-column tiles), one barrier, and the loop is
+// barrier-free with R k-steps of weight fragments in flight.  Same products in the same order: bitwise the loop above.
+#ifndef SYN_GEMM_RING
+#define SYN_GEMM_RING 12
+#endif
+constexpr int kResidentMaxK = 2048;
+template <int MT, int NF, int R>
+__device__ __forceinline__ void gemm_mainloop_resident(f32x4 (&acc)[NF][MT / 16], const __bf16* __restrict__ X, int ldx, int x_rows, int m0, int M,
+                                                       int K, const uint4* __restrict__ Wq, char* smem) {
+    static_assert(R % 2 == 0 && (R - 1) * NF <= 63, "even ring (the k-step's half of its K tile is static), vmcnt has 6 bits");
+    constexpr int MF = MT / 16, TILE = MT * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int KS = K / 32, total = (K / kKT) * MT * 8;       // 16-byte chunks of the block: [K tile][row 0..MT-1][slot 0..7]
+    uint4 w[R][NF];
+    auto w_load = [&](uint4 (&wr)[NF], int kstep) {
+        if (kstep < KS) {
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) wr[nf] = Wq[((size_t)nf * KS + kstep) * 64];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < R - 1; ++s) w_load(w[s], s);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int base = 0; base < total; base += 4 * kThreads) {
+        uint4 st[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = base + i * kThreads + tid, row = (idx >> 3) % MT, m = m0 + row;
+            st[i] = make_uint4(0, 0, 0, 0);
+            if (idx < total && m < M) st[i] = *reinterpret_cast<const uint4*>(X + (size_t)(m % x_rows) * ldx + (idx / (MT * 8)) * kKT + (idx & 7) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = base + i * kThreads + tid, row = (idx >> 3) % MT, slot = idx & 7;
+            if (idx < total) *reinterpret_cast<uint4*>(smem + (idx / (MT * 8)) * TILE + row * 128 + ((slot ^ (row & 7)) << 4)) = st[i];
+        }
+    }
+    int xoff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) xoff[h] = (lane & 15) * 128 + ((((4 * h) + (lane >> 4)) ^ (lane & 7)) << 4);
+    __syncthreads();
+    for (int base = 0; base < KS; base += R) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int ks = base + i;
+            w_load(w[(i + R - 1) % R], ks + R - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks < KS) {
+                bf16x8 xf[MF];
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) xf[mf] = *reinterpret_cast<const bf16x8*>(smem + (ks >> 1) * TILE + mf * 2048 + xoff[i & 1]);
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                    for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = MFMA16(__builtin_bit_cast(bf16x8, w[i][nf]), xf[mf], acc[nf][mf]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // Row mean / rstd over the 512 columns a workgroup owns (8 waves x 64).  One pass (sum and sum of squares,
 // fp32), ONE workgroup barrier: every lane then adds the 8 per-wave partials of its own rows (broadcast LDS
 // reads).  The cancellation in E[x^2] - mean^2 costs ~6e-8 * (1 + mean^2/var) relative, far below the bf16
@@ -299,6 +366,19 @@ __device__ __forceinline__ void store_h_and_norm(const GArgs& a, f32x4 (&v)[4][M
 // shadow is therefore written element by element, every result passed through this opaque no-op.
 __device__ __forceinline__ float nopk(float x) { asm("" : "+v"(x)); return x; }
 
+// x + DropPath(branch) (timm_transformer/transformer.py:195-198) in the epilogue of the branch's last Linear: res + factor * (x W^T + b),
+// the factor one float per sample (rows_per_scale rows), rounded as torch.addcmul rounds it (product, then sum).
+__device__ __forceinline__ f32x4 plain_residual(const GArgs& a, f32x4 v, int m, int n) {
+    const f32x4 r = *reinterpret_cast<const f32x4*>(a.res + (size_t)m * a.ldyf + n);
+    if (a.rscale) {
+        const float sc = a.rscale[m / a.rows_per_scale];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = nopk(v[e] * sc);
+    }
+    return r + v;
+}
+
+
 // Philox4x32-10 (Salmon et al. 2011), counter = (index/4, stream_id), key = seed; Box-Muller pairs.
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
@@ -328,8 +408,9 @@ __device__ __forceinline__ f32x4 randn4(uint64_t seed, uint64_t stream_id, uint6
     return z;
 }
 
-template <int MT, int EPI>
+template <int MT, int EPI, bool RES = false>
 __device__ __forceinline__ void gemm_body(const GArgs& a, const int bx, const int by) {
+    static_assert(!RES || (MT == 16 && EPI == EPI_PLAIN), "the activation-resident loop serves the plain 16-row GEMMs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MF = MT / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lr = lane & 15;
@@ -377,7 +458,9 @@ __device__ __forceinline__ void gemm_body(const GArgs& a, const int bx, const in
     const uint4* Wq = a.W + ((size_t)(chunk * 32 + wave * 4) * KS) * 64 + lane;
     const __bf16* X = a.X + (size_t)chunk * a.x_chunk_stride;
     const bool swap = (EPI == EPI_QKV) && (chunk == 2);
-    if (swap)
+    if constexpr (RES)
+        gemm_mainloop_resident<16, 4, SYN_GEMM_RING>(acc, X, a.ldx, a.x_rows, m0, a.M, a.K, Wq, smem);
+    else if (swap)
         gemm_mainloop<MT, 4, 1, 0xF>(acc, X, a.ldx, a.x_rows, m0, a.M, a.K, Wq, smem);
     else
         gemm_mainloop<MT, 4, 1, 0>(acc, X, a.ldx, a.x_rows, m0, a.M, a.K, Wq, smem, EPI == EPI_PLAIN ? a.ablate : 0);
@@ -393,8 +476,11 @@ __device__ __forceinline__ void gemm_body(const GArgs& a, const int bx, const in
 #pragma unroll
             for (int mf = 0; mf < MF; ++mf) {
                 const int m = m0 + mf * 16 + lr;
-                if (m < a.M && (!(a.ablate & 4) || acc[nf][mf][0] == 12345.678f))
-                    *reinterpret_cast<f32x4*>(a.Yf + (size_t)m * a.ldyf + n) = acc[nf][mf] + b;
+                if (m < a.M && (!(a.ablate & 4) || acc[nf][mf][0] == 12345.678f)) {
+                    f32x4 v = acc[nf][mf] + b;
+                    if (a.res) v = plain_residual(a, v, m, n);
+                    *reinterpret_cast<f32x4*>(a.Yf + (size_t)m * a.ldyf + n) = v;
+                }
             }
         }
     } else if constexpr (EPI == EPI_IN) {
@@ -479,25 +565,71 @@ __device__ __forceinline__ void gemm_body(const GArgs& a, const int bx, const in
     }
 }
 
-template <int MT, int EPI>
-__global__ __launch_bounds__(kThreads) void k_gemm(const GArgs a) { gemm_body<MT, EPI>(a, blockIdx.x, blockIdx.y); }
+template <int MT, int EPI, bool RES = false>
+__global__ __launch_bounds__(kThreads) void k_gemm(const GArgs a) { gemm_body<MT, EPI, RES>(a, blockIdx.x, blockIdx.y); }
+
+// Plain GEMM on MT x 128 tiles (8 waves x 16 columns): the training step's shapes (1024 rows, 512 - 1536 columns) on 16 x 512 tiles are 64 - 192
+// workgroups that each pull a 512-column slab of W (512 KB at K = 512) through ONE CU's L1 port - ~85 GB/s: 6 us per 512 of K whatever the
+// ring depth (measured: 8.8 / 11.9 / 21.1 us at K = 512 / 1024 / 2048).  A quarter of the columns per workgroup = four times the workgroups,
+// each pulling (MT + 128) x K x 2 bytes: the same L2 traffic through four times the ports.  Activation block resident in the LDS, deep ring.
+template <int MT>
+__device__ __forceinline__ void gemm_body_n128(const GArgs& a, const int bx, const int by) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MF = MT / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lr = lane & 15;
+    const int m0 = bx * MT, KS = a.K / 32;
+    f32x4 acc[1][MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) acc[0][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const uint4* Wq = a.W + ((size_t)(by * 8 + wave) * KS) * 64 + lane;
+    gemm_mainloop_resident<MT, 1, 16>(acc, a.X, a.ldx, a.x_rows, m0, a.M, a.K, Wq, smem);
+    const int n = by * 128 + wave * 16 + g * 4;
+    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) b = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+        const int m = m0 + mf * 16 + lr;
+        if (m < a.M) {
+            f32x4 v = acc[0][mf] + b;
+            if (a.res) v = plain_residual(a, v, m, n);
+            *reinterpret_cast<f32x4*>(a.Yf + (size_t)m * a.ldyf + n) = v;
+        }
+    }
+}
+__device__ __forceinline__ void gemm_n128(const GArgs& a, const int bx, const int by) {
+    if (a.mt128 == 64) gemm_body_n128<64>(a, bx, by);
+    else if (a.mt128 == 32) gemm_body_n128<32>(a, bx, by);
+    else gemm_body_n128<16>(a, bx, by);
+}
+__global__ __launch_bounds__(kThreads) void k_gemm_n128(const GArgs a) { gemm_n128(a, blockIdx.x, blockIdx.y); }
 
 // Two independent plain GEMMs in one launch (grid z picks; x / y sized for the larger): the data-gradient and weight-gradient GEMMs of
 // an nn.Linear's backward are 64 - 128 workgroups each on 256 CUs and do not depend on each other.
-struct GPair { GArgs g[2]; int gx[2], gy[2]; };
-template <int MT>
+struct GPair { GArgs g[2]; int gx[2], gy[2]; const float* bias_parts; float* bias_grad; int part_rows, part_n; };
+template <int MT, int MODE>              // MODE 0: 16 x 512 tiles, streaming loop; 1: the same tiles, resident loop; 2: 16 x 128 tiles, resident loop
 __global__ __launch_bounds__(kThreads) void k_gemm_pair(const GPair p) {
     const int z = blockIdx.z;
+    if (p.bias_grad && blockIdx.x == 0 && blockIdx.y == 0 && z == 0)       // the Linear's bias gradient: the sum of syn_linear_bwd_prep's per-64-row
+        for (int n = threadIdx.x; n < p.part_n; n += kThreads) {            // column sums, in row-block order (what `part.sum(0)` cost a launch for)
+            float sacc = 0.f;
+            for (int i = 0; i < p.part_rows; ++i) sacc += p.bias_parts[(size_t)i * p.part_n + n];
+            p.bias_grad[n] = sacc;
+        }
     if ((int)blockIdx.x >= p.gx[z] || (int)blockIdx.y >= p.gy[z]) return;
-    gemm_body<MT, EPI_PLAIN>(p.g[z], blockIdx.x, blockIdx.y);
+    if constexpr (MODE == 2) gemm_n128(p.g[z], blockIdx.x, blockIdx.y);
+    else gemm_body<MT, EPI_PLAIN, MODE == 1>(p.g[z], blockIdx.x, blockIdx.y);
 }
 
 // A forward GEMM of the training step fills a quarter to three quarters of the chip (16-row tiles x n / 512 columns), and the
 // backward will need x^T as packed fragments (the weight-gradient GEMM's B operand): grid z = 1 packs them in the GEMM's shadow.
 struct GPack { GArgs g; const __bf16* src; uint4* out; int n, k; };          // pack: fragments of W = src^T, src row-major [k][n] (k_pack_t)
-template <int MT>
+template <int MT, int MODE>
 __global__ __launch_bounds__(kThreads) void k_gemm_and_pack(const GPack p) {
-    if (blockIdx.z == 0) { gemm_body<MT, EPI_PLAIN>(p.g, blockIdx.x, blockIdx.y); return; }
+    if (blockIdx.z == 0) {
+        if constexpr (MODE == 2) gemm_n128(p.g, blockIdx.x, blockIdx.y);
+        else gemm_body<MT, EPI_PLAIN, MODE == 1>(p.g, blockIdx.x, blockIdx.y);
+        return;
+    }
     const int KS = p.k / 32, total = (p.n / 16) * KS * 64;
     const int stride = gridDim.x * gridDim.y * kThreads;
     for (int idx = (blockIdx.y * gridDim.x + blockIdx.x) * kThreads + threadIdx.x; idx < total; idx += stride) {
@@ -1633,6 +1765,25 @@ int fail_msg(const char* what) {
     return -2;
 }
 
+static int g_gemm_resident = 2;      // 16-row plain GEMMs: 2 = 16 x 128 tiles, activation block resident in the LDS, deep weight ring; 1 = the same loop on
+                                     // 16 x 512 tiles; 0 = the streaming loop (syn_debug_gemm_resident: A/B)
+
+int device_cus();
+constexpr int kN128Lds = 128 * 1024;
+// Row tile of the 128-column plain GEMM: the largest of 64 / 32 / 16 that still gives every CU a workgroup (fewer bytes through each CU's L1
+// port: a workgroup pulls (MT + 128) x K x 2) and whose activation block fits the LDS; 0 = the shape does not fit this kernel at all.
+int pick_mt128(int M, int N, int K) {
+    if (K * 32 > kN128Lds) return 0;
+    static int g_force = -1;
+    if (g_force < 0) { const char* e = getenv("SYN_GEMM_MT128"); g_force = e ? atoi(e) : 0; }
+    if (g_force && g_force * K * 2 <= kN128Lds) return g_force;
+    const int cus = device_cus();
+    for (int mt = 64; mt > 16; mt >>= 1)
+        if (mt * K * 2 <= kN128Lds && ((M + mt - 1) / mt) * (N / 128) >= cus * 3 / 4) return mt;
+    return 16;
+}
+void n128_setup();
+
 template <int EPI>
 int launch_gemm(const GArgs& a, int mt, int chunks, hipStream_t s) {
     if (a.K % 128 != 0 || a.M <= 0) return fail_msg("gemm: K must be a multiple of 128 and M > 0");
@@ -1642,7 +1793,17 @@ int launch_gemm(const GArgs& a, int mt, int chunks, hipStream_t s) {
         case 64:  hipLaunchKernelGGL((k_gemm<64, EPI>), grid, block, 2 * 64 * 128, s, a); break;
         case 32:  hipLaunchKernelGGL((k_gemm<32, EPI>), grid, block, 2 * 32 * 128 + 1024, s, a); break;
         case 16:
-            if constexpr (EPI == EPI_PLAIN) { hipLaunchKernelGGL((k_gemm<16, EPI>), grid, block, 2 * 32 * 128 + 1024, s, a); break; }
+            if constexpr (EPI == EPI_PLAIN) {
+                if (const int m128 = (g_gemm_resident == 2 && !a.ablate) ? pick_mt128(a.M, chunks * kNT, a.K) : 0) {
+                    GArgs b = a;
+                    b.mt128 = m128;
+                    n128_setup();
+                    hipLaunchKernelGGL(k_gemm_n128, dim3((a.M + m128 - 1) / m128, chunks * 4), block, m128 * a.K * 2, s, b);
+                }
+                else if (g_gemm_resident == 1 && a.K <= kResidentMaxK && !a.ablate) hipLaunchKernelGGL((k_gemm<16, EPI, true>), grid, block, a.K * 32, s, a);
+                else hipLaunchKernelGGL((k_gemm<16, EPI>), grid, block, 2 * 32 * 128 + 1024, s, a);
+                break;
+            }
             return fail_msg("gemm: 16-row tiles exist for the plain epilogue only");
         default:  return fail_msg("gemm: m_tile must be 16, 32, 64 or 128");
     }
@@ -1668,6 +1829,15 @@ struct OncePerDevice {
         return true;
     }
 };
+
+void n128_setup() {
+    static OncePerDevice once;
+    if (once.first()) {
+        allow_lds(k_gemm_n128, kN128Lds);
+        allow_lds(k_gemm_pair<16, 2>, kN128Lds);
+        allow_lds(k_gemm_and_pack<16, 2>, kN128Lds);
+    }
+}
 
 int launch_attn_block(const AArgs& a, int mt, hipStream_t s) {
     static OncePerDevice once;
@@ -2162,48 +2332,67 @@ int syn_test_gemm(const void* x_bf16, const void* w_packed, const float* bias, i
 
 static int g_linear_mt = 0;
 
-int syn_linear(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k, float* y,
-               void* stream) {
-    if (!x_bf16 || !w_packed || !y || n % kNT || k % 128 || m_rows <= 0)
-        return fail_msg("syn_linear: need n % 512 == 0, k % 128 == 0, m_rows > 0 and non-null pointers");
-    GArgs a;
-    memset(&a, 0, sizeof(a));
-    a.X = (const __bf16*)x_bf16; a.ldx = k; a.x_rows = m_rows; a.W = (const uint4*)w_packed; a.K = k; a.M = m_rows;
-    a.bias = bias; a.Yf = y; a.ldyf = n;
-    // the training step's GEMMs have 512 .. 1536 rows: 16-row tiles give 32 .. 96 x (n / 512) workgroups, twice what 32-row ones do
-    const int mt = g_linear_mt > 0 ? g_linear_mt : (m_rows <= 2048 ? 16 : pick_tile(m_rows));
-    return launch_gemm<EPI_PLAIN>(a, mt, n / kNT, (hipStream_t)stream);
-}
-
-int syn_linear_and_pack(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k, float* y,
-                        void* xt_packed, void* stream) {
-    if (!x_bf16 || !w_packed || !y || !xt_packed || n % kNT || k % 128 || m_rows <= 0 || m_rows % 32 || k % 16)
-        return fail_msg("syn_linear_and_pack: need n % 512 == 0, k % 128 == 0, m_rows % 32 == 0 and non-null pointers");
-    if (m_rows > 2048 || g_linear_mt > 0) {                          // larger row tiles: two launches
-        if (int rc = syn_linear(x_bf16, w_packed, bias, m_rows, n, k, y, stream)) return rc;
-        return syn_pack_weight_t(x_bf16, 1, k, m_rows, xt_packed, stream);
-    }
+static int linear_impl(const void* x_bf16, const void* w_packed, const float* bias, const float* res, const float* rscale, int rows_per_scale,
+                       int32_t m_rows, int32_t n, int32_t k, float* y, void* xt_packed, void* stream, const char* who) {
+    if (!x_bf16 || !w_packed || !y || n % kNT || k % 128 || m_rows <= 0 || (rscale && (!res || rows_per_scale <= 0)))
+        return fail_msg("syn_linear*: need n % 512 == 0, k % 128 == 0, m_rows > 0, non-null pointers (a row scale needs the residual and rows_per_scale > 0)");
+    if (xt_packed && (m_rows % 32 || k % 16)) return fail_msg("syn_linear_and_pack: the x^T pack needs m_rows % 32 == 0");
     GPack p;
     memset(&p, 0, sizeof(p));
     GArgs& a = p.g;
     a.X = (const __bf16*)x_bf16; a.ldx = k; a.x_rows = m_rows; a.W = (const uint4*)w_packed; a.K = k; a.M = m_rows;
     a.bias = bias; a.Yf = y; a.ldyf = n;
+    a.res = res; a.rscale = rscale; a.rows_per_scale = rows_per_scale;
+    if (!xt_packed || m_rows > 2048 || g_linear_mt > 0) {            // no pack, or larger row tiles: the pack is a launch of its own
+        // the training step's GEMMs have 512 .. 1536 rows: 16-row tiles give 32 .. 96 x (n / 512) workgroups, twice what 32-row ones do
+        const int mt = g_linear_mt > 0 ? g_linear_mt : (m_rows <= 2048 ? 16 : pick_tile(m_rows));
+        if (int rc = launch_gemm<EPI_PLAIN>(a, mt, n / kNT, (hipStream_t)stream)) return rc;
+        return xt_packed ? syn_pack_weight_t(x_bf16, 1, k, m_rows, xt_packed, stream) : 0;
+    }
     p.src = (const __bf16*)x_bf16; p.out = (uint4*)xt_packed; p.n = k; p.k = m_rows;     // x [m][k] is the row-major [k' = m][n' = k] of x^T [k][m]
-    hipLaunchKernelGGL((k_gemm_and_pack<16>), dim3((m_rows + 15) / 16, n / kNT, 2), dim3(kThreads), 2 * 32 * 128 + 1024, (hipStream_t)stream, p);
+    if (const int m128 = g_gemm_resident == 2 ? pick_mt128(m_rows, n, k) : 0) {
+        a.mt128 = m128;
+        n128_setup();
+        hipLaunchKernelGGL((k_gemm_and_pack<16, 2>), dim3((m_rows + m128 - 1) / m128, n / 128, 2), dim3(kThreads), m128 * k * 2, (hipStream_t)stream, p);
+    } else if (g_gemm_resident == 1 && k <= kResidentMaxK)
+        hipLaunchKernelGGL((k_gemm_and_pack<16, 1>), dim3((m_rows + 15) / 16, n / kNT, 2), dim3(kThreads), k * 32, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((k_gemm_and_pack<16, 0>), dim3((m_rows + 15) / 16, n / kNT, 2), dim3(kThreads), 2 * 32 * 128 + 1024, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("k_gemm_and_pack launch", e);
+    return e == hipSuccess ? 0 : fail(who, e);
+}
+
+int syn_linear(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k, float* y,
+               void* stream) {
+    return linear_impl(x_bf16, w_packed, bias, nullptr, nullptr, 0, m_rows, n, k, y, nullptr, stream, "k_gemm launch");
+}
+
+int syn_linear_and_pack(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k, float* y,
+                        void* xt_packed, void* stream) {
+    if (!xt_packed) return fail_msg("syn_linear_and_pack: xt_packed is NULL");
+    return linear_impl(x_bf16, w_packed, bias, nullptr, nullptr, 0, m_rows, n, k, y, xt_packed, stream, "k_gemm_and_pack launch");
+}
+
+int syn_linear_res(const void* x_bf16, const void* w_packed, const float* bias, const float* residual, const float* row_scale,
+                   int32_t rows_per_scale, int32_t m_rows, int32_t n, int32_t k, float* y, void* xt_packed, void* stream) {
+    if (!residual) return fail_msg("syn_linear_res: residual is NULL (use syn_linear)");
+    return linear_impl(x_bf16, w_packed, bias, residual, row_scale, rows_per_scale, m_rows, n, k, y, xt_packed, stream, "k_gemm (residual) launch");
 }
 
 int syn_linear_pair(const void* x1_bf16, const void* w1_packed, int32_t m1, int32_t n1, int32_t k1, float* y1,
-                    const void* x2_bf16, const void* w2_packed, int32_t m2, int32_t n2, int32_t k2, float* y2, void* stream) {
+                    const void* x2_bf16, const void* w2_packed, int32_t m2, int32_t n2, int32_t k2, float* y2,
+                    const float* bias_parts, int32_t part_rows, int32_t part_n, float* bias_grad, void* stream) {
+    if (bias_grad && (!bias_parts || part_rows <= 0 || part_n <= 0)) return fail_msg("syn_linear_pair: bias_grad needs bias_parts [part_rows][part_n]");
     if (!x1_bf16 || !w1_packed || !y1 || !x2_bf16 || !w2_packed || !y2 || n1 % kNT || n2 % kNT || k1 % 128 || k2 % 128 || m1 <= 0 || m2 <= 0)
         return fail_msg("syn_linear_pair: need n % 512 == 0, k % 128 == 0, m_rows > 0 and non-null pointers");
     if (m1 > 2048 || m2 > 2048 || g_linear_mt > 0) {                 // larger row tiles: two launches
+        if (bias_grad) return fail_msg("syn_linear_pair: the bias-gradient sum rides the single launch (m <= 2048, automatic row tile)");
         if (int rc = syn_linear(x1_bf16, w1_packed, nullptr, m1, n1, k1, y1, stream)) return rc;
         return syn_linear(x2_bf16, w2_packed, nullptr, m2, n2, k2, y2, stream);
     }
     GPair p;
     memset(&p, 0, sizeof(p));
+    p.bias_parts = bias_parts; p.bias_grad = bias_grad; p.part_rows = part_rows; p.part_n = part_n;
     const void* xs[2] = {x1_bf16, x2_bf16}; const void* ws[2] = {w1_packed, w2_packed};
     const int ms[2] = {m1, m2}, ns[2] = {n1, n2}, ks[2] = {k1, k2}; float* ys[2] = {y1, y2};
     for (int i = 0; i < 2; ++i) {
@@ -2212,12 +2401,28 @@ int syn_linear_pair(const void* x1_bf16, const void* w1_packed, int32_t m1, int3
         a.Yf = ys[i]; a.ldyf = ns[i];
         p.gx[i] = (ms[i] + 15) / 16; p.gy[i] = ns[i] / kNT;
     }
+    const bool fits = k1 <= kResidentMaxK && k2 <= kResidentMaxK;
+    int lds128 = 0;
+    const bool n128 = g_gemm_resident == 2 && pick_mt128(m1, n1, k1) && pick_mt128(m2, n2, k2);
+    if (n128)                                                                  // 128-column tiles, the row tile per shape (half a chip each)
+        for (int i = 0; i < 2; ++i) {
+            const int mt = pick_mt128(ms[i] * 2, ns[i], ks[i]);
+            p.g[i].mt128 = mt; p.gx[i] = (ms[i] + mt - 1) / mt; p.gy[i] = ns[i] / 128;
+            lds128 = mt * ks[i] * 2 > lds128 ? mt * ks[i] * 2 : lds128;
+        }
     const dim3 grid(p.gx[0] > p.gx[1] ? p.gx[0] : p.gx[1], p.gy[0] > p.gy[1] ? p.gy[0] : p.gy[1], 2);
-    hipLaunchKernelGGL((k_gemm_pair<16>), grid, dim3(kThreads), 2 * 32 * 128 + 1024, (hipStream_t)stream, p);
+    if (n128) {
+        n128_setup();
+        hipLaunchKernelGGL((k_gemm_pair<16, 2>), grid, dim3(kThreads), lds128, (hipStream_t)stream, p);
+    } else if (g_gemm_resident == 1 && fits)
+        hipLaunchKernelGGL((k_gemm_pair<16, 1>), grid, dim3(kThreads), (k1 > k2 ? k1 : k2) * 32, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL((k_gemm_pair<16, 0>), grid, dim3(kThreads), 2 * 32 * 128 + 1024, (hipStream_t)stream, p);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_gemm_pair launch", e);
 }
 
+void syn_debug_gemm_resident(int on) { g_gemm_resident = on; }     /* diagnostics: 0 = the streaming loop for the 16-row plain GEMMs too (A/B) */
 void syn_debug_linear_tile(int rows) { g_linear_mt = rows; }       /* diagnostics: pin syn_linear's row tile (16 / 32 / 64 / 128), 0 = automatic */
 
 int syn_test_handoff(uint32_t* sync_320_zeroed, uint32_t* buf_8x4096, const float* stream, int64_t stream_n, uint32_t* stale_9_zeroed,
@@ -2244,9 +2449,9 @@ int syn_test_attention(const void* q, const void* k, const void* vt, int32_t n_s
 }
 
 // ---- training path: fp32 forward / backward of LayerNorm(512), GELU and the 32-token attention ---------------
-int syn_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int32_t rows, void* stream) {
-    if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0) return fail_msg("syn_ln_fwd: bad arguments");
-    hipLaunchKernelGGL(trn::k_ln_fwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, rows);
+int syn_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, void* y_bf16, float* mean, float* rstd, int32_t rows, void* stream) {
+    if (!x || !gamma || !beta || (!y && !y_bf16) || !mean || !rstd || rows <= 0) return fail_msg("syn_ln_fwd: bad arguments");
+    hipLaunchKernelGGL(trn::k_ln_fwd, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, (__bf16*)y_bf16, mean, rstd, rows);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_ln_fwd launch", e);
 }
@@ -2263,9 +2468,9 @@ int syn_ln_bwd(const float* dy, const float* x, const float* gamma, const float*
     return e == hipSuccess ? 0 : fail("k_ln_bwd launch", e);
 }
 
-int syn_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
-    if (!x || !y || n <= 0 || n % 4) return fail_msg("syn_gelu_fwd: n must be a positive multiple of 4");
-    hipLaunchKernelGGL(trn::k_gelu_fwd, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)(n / 4));
+int syn_gelu_fwd(const float* x, float* y, void* y_bf16, int64_t n, void* stream) {
+    if (!x || (!y && !y_bf16) || n <= 0 || n % 4) return fail_msg("syn_gelu_fwd: n must be a positive multiple of 4");
+    hipLaunchKernelGGL(trn::k_gelu_fwd, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, (__bf16*)y_bf16, (size_t)(n / 4));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_gelu_fwd launch", e);
 }
@@ -2361,13 +2566,13 @@ int syn_bn_act_bwd_apply(const float* dz, const float* z, const float* y, const 
     return e == hipSuccess ? 0 : fail("syn_bn_act_bwd_apply", e);
 }
 
-int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, void* dy_bf16, void* dy_bf16_t, float* colsum_part, int32_t* counters,
-                        float* colsum, void* stream) {
-    if (!dy || !dy_bf16 || !dy_bf16_t || m_rows <= 0 || n <= 0 || m_rows % 64 || n % 64)
+int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, const float* row_scale, int32_t rows_per_scale, void* dy_bf16, void* dy_bf16_t,
+                        float* colsum_part, int32_t* counters, float* colsum, void* stream) {
+    if (!dy || !dy_bf16 || !dy_bf16_t || m_rows <= 0 || n <= 0 || m_rows % 64 || n % 64 || (row_scale && rows_per_scale <= 0))
         return fail_msg("syn_linear_bwd_prep: need m_rows % 64 == 0, n % 64 == 0 and non-null pointers");
     if (colsum && (!colsum_part || !counters)) return fail_msg("syn_linear_bwd_prep: colsum needs colsum_part and counters");
-    hipLaunchKernelGGL(trn::k_linear_bwd_prep, dim3(n / 64, m_rows / 64), dim3(256), 0, (hipStream_t)stream, dy, m_rows, n, (__bf16*)dy_bf16,
-                       (__bf16*)dy_bf16_t, colsum_part, counters, colsum);
+    hipLaunchKernelGGL(trn::k_linear_bwd_prep, dim3(n / 64, m_rows / 64), dim3(256), 0, (hipStream_t)stream, dy, m_rows, n, row_scale, rows_per_scale,
+                       (__bf16*)dy_bf16, (__bf16*)dy_bf16_t, colsum_part, counters, colsum);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_linear_bwd_prep launch", e);
 }
@@ -2388,11 +2593,11 @@ int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* st
     return e == hipSuccess ? 0 : fail("k_gelu_bwd launch", e);
 }
 
-int syn_attn_fwd(const float* qkv, float* o, int32_t n_seq, void* stream) {
-    if (!qkv || !o || n_seq <= 0) return fail_msg("syn_attn_fwd: bad arguments");
+int syn_attn_fwd(const float* qkv, float* o, void* o_bf16, int32_t n_seq, void* stream) {
+    if (!qkv || (!o && !o_bf16) || n_seq <= 0) return fail_msg("syn_attn_fwd: bad arguments");
     static const bool v1 = getenv("SYN_ATTN_BWD_V1") != nullptr;    // diagnostics: the first version of the kernels
-    if (v1) hipLaunchKernelGGL(trn::k_attn_fwd, dim3(n_seq * SYN_HEADS), dim3(256), 0, (hipStream_t)stream, qkv, o);
-    else hipLaunchKernelGGL(trn::k_attn_fwd2, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnFwd2Lds, (hipStream_t)stream, qkv, o);
+    if (v1) hipLaunchKernelGGL(trn::k_attn_fwd, dim3(n_seq * SYN_HEADS), dim3(256), 0, (hipStream_t)stream, qkv, o, (__bf16*)o_bf16);
+    else hipLaunchKernelGGL(trn::k_attn_fwd2, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnFwd2Lds, (hipStream_t)stream, qkv, o, (__bf16*)o_bf16);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_attn_fwd launch", e);
 }

@@ -179,8 +179,11 @@ class HipLinearFn(torch.autograd.Function):
         M = xb.shape[0]
         dy2 = dy.reshape(-1, N)
         dx = dw = db = dybt = None
+        pair = (LINEAR_BWD_PAIR and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and K % 512 == 0 and N % 128 == 0
+                and M % 128 == 0 and w.dtype is torch.float32 and w.is_contiguous() and xb.is_contiguous())
+        part = None
         if LINEAR_BWD_PREP and M % 64 == 0 and N % 64 == 0 and dy2.dtype is torch.float32 and dy2.is_cuda:
-            # one pass over dy: bf16 copy, bf16 transpose (weight gradient) and the bias gradient
+            # one pass over dy: bf16 copy, bf16 transpose (weight gradient) and the bias gradient's per-64-row partial sums
             dy2 = dy2.contiguous()
             dyb = torch.empty(M, N, dtype=torch.bfloat16, device=dy.device)
             dybt = torch.empty(N, M, dtype=torch.bfloat16, device=dy.device)
@@ -189,26 +192,31 @@ class HipLinearFn(torch.autograd.Function):
             in_launch = want_db and LINEAR_BWD_PREP > 2 and N // 64 <= 1024
             if in_launch:
                 db = torch.empty(N, dtype=torch.float32, device=dy.device)
-            _lib.check(_lib.load().syn_linear_bwd_prep(dy2.data_ptr(), M, N, dyb.data_ptr(), dybt.data_ptr(), _lib.ptr(part),
+            _lib.check(_lib.load().syn_linear_bwd_prep(dy2.data_ptr(), M, N, None, 0, dyb.data_ptr(), dybt.data_ptr(), _lib.ptr(part),
                                                        _lib.ptr(_counters(dy.device)) if in_launch else None, _lib.ptr(db) if in_launch else None,
                                                        _lib.current_stream(dy.device)), "syn_linear_bwd_prep")
-            if want_db and not in_launch:
+            if want_db and not in_launch and not (pair and M <= 2048):
                 db = part.sum(0)
         else:
             dyb = dy2.to(torch.bfloat16).contiguous()
-        if (LINEAR_BWD_PAIR and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dybt is not None and K % 512 == 0 and N % 128 == 0
-                and M % 128 == 0 and w.dtype is torch.float32 and w.is_contiguous() and xb.is_contiguous()):
-            # dy . W and dy^T . x - independent, half a chip each - as one launch
+        if pair and dybt is not None:
+            # dy . W and dy^T . x - independent, half a chip each - as one launch, which also adds the bias gradient's partial sums up
             wt = ctx.pack_t if ctx.pack_t is not None else _pack_t(w, K, N)
             dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
             dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+            sum_here = part is not None and db is None
+            if sum_here:
+                db = torch.empty(N, dtype=torch.float32, device=dy.device)
             _lib.check(_lib.load().syn_linear_pair(dyb.data_ptr(), wt.data_ptr(), M, K, N, dx.data_ptr(),
                                                    dybt.data_ptr(), (ctx.xt if ctx.xt is not None else _pack_t(xb, K, M)).data_ptr(), N, K, M, dw.data_ptr(),
+                                                   _lib.ptr(part) if sum_here else None, M // 64, N, _lib.ptr(db) if sum_here else None,
                                                    _lib.current_stream(dy.device)), "syn_linear_pair")
             dx = dx.reshape(ctx.in_shape)
             if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
                 db = dy2.sum(0)
             return dx, dw.to(w.dtype), db
+        if part is not None and db is None:
+            db = part.sum(0)
         if ctx.needs_input_grad[0]:
             if K % 512 == 0 and N % 128 == 0 and w.dtype is torch.float32 and w.is_contiguous():
                 wt = ctx.pack_t if ctx.pack_t is not None else _pack_t(w, K, N)          # W^T: the step's pack, or packed in place
@@ -301,7 +309,7 @@ class HipLayerNormFn(torch.autograd.Function):
         rows = xc.shape[0]
         y = torch.empty_like(xc)
         mean, rstd = torch.empty(rows, device=x.device), torch.empty(rows, device=x.device)
-        _lib.check(_lib.load().syn_ln_fwd(xc.data_ptr(), gc.data_ptr(), bc.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+        _lib.check(_lib.load().syn_ln_fwd(xc.data_ptr(), gc.data_ptr(), bc.data_ptr(), y.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(),
                                           rows, _lib.current_stream(y.device)), "syn_ln_fwd")
         ctx.save_for_backward(xc, gc, mean, rstd)
         return y.view(x.shape)
@@ -349,7 +357,7 @@ class HipGeluFn(torch.autograd.Function):
         engine._require_cuda(x, "GELU input")
         xc = _f32c(x)
         y = torch.empty_like(xc)
-        _lib.check(_lib.load().syn_gelu_fwd(xc.data_ptr(), y.data_ptr(), xc.numel(), _lib.current_stream(y.device)), "syn_gelu_fwd")
+        _lib.check(_lib.load().syn_gelu_fwd(xc.data_ptr(), y.data_ptr(), None, xc.numel(), _lib.current_stream(y.device)), "syn_gelu_fwd")
         ctx.save_for_backward(xc)
         return y
 
@@ -373,7 +381,7 @@ class HipAttentionFn(torch.autograd.Function):
         bs, T, _ = q.shape
         assert T == 32 and q.shape[2] == 1536, q.shape
         o = torch.empty(bs, T, 512, device=q.device)
-        _lib.check(_lib.load().syn_attn_fwd(q.data_ptr(), o.data_ptr(), bs, _lib.current_stream(o.device)), "syn_attn_fwd")
+        _lib.check(_lib.load().syn_attn_fwd(q.data_ptr(), o.data_ptr(), None, bs, _lib.current_stream(o.device)), "syn_attn_fwd")
         ctx.save_for_backward(q)
         return o
 
@@ -384,6 +392,148 @@ class HipAttentionFn(torch.autograd.Function):
         dqkv = torch.empty_like(q)
         _lib.check(_lib.load().syn_attn_bwd(q.data_ptr(), doc.data_ptr(), dqkv.data_ptr(), q.shape[0], _lib.current_stream(dqkv.device)), "syn_attn_bwd")
         return dqkv
+
+
+# ---- a pre-LN residual branch as ONE autograd node ---------------------------------------------------------------------------
+# x + drop_path(attn(norm1(x))) and x + drop_path(mlp(norm2(x))) (timm_transformer/transformer.py:195-198).  Built from the ops above
+# these are 7 / 6 autograd nodes per branch with PyTorch glue between them - a bf16 cast in front of every Linear, addcmul for the
+# DropPath factor and its mul in the backward, a sum for every bias gradient, copies where a gradient is not contiguous: ~25 launches
+# of 3-5 us per branch and direction around kernels that run 5-15 us.  As one node the branch is the kernels and nothing else:
+#   forward   LayerNorm -> bf16 rows | GEMM (+ x^T pack) | attention -> bf16 / GELU -> bf16 | GEMM with `x + factor * (.)` in its epilogue
+#   backward  prep (factor * dy -> bf16, bf16^T, bias partials) | GEMM pair (+ bias sum) | attention / GELU backward | prep | GEMM pair |
+#             LayerNorm backward with dy as its addend (the residual path)
+# The fp32 LayerNorm / attention / GELU outputs are never written: the Linear behind each takes bf16 operands and nothing else reads them.
+BLOCK_FUSED = bool(int(_os.environ.get("SYN_TRAIN_BLOCK_FUSED", "1")))
+
+
+def _fused_ok(M, *layers) -> bool:
+    """Every Linear of the branch has its step packs (W and W^T fragments) and the GEMM pair's shape constraints hold."""
+    if not (BLOCK_FUSED and M % 128 == 0):
+        return False
+    for l in layers:
+        pk, tr = _lookup_packs(l.weight)
+        if pk is None or tr is None or l.weight.shape[1] % 512 or l.weight.shape[0] % 128:
+            return False
+        if l.bias is not None and not (l.bias.dtype is torch.float32 and l.bias.is_contiguous()):
+            return False
+    return True
+
+
+def _lin_fwd(xb, w, b, res=None, scale=None, rows_per_scale=1):
+    """bf16 rows [M][K] -> fp32 [M][N] = x W^T + b, or res + scale[row // rows_per_scale] * (x W^T + b); also the x^T fragments the
+    weight-gradient GEMM will take (packed by the same launch while M <= 2048)."""
+    pk, _ = _lookup_packs(w)
+    M, K = xb.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=xb.device)
+    xt = torch.empty(K * M * 2, dtype=torch.uint8, device=xb.device)
+    lib, st = _lib.load(), _lib.current_stream(xb.device)
+    if res is not None:
+        _lib.check(lib.syn_linear_res(xb.data_ptr(), pk.data_ptr(), _lib.ptr(b), res.data_ptr(), _lib.ptr(scale), rows_per_scale, M, N, K,
+                                      y.data_ptr(), xt.data_ptr(), st), "syn_linear_res")
+    else:
+        _lib.check(lib.syn_linear_and_pack(xb.data_ptr(), pk.data_ptr(), _lib.ptr(b), M, N, K, y.data_ptr(), xt.data_ptr(), st), "syn_linear_and_pack")
+    return y, xt
+
+
+def _lin_bwd(dy2, xb, xt, w, has_bias, scale=None, rows_per_scale=1):
+    """fp32 dy [M][N] (contiguous) -> dx [M][K], dW [N][K], db [N] of y = x W^T + b (dy first multiplied by its rows' factors)."""
+    M, N = dy2.shape
+    K = w.shape[1]
+    dev = dy2.device
+    lib, st = _lib.load(), _lib.current_stream(dev)
+    dyb = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    dybt = torch.empty(N, M, dtype=torch.bfloat16, device=dev)
+    part = torch.empty(M // 64, N, dtype=torch.float32, device=dev) if has_bias else None
+    _lib.check(lib.syn_linear_bwd_prep(dy2.data_ptr(), M, N, _lib.ptr(scale), rows_per_scale, dyb.data_ptr(), dybt.data_ptr(), _lib.ptr(part),
+                                       None, None, st), "syn_linear_bwd_prep")
+    _, wt = _lookup_packs(w)
+    dx = torch.empty(M, K, dtype=torch.float32, device=dev)
+    dw = torch.empty(N, K, dtype=torch.float32, device=dev)
+    in_pair = has_bias and M <= 2048
+    db = torch.empty(N, dtype=torch.float32, device=dev) if in_pair else None
+    _lib.check(lib.syn_linear_pair(dyb.data_ptr(), wt.data_ptr(), M, K, N, dx.data_ptr(), dybt.data_ptr(), xt.data_ptr(), N, K, M, dw.data_ptr(),
+                                   _lib.ptr(part) if in_pair else None, M // 64, N, _lib.ptr(db), st), "syn_linear_pair")
+    if has_bias and db is None:
+        db = part.sum(0)
+    return dx, dw, db
+
+
+def _ln_rows_bf16(hc, g, b):
+    rows = hc.numel() // 512
+    zb = torch.empty(rows, 512, dtype=torch.bfloat16, device=hc.device)
+    mean, rstd = torch.empty(rows, device=hc.device), torch.empty(rows, device=hc.device)
+    _lib.check(_lib.load().syn_ln_fwd(hc.data_ptr(), g.data_ptr(), b.data_ptr(), None, zb.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows,
+                                      _lib.current_stream(hc.device)), "syn_ln_fwd")
+    return zb, mean, rstd
+
+
+def _ln_bwd_rows(dz, hc, g, mean, rstd, add):
+    rows = hc.numel() // 512
+    dh = torch.empty_like(hc)
+    dg, db = torch.empty(512, device=hc.device), torch.empty(512, device=hc.device)
+    scratch = torch.empty((rows + 15) // 16 * 1024, device=hc.device)
+    _lib.check(_lib.load().syn_ln_bwd(dz.data_ptr(), hc.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), add.data_ptr(), dh.data_ptr(),
+                                      dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), rows, _lib.current_stream(hc.device)), "syn_ln_bwd")
+    return dh, dg, db
+
+
+class AttnBranchFn(torch.autograd.Function):
+    """h + factor * proj(attention(qkv(LayerNorm(h)))) for h (B, 32, 512); factor (B, 1, 1) or None."""
+
+    @staticmethod
+    def forward(ctx, h, g, b, wqkv, bqkv, wproj, bproj, factor):
+        hc, gc, bc = _f32c(h), _f32c(g), _f32c(b)
+        B, T, _ = hc.shape
+        zb, mean, rstd = _ln_rows_bf16(hc, gc, bc)
+        qkv, xt1 = _lin_fwd(zb, wqkv, bqkv)
+        ob = torch.empty(B * T, 512, dtype=torch.bfloat16, device=hc.device)
+        _lib.check(_lib.load().syn_attn_fwd(qkv.data_ptr(), None, ob.data_ptr(), B, _lib.current_stream(hc.device)), "syn_attn_fwd")
+        out, xt2 = _lin_fwd(ob, wproj, bproj, hc, factor, T)
+        ctx.save_for_backward(hc, gc, mean, rstd, xt1, qkv, xt2, wqkv, wproj, factor)
+        ctx.bias = (bqkv is not None, bproj is not None)
+        return out.view(B, T, 512)
+
+    @staticmethod
+    def backward(ctx, dout):
+        hc, gc, mean, rstd, xt1, qkv, xt2, wqkv, wproj, factor = ctx.saved_tensors
+        B, T, _ = hc.shape
+        d = _f32c(dout).view(B * T, 512)
+        do, dwp, dbp = _lin_bwd(d, None, xt2, wproj, ctx.bias[1], factor, T)
+        dqkv = torch.empty_like(qkv)
+        _lib.check(_lib.load().syn_attn_bwd(qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), B, _lib.current_stream(d.device)), "syn_attn_bwd")
+        dz, dwq, dbq = _lin_bwd(dqkv, None, xt1, wqkv, ctx.bias[0])
+        dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d)
+        return dh.view(B, T, 512), dg, db, dwq, dbq, dwp, dbp, None
+
+
+class MlpBranchFn(torch.autograd.Function):
+    """h + factor * fc2(GELU(fc1(LayerNorm(h))))."""
+
+    @staticmethod
+    def forward(ctx, h, g, b, w1, b1, w2, b2, factor):
+        hc, gc, bc = _f32c(h), _f32c(g), _f32c(b)
+        B, T, _ = hc.shape
+        zb, mean, rstd = _ln_rows_bf16(hc, gc, bc)
+        pre, xt1 = _lin_fwd(zb, w1, b1)
+        ab = torch.empty(pre.shape, dtype=torch.bfloat16, device=hc.device)
+        _lib.check(_lib.load().syn_gelu_fwd(pre.data_ptr(), None, ab.data_ptr(), pre.numel(), _lib.current_stream(hc.device)), "syn_gelu_fwd")
+        out, xt2 = _lin_fwd(ab, w2, b2, hc, factor, T)
+        ctx.save_for_backward(hc, gc, mean, rstd, xt1, pre, xt2, w1, w2, factor)
+        ctx.bias = (b1 is not None, b2 is not None)
+        return out.view(B, T, 512)
+
+    @staticmethod
+    def backward(ctx, dout):
+        hc, gc, mean, rstd, xt1, pre, xt2, w1, w2, factor = ctx.saved_tensors
+        B, T, _ = hc.shape
+        d = _f32c(dout).view(B * T, 512)
+        da, dw2, db2 = _lin_bwd(d, None, xt2, w2, ctx.bias[1], factor, T)
+        dpre = torch.empty_like(pre)
+        _lib.check(_lib.load().syn_gelu_bwd(pre.data_ptr(), da.data_ptr(), dpre.data_ptr(), pre.numel(), _lib.current_stream(d.device)), "syn_gelu_bwd")
+        dz, dw1, db1 = _lin_bwd(dpre, None, xt1, w1, ctx.bias[0])
+        dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d)
+        return dh.view(B, T, 512), dg, db, dw1, db1, dw2, db2, None
 
 
 def _rotary(m, h):
@@ -669,6 +819,9 @@ def _conv_raw(conv, x):
     raise _unsupported_conv("forward", cin, stride, pad, cout)
 
 
+_tracked: list = []
+
+
 def _conv_bn_act(conv, bn, x, shortcut, act):
     """Training-mode conv -> BatchNorm (batch statistics) [+ shortcut] [-> LeakyReLU] with the fused tail."""
     if bn.momentum is None:
@@ -681,8 +834,8 @@ def _conv_bn_act(conv, bn, x, shortcut, act):
     else:
         z = BnActFn.apply(y, bn.weight, bn.bias, conv.bias, shortcut, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act)
     if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)                       # as nn.BatchNorm1d.forward does in train() mode (checkpoints carry it)
-    return z
+        _tracked.append(bn.num_batches_tracked)              # +1 as nn.BatchNorm1d.forward does in train() mode (checkpoints carry it):
+    return z                                                 # one launch for all of the encoder's counters, at the end of its forward
 
 
 def _conv_bn_eval(conv, bn, x):
@@ -733,8 +886,12 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     # (train.py:90 may have converted the BatchNorms to SyncBatchNorm: `_conv_bn_act` then reduces the statistics over the module's
     # process group - the same kernels, one small all-reduce per BatchNorm and direction)
     a = a.unsqueeze(2).contiguous(memory_format=torch.channels_last)       # (B, C, 1, L), channel innermost
+    _tracked.clear()
     for blk in m.WavEncoder.feat_extractor:
         a = _wav_block(blk, a)
+    if _tracked:
+        torch._foreach_add_(list(_tracked), 1)
+        _tracked.clear()
     a = a.squeeze(2)
     a_feat = a.transpose(1, 2).permute(1, 0, 2)                                  # (128, B, 256)
     w_feat = lin(_embed(m.text_pre_encoder_body, word), m.text_encoder_body).permute(1, 0, 2)
@@ -761,6 +918,12 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
         keep = 1. - drop_path
         dp = h.new_empty(2 * len(m.mytimmblocks), bs, 1, 1).bernoulli_(keep).div_(keep)
     for i, blk in enumerate(m.mytimmblocks):
+        if torch.is_grad_enabled() and _fused_ok(bs * T, blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
+            h = AttnBranchFn.apply(h, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight,
+                                   blk.attn.proj.bias, None if dp is None else dp[2 * i])
+            h = MlpBranchFn.apply(h, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight,
+                                  blk.mlp.fc2.bias, None if dp is None else dp[2 * i + 1])
+            continue
         z, h = HipLnForkFn.apply(h, blk.norm1.weight, blk.norm1.bias)
         o = HipAttentionFn.apply(lin(z, blk.attn.qkv))           # (B, T, 3 x 4 heads x 128) -> (B, T, 512)
         br = lin(o, blk.attn.proj)

@@ -195,6 +195,60 @@ def test_training_block_ops_vs_torch_autograd():
     assert rel_l2(o.detach().cpu(), orf.detach().cpu()) < 1e-5 and rel_l2(gq.cpu(), rq.cpu()) < 1e-5
 
 
+def test_fused_residual_branches_equal_the_op_by_op_composition():
+    """training.AttnBranchFn / MlpBranchFn (a pre-LN residual branch as one autograd node: bf16 rows straight from the LayerNorm /
+    attention / GELU kernels, `x + DropPath factor * (.)` in the last GEMM's epilogue, the factor applied to dy by the backward's prep
+    pass, bias gradients summed by the GEMM-pair launch) against the same branch built from the single ops with PyTorch glue: the
+    same kernels on the same bf16 operands - outputs and all gradients agree to fp32 rounding of the epilogue (1e-6), with and without
+    DropPath factors, at 128 rows (one row tile round) and 1024 (the bench's)."""
+    import torch.nn as nn
+    from syntalker_amd import training
+    dev = "cuda"
+    for B in (4, 32):
+        torch.manual_seed(B)
+        n1, n2 = nn.LayerNorm(512).to(dev), nn.LayerNorm(512).to(dev)
+        qkv, proj = nn.Linear(512, 1536, bias=False).to(dev), nn.Linear(512, 512).to(dev)
+        fc1, fc2 = nn.Linear(512, 1024).to(dev), nn.Linear(1024, 512).to(dev)
+        with torch.no_grad():
+            for ln in (n1, n2):
+                ln.weight.uniform_(0.5, 1.5); ln.bias.normal_(0, 0.2)
+        layers = (qkv, proj, fc1, fc2)
+        params = [p for mod in (n1, n2) + layers for p in mod.parameters()]
+        packs = training.WeightPacks([l.weight for l in layers])
+        packs.refresh()
+        training._packs = packs
+        try:
+            assert training._fused_ok(B * 32, *layers)
+            h0 = torch.randn(B, 32, 512, device=dev)
+            up = torch.randn(B, 32, 512, device=dev)
+            for factors in (None, torch.empty(2, B, 1, 1, device=dev).bernoulli_(0.7).div_(0.7)):
+                f = (None, None) if factors is None else (factors[0], factors[1])
+                res = {}
+                for fused in (True, False):
+                    h = h0.clone().requires_grad_()
+                    if fused:
+                        a = training.AttnBranchFn.apply(h, n1.weight, n1.bias, qkv.weight, qkv.bias, proj.weight, proj.bias, f[0])
+                        out = training.MlpBranchFn.apply(a, n2.weight, n2.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, f[1])
+                    else:
+                        z, r = training.HipLnForkFn.apply(h, n1.weight, n1.bias)
+                        br = training.lin(training.HipAttentionFn.apply(training.lin(z, qkv)), proj)
+                        a = r + br if f[0] is None else torch.addcmul(r, br, f[0])
+                        z, r = training.HipLnForkFn.apply(a, n2.weight, n2.bias)
+                        br = training.lin(training.HipGeluFn.apply(training.lin(z, fc1)), fc2)
+                        out = r + br if f[1] is None else torch.addcmul(r, br, f[1])
+                    res[fused] = [out.detach()] + list(torch.autograd.grad(out, [h] + params, up))
+                names = ["out", "dh"] + [f"{n}.{k}" for n, mod in zip(("n1", "n2", "qkv", "proj", "fc1", "fc2"), (n1, n2) + layers)
+                                         for k, _ in mod.named_parameters()]
+                for name, a_, b_ in zip(names, res[True], res[False]):
+                    assert torch.isfinite(a_).all() and rel_l2(a_.cpu(), b_.cpu()) < 1e-6, (B, factors is not None, name, rel_l2(a_.cpu(), b_.cpu()))
+                if factors is not None:                    # a dropped sample's branch contributes nothing: out == h there
+                    dropped = (factors[0].view(-1) == 0) & (factors[1].view(-1) == 0)
+                    if dropped.any():
+                        assert torch.equal(res[True][0][dropped], h0[dropped])
+        finally:
+            training._packs = None
+
+
 def test_wav_encoder_single_channel():
     """audio_rep variants with one waveform channel (models/denoiser.py:64-67): the first layer has cin = 1."""
     from syntalker_amd import conditioning
