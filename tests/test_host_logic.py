@@ -206,7 +206,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.syn_version() == 4 == _lib.ABI_VERSION
+    assert lib.syn_version() == 5 == _lib.ABI_VERSION
     # struct sizes exactly as the C compiler lays out include/syn_hip.h (gcc, same ABI as hipcc's host side)
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as td:
