@@ -233,8 +233,8 @@ int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* st
  * of the audio encoder's BasicBlock (models/utils/layer.py:171-184) on channels-last fp32 [rows][channels], rows = clips x
  * positions: z = act(gamma (y - mean) rstd + beta [+ shortcut]).  ws: 2 * syn_bn_chunks(rows) * channels floats; stats
  * [2][channels] receives mean / rstd for the backward; run_mean / run_var may be NULL; conv_bias (or NULL): the bias of the
- * convolution that produced y, NOT added to y by the caller - under batch statistics it only shifts the running mean.  Backward: dgamma_dbeta [2][channels],
- * dy, and dshortcut (NULL when there is none) from dz, the saved z and y.  z may be NULL when there was no shortcut (beta then
+ * convolution that produced y, NOT added to y by the caller - under batch statistics it only shifts the running mean.  Backward: dgamma_dbeta [3][channels]
+ * (ABI 5: the third row is written with zeros - the gradient of conv_bias, which the mean subtraction cancels), dy, and dshortcut (NULL when there is none) from dz, the saved z and y.  z may be NULL when there was no shortcut (beta then
  * required): the activation's sign is recomputed from y, which the passes read anyway. */
 int32_t syn_bn_chunks(int64_t rows);
 int syn_bn_act_fwd(const float* y, const float* shortcut, int64_t rows, int32_t channels, const float* gamma, const float* beta, float eps,

@@ -603,6 +603,43 @@ __device__ __forceinline__ void gemm_n128(const GArgs& a, const int bx, const in
 }
 __global__ __launch_bounds__(kThreads) void k_gemm_n128(const GArgs a) { gemm_n128(a, blockIdx.x, blockIdx.y); }
 
+// A handful of rows against a long K (embed_text: 32 clips x 6144 seed values -> 512, models/denoiser.py:100-104): on row tiles this is two
+// workgroups walking 192 k-steps one after the other (78 us).  Here a workgroup owns a 16 x 16 output tile and its 8 waves split K - both operands
+// straight from L2, eight k-steps of loads in flight per wave - and the partial tiles are added in wave order through the LDS (deterministic).
+__global__ __launch_bounds__(kThreads) void k_gemm_skinny(const GArgs a) {
+    __shared__ f32x4 red[8][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lr = lane & 15;
+    const int nf = blockIdx.x, m0 = blockIdx.y * 16, KS = a.K / 32, per = (KS + 7) / 8;
+    const int k0 = wave * per, k1 = min(KS, k0 + per);
+    const int m = m0 + lr;
+    const __bf16* xrow = a.X + (size_t)((m < a.M ? m : 0) % a.x_rows) * a.ldx + 8 * g;
+    const uint4* wq = a.W + (size_t)nf * KS * 64 + lane;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kb = k0; kb < k1; kb += 8) {
+        uint4 wv[8], xv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ks = kb + i < k1 ? kb + i : k0;
+            wv[i] = wq[(size_t)ks * 64];
+            xv[i] = *reinterpret_cast<const uint4*>(xrow + ks * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (kb + i < k1) acc = MFMA16(__builtin_bit_cast(bf16x8, wv[i]), __builtin_bit_cast(bf16x8, m < a.M ? xv[i] : make_uint4(0, 0, 0, 0)), acc);
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && m < a.M) {
+        f32x4 v = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) v = v + red[w][lane];
+        const int n = nf * 16 + g * 4;
+        if (a.bias) v = v + *reinterpret_cast<const f32x4*>(a.bias + n);
+        *reinterpret_cast<f32x4*>(a.Yf + (size_t)m * a.ldyf + n) = v;
+    }
+}
+
 // Two independent plain GEMMs in one launch (grid z picks; x / y sized for the larger): the data-gradient and weight-gradient GEMMs of
 // an nn.Linear's backward are 64 - 128 workgroups each on 256 CUs and do not depend on each other.
 struct GPair { GArgs g[2]; int gx[2], gy[2]; const float* bias_parts; float* bias_grad; int part_rows, part_n; };
@@ -2343,6 +2380,11 @@ static int linear_impl(const void* x_bf16, const void* w_packed, const float* bi
     a.X = (const __bf16*)x_bf16; a.ldx = k; a.x_rows = m_rows; a.W = (const uint4*)w_packed; a.K = k; a.M = m_rows;
     a.bias = bias; a.Yf = y; a.ldyf = n;
     a.res = res; a.rscale = rscale; a.rows_per_scale = rows_per_scale;
+    if (!xt_packed && !res && m_rows <= 64 && k >= 2048 && g_linear_mt == 0 && g_gemm_resident) {       // a few rows, long K: split K over the waves
+        hipLaunchKernelGGL(k_gemm_skinny, dim3(n / 16, (m_rows + 15) / 16), dim3(kThreads), 0, (hipStream_t)stream, a);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : fail("k_gemm_skinny launch", e);
+    }
     if (!xt_packed || m_rows > 2048 || g_linear_mt > 0) {            // no pack, or larger row tiles: the pack is a launch of its own
         // the training step's GEMMs have 512 .. 1536 rows: 16-row tiles give 32 .. 96 x (n / 512) workgroups, twice what 32-row ones do
         const int mt = g_linear_mt > 0 ? g_linear_mt : (m_rows <= 2048 ? 16 : pick_tile(m_rows));

@@ -721,13 +721,13 @@ class BnActFn(torch.autograd.Function):
         rows = n * l
         dzc = dz.contiguous(memory_format=torch.channels_last)
         ws = torch.empty(2 * lib.syn_bn_chunks(rows) * c, device=dz.device, dtype=torch.float32)
-        dgb = torch.empty(2, c, device=dz.device, dtype=torch.float32)
+        dgb = torch.empty(3, c, device=dz.device, dtype=torch.float32)          # [dgamma | dbeta | 0 = the conv bias's gradient]
         dy = torch.empty_like(yc, memory_format=torch.channels_last)
         dsh = torch.empty_like(yc, memory_format=torch.channels_last) if ctx.has_short else None
         _lib.check(lib.syn_bn_act_bwd(dzc.data_ptr(), _lib.ptr(z), yc.data_ptr(), stats.data_ptr(), g.data_ptr(), b.data_ptr(), rows, c, int(ctx.act),
                                       ws.data_ptr(), dgb.data_ptr(), dy.data_ptr(), _lib.ptr(dsh), _lib.current_stream(dz.device)),
                    "syn_bn_act_bwd")
-        dcb = torch.zeros(c, device=dz.device, dtype=torch.float32) if ctx.has_cb else None
+        dcb = dgb[2] if ctx.has_cb else None
         return dy, dgb[0], dgb[1], dcb, dsh, None, None, None, None, None
 
 
@@ -793,14 +793,14 @@ class SyncBnActFn(torch.autograd.Function):
         _lib.check(lib.syn_bn_bwd_sums(dzc.data_ptr(), _lib.ptr(z), yc.data_ptr(), stats.data_ptr(), g.data_ptr(), b.data_ptr(), rows, c, int(ctx.act),
                                        ws.data_ptr(), local.data_ptr(), _lib.current_stream(dz.device)), "syn_bn_bwd_sums")
         total = _all_reduce_sum(local.clone(), ctx.group, (ctx.key, "bwd"))
-        dgb = torch.empty(2, c, device=dz.device, dtype=torch.float32)
+        dgb = torch.empty(3, c, device=dz.device, dtype=torch.float32)          # [dgamma | dbeta | 0 = the conv bias's gradient]
         scratch = torch.empty(2, c, device=dz.device, dtype=torch.float32)
         dy = torch.empty_like(yc, memory_format=torch.channels_last)
         dsh = torch.empty_like(yc, memory_format=torch.channels_last) if ctx.has_short else None
         _lib.check(lib.syn_bn_act_bwd_apply(dzc.data_ptr(), _lib.ptr(z), yc.data_ptr(), stats.data_ptr(), g.data_ptr(), b.data_ptr(), local.data_ptr(),
                                             total.data_ptr(), rows, ctx.rows_total, c, int(ctx.act), dgb.data_ptr(), scratch.data_ptr(), dy.data_ptr(),
                                             _lib.ptr(dsh), _lib.current_stream(dz.device)), "syn_bn_act_bwd_apply")
-        dcb = torch.zeros(c, device=dz.device, dtype=torch.float32) if ctx.has_cb else None
+        dcb = dgb[2] if ctx.has_cb else None
         return dy, dgb[0], dgb[1], dcb, dsh, None, None, None, None, None, None, None
 
 

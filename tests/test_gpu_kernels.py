@@ -38,6 +38,34 @@ def test_gemm_matches_fp32_matmul(lib, mt, m, n, k):
     assert torch.isfinite(y).all()
 
 
+@pytest.mark.parametrize("m,n,k", [(32, 512, 6144), (20, 512, 2048), (64, 1024, 2176), (1024, 512, 512), (1000, 1536, 640), (256, 512, 2304)])
+def test_training_linear_kernels_match_fp32_matmul(lib, m, n, k):
+    """syn_linear's kernels for the training step's shapes - 128-column tiles with the activation block resident in the LDS (row tile by
+    shape), the split-K kernel for a few rows against a long K (embed_text: 32 x 6144), the streaming loop beyond their limits - against
+    an fp32 matmul of the same bf16 operands, ragged row counts included; and the resident kernels bitwise against the streaming loop
+    (same products, same order) where K is not split."""
+    from syntalker_amd import engine
+    g = torch.Generator().manual_seed(m + n + k)
+    xb = _bf(torch.randn(m, k, generator=g)).cuda().contiguous()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    wp = engine.pack_weight(w)
+    want = xb.float() @ _bf(w).float().T + b
+    outs = {}
+    try:
+        for mode in (2, 0):
+            lib.load().syn_debug_gemm_resident(mode)
+            y = torch.full((m, n), float("nan"), device="cuda")
+            lib.check(lib.load().syn_linear(xb.data_ptr(), wp.data_ptr(), b.data_ptr(), m, n, k, y.data_ptr(), lib.current_stream()), "syn_linear")
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all() and rel_l2(y.cpu(), want.cpu()) < 2e-6, (mode, rel_l2(y.cpu(), want.cpu()))
+            outs[mode] = y
+    finally:
+        lib.load().syn_debug_gemm_resident(2)
+    if not (m <= 64 and k >= 2048):
+        assert torch.equal(outs[2], outs[0])
+
+
 def test_gemm_tile_sizes_agree_bitwise(lib):
     """The per-element K-summation order does not depend on the M tile."""
     from syntalker_amd import engine
