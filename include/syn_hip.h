@@ -266,9 +266,11 @@ int syn_embedding_wgrad(const int64_t* ids, const float* dy, int32_t n_pos, int3
  * (NULL to skip; the bias gradient is their sum over the first index).  With colsum [n] (and counters: n / 64 ints, zero before the
  * first use, left zero by every launch) the launch also adds the partial sums up, in row-block order: the bias gradient itself.
  * (ABI 5) row_scale (NULL or one float per rows_per_scale rows): dy is multiplied by its row's factor first - the backward of
- * syn_linear_res's `residual + row_scale * (x W^T + b)`, i.e. of x + DropPath(branch) (timm_transformer/transformer.py:21-38,195-198). */
-int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, const float* row_scale, int32_t rows_per_scale, void* dy_bf16,
-                        void* dy_bf16_t, float* colsum_part, int32_t* counters, float* colsum, void* stream);
+ * syn_linear_res's `residual + row_scale * (x W^T + b)`, i.e. of x + DropPath(branch) (timm_transformer/transformer.py:21-38,195-198).
+ * gelu_pre (NULL or [m_rows][n]): the Linear's output went through nn.GELU() before dy was formed - dy is multiplied by GELU'(gelu_pre) here
+ * (syn_gelu_bwd's arithmetic) instead of by a launch of its own: the backward of syn_linear_gelu. */
+int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, const float* row_scale, int32_t rows_per_scale, const float* gelu_pre,
+                        void* dy_bf16, void* dy_bf16_t, float* colsum_part, int32_t* counters, float* colsum, void* stream);
 /* Attention core (transformer.py:83-104, 4 heads x 128, 32 tokens, no mask, no dropout) on the packed output of the
  * qkv Linear: qkv [n_seq][32][3][4][128] -> o [n_seq][32][512]; backward recomputes the probabilities. */
 /* (ABI 5) o fp32 and / or o_bf16 (either may be NULL), as syn_ln_fwd. */
@@ -420,6 +422,10 @@ int syn_linear_pair(const void* x1_bf16, const void* w1_packed, int32_t m1, int3
  * xt_packed (NULL to skip): as syn_linear_and_pack. */
 int syn_linear_res(const void* x_bf16, const void* w_packed, const float* bias, const float* residual, const float* row_scale,
                    int32_t rows_per_scale, int32_t m_rows, int32_t n, int32_t k, float* y, void* xt_packed, void* stream);
+/* (ABI 5) fc1 of the MLP (transformer.py:117-151) with the GELU behind it in the epilogue: y fp32 [m_rows][n] = x W^T + bias (kept for the
+ * backward) and y_gelu_bf16 = bf16(GELU(y)) (exact erf form), the operand fc2 takes.  xt_packed (NULL to skip): as syn_linear_and_pack. */
+int syn_linear_gelu(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k, float* y, void* y_gelu_bf16,
+                    void* xt_packed, void* stream);
 
 /* ---- single stages, exported for unit tests and bisecting ----------------------------------- */
 /* Y[m][n] = sum_k X[m][k] * W[n][k] (+ bias[n]); X bf16 [m_rows][k], W packed, Y fp32 [m_rows][n]. n % 512 == 0. */

@@ -108,6 +108,15 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// nn.GELU() of the plain epilogue's value as the bf16 operand of the NEXT Linear (fc1 -> GELU -> fc2, transformer.py:117-151): k_gelu_fwd's
+// arithmetic (exact erf form), so the fused MLP branch rounds exactly as the single-op composition does.
+__device__ __forceinline__ void plain_gelu_bf16(const GArgs& a, const f32x4 v, int m, int n) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = 0.5f * v[e] * (1.0f + erff(v[e] * 0.70710678118654752440f));
+    *reinterpret_cast<bf16x4*>(a.Y + (size_t)m * a.ldyf + n) = to_bf16x4(o);
+}
+
 // Main loop: acc[nf][mf] += W-frag(nf) x X-frag(mf) over K (K a multiple of 128).
 //   slot nf not in SWAPMASK: acc[nf][mf][r] = out[m = 16mf + (l&15)][n = 16nf' + 4(l>>4) + r]
 //   slot nf in SWAPMASK    : acc[nf][mf][r] = out[m = 16mf + 4(l>>4) + r][n = 16nf' + (l&15)]
@@ -480,6 +489,7 @@ __device__ __forceinline__ void gemm_body(const GArgs& a, const int bx, const in
                     f32x4 v = acc[nf][mf] + b;
                     if (a.res) v = plain_residual(a, v, m, n);
                     *reinterpret_cast<f32x4*>(a.Yf + (size_t)m * a.ldyf + n) = v;
+                    if (a.Y) plain_gelu_bf16(a, v, m, n);
                 }
             }
         }
@@ -593,6 +603,7 @@ __device__ __forceinline__ void gemm_body_n128(const GArgs& a, const int bx, con
             f32x4 v = acc[0][mf] + b;
             if (a.res) v = plain_residual(a, v, m, n);
             *reinterpret_cast<f32x4*>(a.Yf + (size_t)m * a.ldyf + n) = v;
+            if (a.Y) plain_gelu_bf16(a, v, m, n);
         }
     }
 }
@@ -2370,7 +2381,7 @@ int syn_test_gemm(const void* x_bf16, const void* w_packed, const float* bias, i
 static int g_linear_mt = 0;
 
 static int linear_impl(const void* x_bf16, const void* w_packed, const float* bias, const float* res, const float* rscale, int rows_per_scale,
-                       int32_t m_rows, int32_t n, int32_t k, float* y, void* xt_packed, void* stream, const char* who) {
+                       int32_t m_rows, int32_t n, int32_t k, float* y, void* xt_packed, void* stream, const char* who, void* gelu_bf16 = nullptr) {
     if (!x_bf16 || !w_packed || !y || n % kNT || k % 128 || m_rows <= 0 || (rscale && (!res || rows_per_scale <= 0)))
         return fail_msg("syn_linear*: need n % 512 == 0, k % 128 == 0, m_rows > 0, non-null pointers (a row scale needs the residual and rows_per_scale > 0)");
     if (xt_packed && (m_rows % 32 || k % 16)) return fail_msg("syn_linear_and_pack: the x^T pack needs m_rows % 32 == 0");
@@ -2380,7 +2391,8 @@ static int linear_impl(const void* x_bf16, const void* w_packed, const float* bi
     a.X = (const __bf16*)x_bf16; a.ldx = k; a.x_rows = m_rows; a.W = (const uint4*)w_packed; a.K = k; a.M = m_rows;
     a.bias = bias; a.Yf = y; a.ldyf = n;
     a.res = res; a.rscale = rscale; a.rows_per_scale = rows_per_scale;
-    if (!xt_packed && !res && m_rows <= 64 && k >= 2048 && g_linear_mt == 0 && g_gemm_resident) {       // a few rows, long K: split K over the waves
+    a.Y = (__bf16*)gelu_bf16;
+    if (!xt_packed && !res && !gelu_bf16 && m_rows <= 64 && k >= 2048 && g_linear_mt == 0 && g_gemm_resident) {       // a few rows, long K: split K over the waves
         hipLaunchKernelGGL(k_gemm_skinny, dim3(n / 16, (m_rows + 15) / 16), dim3(kThreads), 0, (hipStream_t)stream, a);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? 0 : fail("k_gemm_skinny launch", e);
@@ -2413,6 +2425,12 @@ int syn_linear_and_pack(const void* x_bf16, const void* w_packed, const float* b
                         void* xt_packed, void* stream) {
     if (!xt_packed) return fail_msg("syn_linear_and_pack: xt_packed is NULL");
     return linear_impl(x_bf16, w_packed, bias, nullptr, nullptr, 0, m_rows, n, k, y, xt_packed, stream, "k_gemm_and_pack launch");
+}
+
+int syn_linear_gelu(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k, float* y, void* y_gelu_bf16,
+                    void* xt_packed, void* stream) {
+    if (!y_gelu_bf16) return fail_msg("syn_linear_gelu: y_gelu_bf16 is NULL (use syn_linear)");
+    return linear_impl(x_bf16, w_packed, bias, nullptr, nullptr, 0, m_rows, n, k, y, xt_packed, stream, "k_gemm (GELU) launch", y_gelu_bf16);
 }
 
 int syn_linear_res(const void* x_bf16, const void* w_packed, const float* bias, const float* residual, const float* row_scale,
@@ -2608,12 +2626,12 @@ int syn_bn_act_bwd_apply(const float* dz, const float* z, const float* y, const 
     return e == hipSuccess ? 0 : fail("syn_bn_act_bwd_apply", e);
 }
 
-int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, const float* row_scale, int32_t rows_per_scale, void* dy_bf16, void* dy_bf16_t,
-                        float* colsum_part, int32_t* counters, float* colsum, void* stream) {
+int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, const float* row_scale, int32_t rows_per_scale, const float* gelu_pre,
+                        void* dy_bf16, void* dy_bf16_t, float* colsum_part, int32_t* counters, float* colsum, void* stream) {
     if (!dy || !dy_bf16 || !dy_bf16_t || m_rows <= 0 || n <= 0 || m_rows % 64 || n % 64 || (row_scale && rows_per_scale <= 0))
         return fail_msg("syn_linear_bwd_prep: need m_rows % 64 == 0, n % 64 == 0 and non-null pointers");
     if (colsum && (!colsum_part || !counters)) return fail_msg("syn_linear_bwd_prep: colsum needs colsum_part and counters");
-    hipLaunchKernelGGL(trn::k_linear_bwd_prep, dim3(n / 64, m_rows / 64), dim3(256), 0, (hipStream_t)stream, dy, m_rows, n, row_scale, rows_per_scale,
+    hipLaunchKernelGGL(trn::k_linear_bwd_prep, dim3(n / 64, m_rows / 64), dim3(256), 0, (hipStream_t)stream, dy, m_rows, n, row_scale, rows_per_scale, gelu_pre,
                        (__bf16*)dy_bf16, (__bf16*)dy_bf16_t, colsum_part, counters, colsum);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_linear_bwd_prep launch", e);

@@ -192,7 +192,7 @@ class HipLinearFn(torch.autograd.Function):
             in_launch = want_db and LINEAR_BWD_PREP > 2 and N // 64 <= 1024
             if in_launch:
                 db = torch.empty(N, dtype=torch.float32, device=dy.device)
-            _lib.check(_lib.load().syn_linear_bwd_prep(dy2.data_ptr(), M, N, None, 0, dyb.data_ptr(), dybt.data_ptr(), _lib.ptr(part),
+            _lib.check(_lib.load().syn_linear_bwd_prep(dy2.data_ptr(), M, N, None, 0, None, dyb.data_ptr(), dybt.data_ptr(), _lib.ptr(part),
                                                        _lib.ptr(_counters(dy.device)) if in_launch else None, _lib.ptr(db) if in_launch else None,
                                                        _lib.current_stream(dy.device)), "syn_linear_bwd_prep")
             if want_db and not in_launch and not (pair and M <= 2048):
@@ -399,11 +399,12 @@ class HipAttentionFn(torch.autograd.Function):
 # these are 7 / 6 autograd nodes per branch with PyTorch glue between them - a bf16 cast in front of every Linear, addcmul for the
 # DropPath factor and its mul in the backward, a sum for every bias gradient, copies where a gradient is not contiguous: ~25 launches
 # of 3-5 us per branch and direction around kernels that run 5-15 us.  As one node the branch is the kernels and nothing else:
-#   forward   LayerNorm -> bf16 rows | GEMM (+ x^T pack) | attention -> bf16 / GELU -> bf16 | GEMM with `x + factor * (.)` in its epilogue
-#   backward  prep (factor * dy -> bf16, bf16^T, bias partials) | GEMM pair (+ bias sum) | attention / GELU backward | prep | GEMM pair |
+#   forward   LayerNorm -> bf16 rows | GEMM (+ x^T pack; fc1: + GELU -> bf16) | attention -> bf16 | GEMM with `x + factor * (.)` in its epilogue
+#   backward  prep (factor * dy -> bf16, bf16^T, bias partials) | GEMM pair (+ bias sum) | attention backward | prep (fc1: x GELU') | GEMM pair |
 #             LayerNorm backward with dy as its addend (the residual path)
 # The fp32 LayerNorm / attention / GELU outputs are never written: the Linear behind each takes bf16 operands and nothing else reads them.
 BLOCK_FUSED = bool(int(_os.environ.get("SYN_TRAIN_BLOCK_FUSED", "1")))
+XX
 
 
 def _fused_ok(M, *layers) -> bool:
@@ -419,7 +420,7 @@ def _fused_ok(M, *layers) -> bool:
     return True
 
 
-def _lin_fwd(xb, w, b, res=None, scale=None, rows_per_scale=1):
+def _lin_fwd(xb, w, b, res=None, scale=None, rows_per_scale=1, gelu_out=None):
     """bf16 rows [M][K] -> fp32 [M][N] = x W^T + b, or res + scale[row // rows_per_scale] * (x W^T + b); also the x^T fragments the
     weight-gradient GEMM will take (packed by the same launch while M <= 2048)."""
     pk, _ = _lookup_packs(w)
@@ -428,7 +429,10 @@ def _lin_fwd(xb, w, b, res=None, scale=None, rows_per_scale=1):
     y = torch.empty(M, N, dtype=torch.float32, device=xb.device)
     xt = torch.empty(K * M * 2, dtype=torch.uint8, device=xb.device)
     lib, st = _lib.load(), _lib.current_stream(xb.device)
-    if res is not None:
+    if gelu_out is not None:                   # fc1: y stays fp32 for the backward, gelu_out receives bf16(GELU(y)) - fc2's operand
+        _lib.check(lib.syn_linear_gelu(xb.data_ptr(), pk.data_ptr(), _lib.ptr(b), M, N, K, y.data_ptr(), gelu_out.data_ptr(), xt.data_ptr(), st),
+                   "syn_linear_gelu")
+    elif res is not None:
         _lib.check(lib.syn_linear_res(xb.data_ptr(), pk.data_ptr(), _lib.ptr(b), res.data_ptr(), _lib.ptr(scale), rows_per_scale, M, N, K,
                                       y.data_ptr(), xt.data_ptr(), st), "syn_linear_res")
     else:
@@ -436,8 +440,9 @@ def _lin_fwd(xb, w, b, res=None, scale=None, rows_per_scale=1):
     return y, xt
 
 
-def _lin_bwd(dy2, xb, xt, w, has_bias, scale=None, rows_per_scale=1):
-    """fp32 dy [M][N] (contiguous) -> dx [M][K], dW [N][K], db [N] of y = x W^T + b (dy first multiplied by its rows' factors)."""
+def _lin_bwd(dy2, xt, w, has_bias, scale=None, rows_per_scale=1, gelu_pre=None):
+    """fp32 dy [M][N] (contiguous) -> dx [M][K], dW [N][K], db [N] of y = x W^T + b; dy is first multiplied by its rows' factors
+    (scale) or by GELU'(gelu_pre) (dy taken behind a GELU of y).  xt: the x^T fragments packed by the forward."""
     M, N = dy2.shape
     K = w.shape[1]
     dev = dy2.device
@@ -445,7 +450,7 @@ def _lin_bwd(dy2, xb, xt, w, has_bias, scale=None, rows_per_scale=1):
     dyb = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     dybt = torch.empty(N, M, dtype=torch.bfloat16, device=dev)
     part = torch.empty(M // 64, N, dtype=torch.float32, device=dev) if has_bias else None
-    _lib.check(lib.syn_linear_bwd_prep(dy2.data_ptr(), M, N, _lib.ptr(scale), rows_per_scale, dyb.data_ptr(), dybt.data_ptr(), _lib.ptr(part),
+    _lib.check(lib.syn_linear_bwd_prep(dy2.data_ptr(), M, N, _lib.ptr(scale), rows_per_scale, _lib.ptr(gelu_pre), dyb.data_ptr(), dybt.data_ptr(), _lib.ptr(part),
                                        None, None, st), "syn_linear_bwd_prep")
     _, wt = _lookup_packs(w)
     dx = torch.empty(M, K, dtype=torch.float32, device=dev)
@@ -499,10 +504,10 @@ class AttnBranchFn(torch.autograd.Function):
         hc, gc, mean, rstd, xt1, qkv, xt2, wqkv, wproj, factor = ctx.saved_tensors
         B, T, _ = hc.shape
         d = _f32c(dout).view(B * T, 512)
-        do, dwp, dbp = _lin_bwd(d, None, xt2, wproj, ctx.bias[1], factor, T)
+        do, dwp, dbp = _lin_bwd(d, xt2, wproj, ctx.bias[1], factor, T)
         dqkv = torch.empty_like(qkv)
         _lib.check(_lib.load().syn_attn_bwd(qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), B, _lib.current_stream(d.device)), "syn_attn_bwd")
-        dz, dwq, dbq = _lin_bwd(dqkv, None, xt1, wqkv, ctx.bias[0])
+        dz, dwq, dbq = _lin_bwd(dqkv, xt1, wqkv, ctx.bias[0])
         dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d)
         return dh.view(B, T, 512), dg, db, dwq, dbq, dwp, dbp, None
 
@@ -515,9 +520,12 @@ class MlpBranchFn(torch.autograd.Function):
         hc, gc, bc = _f32c(h), _f32c(g), _f32c(b)
         B, T, _ = hc.shape
         zb, mean, rstd = _ln_rows_bf16(hc, gc, bc)
-        pre, xt1 = _lin_fwd(zb, w1, b1)
-        ab = torch.empty(pre.shape, dtype=torch.bfloat16, device=hc.device)
-        _lib.check(_lib.load().syn_gelu_fwd(pre.data_ptr(), None, ab.data_ptr(), pre.numel(), _lib.current_stream(hc.device)), "syn_gelu_fwd")
+        ab = torch.empty(B * T, w1.shape[0], dtype=torch.bfloat16, device=hc.device)
+        if GELU_FUSED & 1:
+            pre, xt1 = _lin_fwd(zb, w1, b1, gelu_out=ab)                 # GELU in fc1's epilogue
+        else:
+            pre, xt1 = _lin_fwd(zb, w1, b1)
+            _lib.check(_lib.load().syn_gelu_fwd(pre.data_ptr(), None, ab.data_ptr(), pre.numel(), _lib.current_stream(hc.device)), "syn_gelu_fwd")
         out, xt2 = _lin_fwd(ab, w2, b2, hc, factor, T)
         ctx.save_for_backward(hc, gc, mean, rstd, xt1, pre, xt2, w1, w2, factor)
         ctx.bias = (b1 is not None, b2 is not None)
@@ -528,10 +536,13 @@ class MlpBranchFn(torch.autograd.Function):
         hc, gc, mean, rstd, xt1, pre, xt2, w1, w2, factor = ctx.saved_tensors
         B, T, _ = hc.shape
         d = _f32c(dout).view(B * T, 512)
-        da, dw2, db2 = _lin_bwd(d, None, xt2, w2, ctx.bias[1], factor, T)
-        dpre = torch.empty_like(pre)
-        _lib.check(_lib.load().syn_gelu_bwd(pre.data_ptr(), da.data_ptr(), dpre.data_ptr(), pre.numel(), _lib.current_stream(d.device)), "syn_gelu_bwd")
-        dz, dw1, db1 = _lin_bwd(dpre, None, xt1, w1, ctx.bias[0])
+        da, dw2, db2 = _lin_bwd(d, xt2, w2, ctx.bias[1], factor, T)
+        if GELU_FUSED & 2:
+            dz, dw1, db1 = _lin_bwd(da, xt1, w1, ctx.bias[0], gelu_pre=pre)    # GELU' in the operand pass of fc1's backward
+        else:
+            dpre = torch.empty_like(pre)
+            _lib.check(_lib.load().syn_gelu_bwd(pre.data_ptr(), da.data_ptr(), dpre.data_ptr(), pre.numel(), _lib.current_stream(d.device)), "syn_gelu_bwd")
+            dz, dw1, db1 = _lin_bwd(dpre, xt1, w1, ctx.bias[0])
         dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d)
         return dh.view(B, T, 512), dg, db, dw1, db1, dw2, db2, None
 
