@@ -404,7 +404,8 @@ class HipAttentionFn(torch.autograd.Function):
 #             LayerNorm backward with dy as its addend (the residual path)
 # The fp32 LayerNorm / attention / GELU outputs are never written: the Linear behind each takes bf16 operands and nothing else reads them.
 BLOCK_FUSED = bool(int(_os.environ.get("SYN_TRAIN_BLOCK_FUSED", "1")))
-XX
+GELU_FUSED = int(_os.environ.get("SYN_TRAIN_GELU_FUSED", "1"))         # bit 0: GELU in fc1's epilogue (-0.1 ms per step); bit 1: GELU' in the backward's
+                                                                       # operand pass (same-box A/B: no gain - erf + exp in the transposing pass cost what the launch did)
 
 
 def _fused_ok(M, *layers) -> bool:
