@@ -280,8 +280,12 @@ def run_train(args, rank, local, world, dev, dist):
         with torch.cuda.stream(side):                           # DDP is built on the stream its iterations run on
             net = training.make_ddp(model, local, capturable=graph)
         torch.cuda.current_stream(dev).wait_stream(side)
-    # (fused: the same update as the reference trainer's optim.Adam, one multi-tensor kernel instead of ~10 foreach launches)
-    opt = torch.optim.Adam(net.parameters(), lr=5e-5, betas=(0.5, 0.999), capturable=graph, fused=True)
+    # clip_grad_norm_(0.99) + Adam as the reference trainer runs them, on training.ClipAdam's three kernels (--torch-adam: PyTorch's foreach norm /
+    # multiply + fused multi-tensor Adam, the same update)
+    if args.torch_adam:
+        opt = torch.optim.Adam(net.parameters(), lr=5e-5, betas=(0.5, 0.999), capturable=graph, fused=True)
+    else:
+        opt = training.ClipAdam(net.parameters(), lr=5e-5, betas=(0.5, 0.999), max_norm=0.99)
     if graph:
         g = training.GraphedTrainStep(net, diff, opt, x0, {"y": y}, warmup=11 if world > 1 else 3, stream=side)
         last = {}
@@ -307,7 +311,8 @@ def run_train(args, rank, local, world, dev, dist):
             ev[1].record()
             l.backward()
             ev[2].record()
-            torch.nn.utils.clip_grad_norm_(net.parameters(), 0.99)
+            if args.torch_adam:
+                torch.nn.utils.clip_grad_norm_(net.parameters(), 0.99)
             opt.step()
             ev[3].record()
             torch.cuda.synchronize()
@@ -432,6 +437,7 @@ def main():
     ap.add_argument("--train-graph", action=argparse.BooleanOptionalAction, default=None,
                     help="train mode: replay the whole step (incl. the all-reduces) from one hipGraph; default: on with one GPU (8.4 ms per step "
                          "against 11.9 ms issued from Python, host-bound), off with several (the captured DDP step has only run with one RCCL rank)")
+    ap.add_argument("--torch-adam", action="store_true", help="train mode: torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(fused) instead of training.ClipAdam (A/B)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: exercises rank start-up, rendezvous (gloo), the barrier / max-over-ranks timing and the JSON line on CPU")
     ap.add_argument("--layer-mode", type=int, default=0, help="0 library's choice (whole-step kernel at the bench batch), 4 / 3 pin the whole-step / small-batch kernel, "

@@ -257,6 +257,21 @@ int syn_bn_act_bwd_apply(const float* dz, const float* z, const float* y, const 
                          const double* sums_local, const double* sums_total, int64_t rows, int64_t rows_total, int32_t channels, int32_t act,
                          float* dgamma_dbeta, float* scratch, float* dy, float* dshortcut, void* stream);
 
+/* (ABI 5) The optimizer step of the reference's training loop (diffusion_rvqvae_trainer.py:351-356: clip_grad_norm_(grad_norm), then Adam)
+ * over lists of <= SYN_OPT_MAX fp32 tensors, pointers as kernel arguments (a captured step holds them by value):
+ *   syn_opt_sqnorm    partials[b] = sum of g^2 over workgroup b's 8192-element chunk, b < syn_opt_blocks(list)        (one read of the gradients)
+ *   syn_opt_scalars   *step_dev += 1; scal4 = {clip = min(1, max_norm / (sqrt(sum partials) + 1e-6)) (1 if max_norm <= 0), lr / (1 - beta1^step),
+ *                     1 / sqrt(1 - beta2^step), total norm}; lr read from lr_dev when that is not NULL (a scheduler's device-resident rate)
+ *   syn_opt_adam      g' = clip * g (+ weight_decay * p); m += (1 - beta1)(g' - m); v = beta2 v + (1 - beta2) g'^2;
+ *                     p -= scal4[1] * m / (sqrt(v) * scal4[2] + eps)       (torch.optim.Adam, amsgrad off; the gradients are not rewritten) */
+#define SYN_OPT_MAX 64
+typedef struct syn_opt_list { float* p[SYN_OPT_MAX]; const float* g[SYN_OPT_MAX]; float* m[SYN_OPT_MAX]; float* v[SYN_OPT_MAX];
+                              int32_t numel[SYN_OPT_MAX]; int32_t n; } syn_opt_list;
+int32_t syn_opt_blocks(const syn_opt_list* l);
+int syn_opt_sqnorm(const syn_opt_list* l, float* partials, void* stream);
+int syn_opt_scalars(const float* partials, int32_t n_partials, float max_norm, const float* lr_dev, float lr, float beta1, float beta2, float* step_dev,
+                    float* scal4, void* stream);
+int syn_opt_adam(const syn_opt_list* l, const float* scal4, float beta1, float beta2, float eps, float weight_decay, void* stream);
 /* Gradient of an nn.Embedding table (models/denoiser.py:72, the word embedding in front of text_encoder_body): dw [vocab][dim] =
  * sum over the positions p with ids[p] == v of dy[p][:], added in increasing p (no atomics on the result; every row written).
  * ids int64 [n_pos] (n_pos <= 8192 per call), dy fp32 [n_pos][dim]. */

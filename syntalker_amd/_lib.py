@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SYN_HIP_LIB") or os.path.join(_HERE, "csrc", "libsyn_
 SYN_LAYERS = 8
 ABI_VERSION = 5             # include/syn_hip.h SYN_ABI_VERSION: a library built from other sources is refused at load time
 EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_steps", "syn_denoise_step_profile", "syn_pack_weight", "syn_pack_weight_t", "syn_to_token_major",
-           "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_linear_pair", "syn_linear_and_pack", "syn_linear_res", "syn_linear_gelu", "syn_test_gemm", "syn_test_attention", "syn_test_handoff",
+           "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_linear_pair", "syn_linear_and_pack", "syn_linear_res", "syn_linear_gelu", "syn_opt_blocks", "syn_opt_sqnorm", "syn_opt_scalars", "syn_opt_adam", "syn_test_gemm", "syn_test_attention", "syn_test_handoff",
            "syn_wav_encode", "syn_wav_workspace_bytes", "syn_wav_out_frames", "syn_linear_bwd_prep", "syn_embedding_wgrad", "syn_pack_weights", "syn_bn_chunks", "syn_bn_act_fwd", "syn_bn_act_bwd", "syn_bn_sums", "syn_bn_act_apply", "syn_bn_bwd_sums", "syn_bn_act_bwd_apply", "syn_conv1d_train_fwd", "syn_conv1d_train_fwd_tiles", "syn_conv1d_pack_split", "syn_conv1d_pack_bytes", "syn_conv1d_train_dgrad_strided", "syn_conv1d_train_wgrad", "syn_conv1d_wgrad_shares", "syn_conv1d_first_parts", "syn_conv1d_first_fwd", "syn_conv1d_first_wgrad", "syn_cond_encode",
            "syn_vq_conv1d", "syn_vq_quantize", "syn_vq_quantize_groups", "syn_vq_codes",
            "syn_vq_workspace_bytes", "syn_vq_map2latent", "syn_vq_latent2origin", "syn_vq_forward_decoder",
@@ -43,6 +43,14 @@ class SynStep(C.Structure):
                 ("ws_h", vp), ("ws_xn", vp), ("ws_q", vp), ("ws_k", vp), ("ws_vt", vp), ("ws_o", vp),
                 ("ws_hid", vp), ("ws_hc", vp), ("ws_sync", vp), ("ws_x0v", vp), ("ws_xch", vp),
                 ("x_fragment_order", i32), ("reserved2", i32)]
+
+
+SYN_OPT_MAX = 64
+
+
+class SynOptList(C.Structure):
+    _fields_ = [("p", vp * SYN_OPT_MAX), ("g", vp * SYN_OPT_MAX), ("m", vp * SYN_OPT_MAX), ("v", vp * SYN_OPT_MAX),
+                ("numel", i32 * SYN_OPT_MAX), ("n", i32)]
 
 
 class SynWavConv(C.Structure):
@@ -106,6 +114,12 @@ def load():
     lib.syn_linear_pair.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp, i32, i32, vp, vp]
     lib.syn_linear_res.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
     lib.syn_linear_gelu.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    f32 = C.c_float
+    lib.syn_opt_blocks.argtypes = [C.POINTER(SynOptList)]
+    lib.syn_opt_blocks.restype = i32
+    lib.syn_opt_sqnorm.argtypes = [C.POINTER(SynOptList), vp, vp]
+    lib.syn_opt_scalars.argtypes = [vp, i32, f32, vp, f32, f32, f32, vp, vp, vp]
+    lib.syn_opt_adam.argtypes = [C.POINTER(SynOptList), vp, f32, f32, f32, f32, vp]
     lib.syn_test_gemm.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.syn_test_attention.argtypes = [vp, vp, vp, i32, vp, vp]
     lib.syn_test_handoff.argtypes = [vp, vp, vp, i64, vp, i32, i32, i32, vp]

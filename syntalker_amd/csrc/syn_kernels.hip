@@ -2637,6 +2637,55 @@ int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, const float*
     return e == hipSuccess ? 0 : fail("k_linear_bwd_prep launch", e);
 }
 
+// ---- optimizer step (clip + Adam) over lists of <= 64 tensors ------------------------------------------------------------------------------------
+static int opt_fill(trn::OptList& L, const syn_opt_list* l, const char* who) {
+    static_assert(SYN_OPT_MAX == trn::kOptMax, "include/syn_hip.h: tensors per optimizer list");
+    if (!l || l->n <= 0 || l->n > SYN_OPT_MAX) return fail_msg(who);
+    int blocks = 0;
+    for (int i = 0; i < l->n; ++i) {
+        if (!l->g[i] || l->numel[i] <= 0) return fail_msg(who);
+        L.p[i] = l->p[i]; L.g[i] = l->g[i]; L.m[i] = l->m[i]; L.v[i] = l->v[i]; L.numel[i] = l->numel[i];
+        L.first[i] = blocks;
+        blocks += (l->numel[i] + trn::kOptChunk - 1) / trn::kOptChunk;
+    }
+    L.first[l->n] = blocks; L.n = l->n;
+    return 0;
+}
+
+int32_t syn_opt_blocks(const syn_opt_list* l) {
+    if (!l || l->n <= 0 || l->n > SYN_OPT_MAX) return -1;
+    int blocks = 0;
+    for (int i = 0; i < l->n; ++i) blocks += (l->numel[i] + trn::kOptChunk - 1) / trn::kOptChunk;
+    return blocks;
+}
+
+int syn_opt_sqnorm(const syn_opt_list* l, float* partials, void* stream) {
+    trn::OptList L;
+    if (!partials) return fail_msg("syn_opt_sqnorm: partials is NULL");
+    if (int rc = opt_fill(L, l, "syn_opt_sqnorm: need 1 .. 64 tensors with gradients")) return rc;
+    hipLaunchKernelGGL(trn::k_opt_sqnorm, dim3(L.first[L.n]), dim3(256), 0, (hipStream_t)stream, L, partials);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_opt_sqnorm launch", e);
+}
+
+int syn_opt_scalars(const float* partials, int32_t n_partials, float max_norm, const float* lr_dev, float lr, float beta1, float beta2, float* step_dev,
+                    float* scal4, void* stream) {
+    if ((n_partials > 0 && !partials) || n_partials < 0 || !step_dev || !scal4) return fail_msg("syn_opt_scalars: bad arguments");
+    hipLaunchKernelGGL(trn::k_opt_scalars, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n_partials, max_norm, lr_dev, lr, beta1, beta2, step_dev, scal4);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_opt_scalars launch", e);
+}
+
+int syn_opt_adam(const syn_opt_list* l, const float* scal4, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+    trn::OptList L;
+    if (!scal4) return fail_msg("syn_opt_adam: scal4 is NULL");
+    if (int rc = opt_fill(L, l, "syn_opt_adam: need 1 .. 64 tensors")) return rc;
+    for (int i = 0; i < L.n; ++i) if (!L.p[i] || !L.m[i] || !L.v[i]) return fail_msg("syn_opt_adam: null parameter / moment pointer");
+    hipLaunchKernelGGL(trn::k_opt_adam, dim3(L.first[L.n]), dim3(256), 0, (hipStream_t)stream, L, scal4, beta1, beta2, eps, weight_decay);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_opt_adam launch", e);
+}
+
 int syn_embedding_wgrad(const int64_t* ids, const float* dy, int32_t n_pos, int32_t vocab, int32_t dim, float* dw, void* stream) {
     if (!ids || !dy || !dw || n_pos <= 0 || n_pos > trn::kEmbMaxPos || vocab <= 0 || dim <= 0)
         return fail_msg("syn_embedding_wgrad: bad arguments (at most 8192 positions per call)");

@@ -19,6 +19,8 @@ scale-by-keep (timm_transformer/transformer.py:21-38), h3d Bernoulli(0.3) style 
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -987,13 +989,111 @@ def ddp_bucket_sizes(ddp) -> list[int]:
         return []
 
 
+class ClipAdam(torch.optim.Optimizer):
+    """`clip_grad_norm_(params, max_norm)` + `torch.optim.Adam(params, lr, betas, eps, weight_decay).step()` (the reference's
+    optimizer step, diffusion_rvqvae_trainer.py:351-356 with optimizers/optim_factory.py's Adam) as `2 + 2 n` launches for `64 n` tensors
+    (`syn_opt_sqnorm` / `syn_opt_scalars` / `syn_opt_adam`): the gradients are read twice and never rewritten - the clip factor is applied
+    inside the update - where PyTorch's foreach norm + multiply + fused Adam read them three times and write them once.
+    State layout and `state_dict()` are torch.optim.Adam's ("step" / "exp_avg" / "exp_avg_sq" per parameter; the step count is ONE device
+    tensor per group that every parameter's "step" aliases), so its checkpoints load here and the other way round.  The step count and,
+    when `lr` is a tensor, the learning rate live on the device: the step is capturable in a hipGraph.  `last_norm()` = the total gradient
+    norm of the latest step (what clip_grad_norm_ returns), a device tensor.
+    Differences from the two PyTorch calls: p.grad keeps the UNCLIPPED gradient after the step; amsgrad / maximize are not offered."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=None):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.max_norm = float(max_norm) if max_norm else 0.0
+        self._lists = {}            # (pointers of the tensors with gradients) -> prepared argument lists
+        self._scal = None
+
+    def last_norm(self):
+        return None if self._scal is None else self._scal[0][0, 3]
+
+    def _group_state(self, group, dev):
+        ps = [p for p in group["params"] if p.grad is not None]
+        for p in ps:
+            if p.dtype is not torch.float32 or not p.is_contiguous() or p.grad.dtype is not torch.float32 or not p.grad.is_contiguous() or p.grad.is_sparse:
+                raise _lib.SynHipError("ClipAdam takes contiguous fp32 parameters with dense contiguous fp32 gradients")
+        step = None
+        for p in group["params"]:
+            st = self.state.get(p)
+            if st and "step" in st:
+                step = st["step"] if step is None else step
+        if step is None or not torch.is_tensor(step) or step.device != dev or step.dtype is not torch.float32 or step.dim() != 0:
+            step = torch.tensor(float(step) if step is not None else 0.0, dtype=torch.float32, device=dev)
+        for p in ps:
+            st = self.state[p]
+            if "exp_avg" not in st:
+                st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format), torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["step"] = step                                           # (one count per group; a loaded state_dict's copies are re-aliased here)
+        return ps, step
+
+    def _prepare(self, ps):
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+        ent = self._lists.get(key)
+        if ent is None:
+            if len(self._lists) > 4:
+                self._lists.clear()
+            lib, lists, blocks = _lib.load(), [], []
+            for lo in range(0, len(ps), _lib.SYN_OPT_MAX):
+                L = _lib.SynOptList()
+                chunk = ps[lo:lo + _lib.SYN_OPT_MAX]
+                for i, p in enumerate(chunk):
+                    st = self.state[p]
+                    L.p[i], L.g[i], L.m[i], L.v[i], L.numel[i] = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+                L.n = len(chunk)
+                lists.append(L)
+                blocks.append(int(lib.syn_opt_blocks(C.byref(L))))
+            ent = self._lists[key] = (lists, blocks)
+        return ent
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        groups = []
+        for group in self.param_groups:
+            first = next((p for p in group["params"] if p.grad is not None), None)
+            if first is None:
+                continue
+            engine._require_cuda(first, "parameter")
+            ps, step = self._group_state(group, first.device)
+            groups.append((group, ps, step) + self._prepare(ps))
+        if not groups:
+            return loss
+        dev = groups[0][1][0].device
+        lib, st = _lib.load(), _lib.current_stream(dev)
+        total = sum(sum(b) for *_, b in groups)
+        if self._scal is None or self._scal[0].device != dev or self._scal[1].numel() < total or len(self._scal[0]) < len(groups):
+            self._scal = (torch.zeros(max(len(groups), 1), 4, device=dev), torch.empty(max(total, 1), device=dev))
+        scal, partials = self._scal
+        if self.max_norm > 0:                                           # the norm is over ALL parameters, whatever their group
+            off = 0
+            for _, _, _, lists, blocks in groups:
+                for L, b in zip(lists, blocks):
+                    _lib.check(lib.syn_opt_sqnorm(C.byref(L), partials[off:].data_ptr(), st), "syn_opt_sqnorm")
+                    off += b
+        for gi, (group, ps, step, lists, blocks) in enumerate(groups):
+            lr, (b1, b2) = group["lr"], group["betas"]
+            lr_dev = lr if torch.is_tensor(lr) else None
+            if lr_dev is not None and (lr_dev.device != dev or lr_dev.dtype is not torch.float32):
+                raise _lib.SynHipError("ClipAdam: a tensor learning rate must be an fp32 tensor on the parameters' device")
+            _lib.check(lib.syn_opt_scalars(partials.data_ptr(), total if self.max_norm > 0 else 0, self.max_norm, _lib.ptr(lr_dev),
+                                           0.0 if lr_dev is not None else float(lr), b1, b2, step.data_ptr(), scal[gi].data_ptr(), st), "syn_opt_scalars")
+            for L in lists:
+                _lib.check(lib.syn_opt_adam(C.byref(L), scal[gi].data_ptr(), b1, b2, group["eps"], group["weight_decay"], st), "syn_opt_adam")
+        return loss
+
+
 def train_step(model, diffusion, sampler, optimizer, x0, model_kwargs, grad_norm: float = 0.99):
     """The body of the reference's hot training loop (diffusion_rvqvae_trainer.py:339-356, 555-560)."""
     t, _ = sampler.sample(x0.shape[0], x0.device)
     optimizer.zero_grad(set_to_none=True)
     loss = diffusion.training_losses(model, x0, t, model_kwargs=model_kwargs)["loss"].mean()
     loss.backward()
-    if grad_norm:
+    if grad_norm and not isinstance(optimizer, ClipAdam):           # (ClipAdam carries its max_norm: the clip is part of its step)
         torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm)
     optimizer.step()
     return loss.detach()
@@ -1041,7 +1141,7 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         loss = self.diffusion.training_losses(self.wrapped, self.x0, self.t, model_kwargs={"y": self.y})["loss"].mean()
         loss.backward()
-        if self.grad_norm:
+        if self.grad_norm and not isinstance(self.opt, ClipAdam):
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
         self.opt.step()
         return loss.detach()

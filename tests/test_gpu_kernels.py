@@ -277,6 +277,56 @@ def test_fused_residual_branches_equal_the_op_by_op_composition():
             training._packs = None
 
 
+def test_clip_adam_equals_clip_grad_norm_plus_torch_adam():
+    """training.ClipAdam (syn_opt_sqnorm / syn_opt_scalars / syn_opt_adam) against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam on the
+    same parameters and gradients over five steps: tensors of awkward sizes (1 element, not a multiple of 4, several 8192-element
+    chunks, a misaligned view), 70 tensors (two argument lists), with the clip active and inactive, weight decay, a device-resident
+    learning rate changed between steps; then torch's state_dict loaded into ClipAdam and the other way round."""
+    from syntalker_amd import training
+    dev = "cuda"
+    g = torch.Generator().manual_seed(11)
+    sizes = [(1,), (3,), (5, 7), (8192,), (8193,), (300, 129), (70001,)] + [(17 + i, 3) for i in range(63)]
+    base = [torch.randn(*sz, generator=g) * 0.3 for sz in sizes]
+    flat = torch.randn(1000 + 3, generator=g)
+    for max_norm, wd in ((0.99, 0.0), (1e9, 0.01), (0.05, 0.01)):
+        mine = [torch.nn.Parameter(b.clone().to(dev)) for b in base]
+        ref = [torch.nn.Parameter(b.clone().to(dev)) for b in base]
+        # a parameter whose storage starts 4 bytes off a 16-byte boundary
+        buf_m, buf_r = flat.clone().to(dev), flat.clone().to(dev)
+        mine.append(torch.nn.Parameter(buf_m[1:1001])); ref.append(torch.nn.Parameter(buf_r[1:1001]))
+        lr_m, lr_r = torch.tensor(3e-3, device=dev), torch.tensor(3e-3, device=dev)
+        om = training.ClipAdam(mine, lr=lr_m, betas=(0.5, 0.999), weight_decay=wd, max_norm=max_norm)
+        orf = torch.optim.Adam(ref, lr=lr_r, betas=(0.5, 0.999), weight_decay=wd, capturable=True, foreach=True)
+        for it in range(5):
+            gg = torch.Generator().manual_seed(100 + it)
+            for a, b in zip(mine, ref):
+                gr = torch.randn(a.shape, generator=gg).to(dev) * (10.0 if it == 2 else 0.01)       # (step 2 is far above the clip threshold)
+                a.grad, b.grad = gr.clone(), gr.clone()
+            want_norm = torch.nn.utils.clip_grad_norm_(ref, max_norm)
+            orf.step(); om.step()
+            assert abs(float(om.last_norm()) / float(want_norm) - 1) < 1e-5
+            if it == 2:
+                lr_m.fill_(1e-3); lr_r.fill_(1e-3)
+        torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            assert torch.isfinite(a).all() and rel_l2(a.detach().cpu(), b.detach().cpu()) < 2e-6, (max_norm, wd, i, rel_l2(a.detach().cpu(), b.detach().cpu()))
+            # (the second moment carries the clip factor squared; the factor itself differs in its last bits - the total norm is summed in
+            #  double from 8192-element partial sums here, in fp32 from per-tensor norms there)
+            assert rel_l2(om.state[a]["exp_avg_sq"].cpu(), orf.state[b]["exp_avg_sq"].cpu()) < 5e-5
+        assert float(om.state[mine[0]]["step"]) == 5.0
+    # checkpoints travel both ways (same state layout)
+    sd = orf.state_dict()
+    om2 = training.ClipAdam(mine, lr=1e-3, betas=(0.5, 0.999), max_norm=0.99)
+    om2.load_state_dict(sd)
+    for a in mine:
+        a.grad = torch.ones_like(a) * 1e-3
+    om2.step()
+    assert float(om2.state[mine[0]]["step"]) == 6.0 and om2.state[mine[3]]["step"] is om2.state[mine[0]]["step"]
+    orf2 = torch.optim.Adam(ref, lr=1e-3, betas=(0.5, 0.999), capturable=True, foreach=True)
+    orf2.load_state_dict(om.state_dict())
+    assert float(orf2.state[ref[0]]["step"]) == 5.0
+
+
 def test_wav_encoder_single_channel():
     """audio_rep variants with one waveform channel (models/denoiser.py:64-67): the first layer has cin = 1."""
     from syntalker_amd import conditioning
