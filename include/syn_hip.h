@@ -195,6 +195,11 @@ int syn_conv1d_first_wgrad(const float* x, const float* dy, int32_t n_clips, int
  * syn_conv1d_train_fwd(dy, ..., cin = cout, stride 1, pad 7, ..., cout = cin). */
 int syn_conv1d_pack_split(const float* w, int32_t cout, int32_t cin, int32_t stride, int32_t transposed, void* out_hi, void* out_lo,
                           void* stream);
+/* (ABI 5) Up to SYN_CONV_PACK_MAX syn_conv1d_pack_split calls as ONE launch (requests: a host array, read at call time): the training step packs every
+ * fragment set its convolutions take - forward and data-gradient forms - once per step, the weights only change in optimizer.step(). */
+#define SYN_CONV_PACK_MAX 40
+typedef struct syn_conv_pack_req { const float* w; void* out_hi; void* out_lo; int32_t cout, cin, stride, transposed; } syn_conv_pack_req;
+int syn_conv1d_pack_split_many(const syn_conv_pack_req* reqs, int32_t n_reqs, void* stream);
 /* Bytes of each of syn_conv1d_pack_split's two outputs. */
 int64_t syn_conv1d_pack_bytes(int32_t cout, int32_t cin, int32_t stride, int32_t transposed);
 /* Data gradient of a STRIDED, unpadded Conv1d(k = 15) of the encoder ((cout, stride) = (64, 6), (128, 6), (256, 3)): dx fp32

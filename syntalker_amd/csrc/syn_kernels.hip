@@ -1704,10 +1704,9 @@ __global__ void k_pack_many(const PackJob* __restrict__ jobs) {
 // transposed = 1: the matrix of the data gradient of a stride-1 convolution, n = ci, c = co, tap reversed.
 // transposed = 2: the data gradient of a STRIDED, unpadded convolution read as a stride-1 one from dy (cout channels) to rows of
 // stride * cin channels: W''[n = r cin + ci][i][co] = w[co][ci][(taps - 1 - i) stride + r], taps = kt_stride (the tap count here).
-__global__ void k_conv_pack_split(const float* __restrict__ w, int cout, int cin, int kt_stride, int transposed, int stride,
-                                  uint4* __restrict__ out_hi, uint4* __restrict__ out_lo) {
+__device__ __forceinline__ void conv_pack_split(const float* __restrict__ w, int cout, int cin, int kt_stride, int transposed, int stride,
+                                                uint4* __restrict__ out_hi, uint4* __restrict__ out_lo, const int idx) {
     const int N = transposed == 2 ? stride * cin : (transposed ? cin : cout), C = transposed ? cout : cin, K = kt_stride * C, KS = K / 32;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (N / 16) * KS * 64) return;
     const int lane = idx & 63, f = idx >> 6, ks = f % KS, nf = f / KS;
     const int n = 16 * nf + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
@@ -1727,6 +1726,19 @@ __global__ void k_conv_pack_split(const float* __restrict__ w, int cout, int cin
     }
     out_hi[idx] = __builtin_bit_cast(uint4, h);
     out_lo[idx] = __builtin_bit_cast(uint4, l);
+}
+__global__ void k_conv_pack_split(const float* __restrict__ w, int cout, int cin, int kt_stride, int transposed, int stride,
+                                  uint4* __restrict__ out_hi, uint4* __restrict__ out_lo) {
+    conv_pack_split(w, cout, cin, kt_stride, transposed, stride, out_hi, out_lo, blockIdx.x * blockDim.x + threadIdx.x);
+}
+// every fragment set the training step's convolutions take (forward and data-gradient forms) in ONE launch: the weights only change in
+// optimizer.step(); grid y = job, the jobs travel as kernel arguments
+constexpr int kConvPackMax = 40;
+struct ConvPackJobs { const float* w[kConvPackMax]; uint4* hi[kConvPackMax]; uint4* lo[kConvPackMax]; short cout[kConvPackMax], cin[kConvPackMax];
+                      signed char kts[kConvPackMax], mode[kConvPackMax], stride[kConvPackMax]; };
+__global__ void k_conv_pack_split_many(const ConvPackJobs j) {
+    const int b = blockIdx.y;
+    conv_pack_split(j.w[b], j.cout[b], j.cin[b], j.kts[b], j.mode[b], j.stride[b], j.hi[b], j.lo[b], blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // (B,1536,32) <-> (B,32,1536): 64 channels x 32 frames per block through a padded LDS tile.
@@ -2893,14 +2905,43 @@ static int dgrad_taps(int stride, int cout) {
     return kt;
 }
 
-int syn_conv1d_pack_split(const float* w, int32_t cout, int32_t cin, int32_t stride, int32_t transposed, void* out_hi, void* out_lo,
-                          void* stream) {
-    if (!w || !out_hi || !out_lo || cout % 16 || cin % 16 || stride < 1) return fail_msg("syn_conv1d_pack_split: bad arguments");
-    int kts, N, C, mode = transposed ? 1 : 0;
+// geometry of one pack: taps (padded), kernel mode, fragments x 64; < 0: not a shape the kernels take
+static int conv_pack_geometry(int cout, int cin, int stride, int transposed, int& kts, int& mode) {
+    if (cout % 16 || cin % 16 || stride < 1 || cout <= 0 || cin <= 0) return -1;
+    int N, C;
+    mode = transposed ? 1 : 0;
     if (transposed && stride > 1) { mode = 2; kts = dgrad_taps(stride, cout); N = stride * cin; C = cout; }
     else { kts = (15 + stride - 1) / stride * stride; N = transposed ? cin : cout; C = transposed ? cout : cin; }
-    if ((kts * C) % 32) return fail_msg("syn_conv1d_pack_split: taps x channels must be a multiple of 32");
-    const int total = (N / 16) * (kts * C / 32) * 64;
+    if ((kts * C) % 32) return -1;
+    return (N / 16) * (kts * C / 32) * 64;
+}
+
+int syn_conv1d_pack_split_many(const syn_conv_pack_req* reqs, int32_t n_reqs, void* stream) {
+    static_assert(SYN_CONV_PACK_MAX == kConvPackMax, "include/syn_hip.h: packs per launch");
+    if (!reqs || n_reqs <= 0 || n_reqs > kConvPackMax) return fail_msg("syn_conv1d_pack_split_many: 1 .. 40 requests");
+    ConvPackJobs j;
+    memset(&j, 0, sizeof(j));
+    int most = 0;
+    for (int i = 0; i < n_reqs; ++i) {
+        const syn_conv_pack_req& r = reqs[i];
+        int kts, mode;
+        const int total = (r.w && r.out_hi && r.out_lo) ? conv_pack_geometry(r.cout, r.cin, r.stride, r.transposed, kts, mode) : -1;
+        if (total < 0) return fail_msg("syn_conv1d_pack_split_many: bad request (as syn_conv1d_pack_split)");
+        j.w[i] = r.w; j.hi[i] = (uint4*)r.out_hi; j.lo[i] = (uint4*)r.out_lo; j.cout[i] = (short)r.cout; j.cin[i] = (short)r.cin;
+        j.kts[i] = (signed char)kts; j.mode[i] = (signed char)mode; j.stride[i] = (signed char)r.stride;
+        most = total > most ? total : most;
+    }
+    hipLaunchKernelGGL(k_conv_pack_split_many, dim3((most + 255) / 256, n_reqs), dim3(256), 0, (hipStream_t)stream, j);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv_pack_split_many launch", e);
+}
+
+int syn_conv1d_pack_split(const float* w, int32_t cout, int32_t cin, int32_t stride, int32_t transposed, void* out_hi, void* out_lo,
+                          void* stream) {
+    if (!w || !out_hi || !out_lo) return fail_msg("syn_conv1d_pack_split: bad arguments");
+    int kts, mode;
+    const int total = conv_pack_geometry(cout, cin, stride, transposed, kts, mode);
+    if (total < 0) return fail_msg("syn_conv1d_pack_split: channels must be multiples of 16 and taps x channels a multiple of 32");
     hipLaunchKernelGGL(k_conv_pack_split, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, cout, cin, kts, mode, stride,
                        (uint4*)out_hi, (uint4*)out_lo);
     hipError_t e = hipGetLastError();

@@ -562,6 +562,59 @@ def _rotary(m, h):
     return g.reshape(B, 8, T, -1).permute(0, 2, 1, 3).reshape(B, T, -1)
 
 
+class ConvPacks:
+    """The hi / lo bf16 fragment sets of the audio encoder's Conv1d(k = 15) layers - the forward form of every layer and the
+    data-gradient form of every layer but the first of the chain - packed in ONE launch per training forward
+    (`syn_conv1d_pack_split_many`) instead of one launch per use (28 per step): the weights only change in optimizer.step().
+    `ConvSplitFn` looks a weight up by storage address and in-place version; a miss takes the per-call pack."""
+
+    def __init__(self, convs):
+        lib = _lib.load()
+        self.items, reqs, self.keep = {}, [], []
+        for conv in convs:
+            w = conv.weight
+            cout, cin, stride = conv.out_channels, conv.in_channels, conv.stride[0]
+            if not (w.is_cuda and w.dtype is torch.float32 and w.is_contiguous() and (cin, stride, cout) in ConvSplitFn.SUPPORTED):
+                continue
+            ent = {"ref": __import__("weakref").ref(w), "ptr": w.data_ptr(), "version": -1}
+            for transposed in (0, 1):
+                nb = lib.syn_conv1d_pack_bytes(cout, cin, stride, transposed)
+                hi, lo = torch.empty(nb, dtype=torch.uint8, device=w.device), torch.empty(nb, dtype=torch.uint8, device=w.device)
+                ent[transposed] = (hi, lo)
+                reqs.append((w.data_ptr(), hi.data_ptr(), lo.data_ptr(), cout, cin, stride, transposed))
+            self.items[w.data_ptr()] = ent
+        self.lists = []
+        for lo in range(0, len(reqs), _lib.SYN_CONV_PACK_MAX):
+            chunk = reqs[lo:lo + _lib.SYN_CONV_PACK_MAX]
+            arr = (_lib.SynConvPackReq * len(chunk))(*[_lib.SynConvPackReq(*r) for r in chunk])
+            self.lists.append(arr)
+        self.device = next((e["ref"]().device for e in self.items.values()), None)
+
+    def valid(self) -> bool:
+        return all(e["ref"]() is not None and e["ref"]().data_ptr() == e["ptr"] for e in self.items.values())
+
+    def refresh(self):
+        for arr in self.lists:
+            _lib.check(_lib.load().syn_conv1d_pack_split_many(C.cast(arr, C.c_void_p), len(arr), _lib.current_stream(self.device)),
+                       "syn_conv1d_pack_split_many")
+        for e in self.items.values():
+            e["version"] = e["ref"]()._version
+
+    def lookup(self, w, transposed):
+        e = self.items.get(w.data_ptr())
+        if e is None or e["ref"]() is None or e["version"] != w._version or e["ptr"] != e["ref"]().data_ptr():
+            return None
+        return e[int(bool(transposed))]
+
+
+CONV_PACKS = bool(int(_os.environ.get("SYN_CONV_PACKS", "1")))        # (A/B: 0 = one pack launch per use)
+_conv_packs: "ConvPacks | None" = None
+
+
+def _lookup_conv_pack(w, transposed):
+    return _conv_packs.lookup(w, transposed) if (_conv_packs is not None and WEIGHT_PACKS and CONV_PACKS) else None
+
+
 def _unsupported_conv(what, cin, stride, pad, cout):
     return _lib.SynHipError(f"{what}: no hand-written kernel covers Conv1d({cin} -> {cout}, k 15, stride {stride}, padding {pad}) of the audio "
                             "encoder (covered: the reference's WavEncoder, models/denoiser.py:304-322); there is no library fallback")
@@ -587,11 +640,15 @@ class ConvSplitFn(torch.autograd.Function):
         cin, cout = (co_w, ci_w) if transposed else (ci_w, co_w)
         assert cx == cin, (x.shape, w.shape, transposed)
         xc = x.contiguous(memory_format=torch.channels_last)                # physically [n][l][cin]
-        kts = -(-15 // stride) * stride
-        whi = torch.empty(cout * kts * cin * 2, dtype=torch.uint8, device=x.device)
-        wlo = torch.empty_like(whi)
-        _lib.check(lib.syn_conv1d_pack_split(wc.data_ptr(), co_w, ci_w, stride, int(transposed), whi.data_ptr(), wlo.data_ptr(),
-                                             _lib.current_stream(x.device)), "syn_conv1d_pack_split")
+        pk = _lookup_conv_pack(w, transposed)
+        if pk is not None:
+            whi, wlo = pk
+        else:
+            kts = -(-15 // stride) * stride
+            whi = torch.empty(cout * kts * cin * 2, dtype=torch.uint8, device=x.device)
+            wlo = torch.empty_like(whi)
+            _lib.check(lib.syn_conv1d_pack_split(wc.data_ptr(), co_w, ci_w, stride, int(transposed), whi.data_ptr(), wlo.data_ptr(),
+                                                 _lib.current_stream(x.device)), "syn_conv1d_pack_split")
         l_out = (l_in + 2 * pad - 15) // stride + 1
         y = torch.empty(n, cout, 1, l_out, device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         part = None
@@ -629,12 +686,16 @@ class ConvSplitFn(torch.autograd.Function):
                 # positions x cin channels (three 128-column launches of the forward kernel)
                 lib = _lib.load()
                 n, _, _, l_in = x.shape
-                wc = w.detach().float().contiguous()
-                nb = lib.syn_conv1d_pack_bytes(cout, cin, stride, 1)
-                whi = torch.empty(nb, dtype=torch.uint8, device=x.device)
-                wlo = torch.empty_like(whi)
-                _lib.check(lib.syn_conv1d_pack_split(wc.data_ptr(), cout, cin, stride, 1, whi.data_ptr(), wlo.data_ptr(),
-                                                     _lib.current_stream(x.device)), "syn_conv1d_pack_split")
+                pk = _lookup_conv_pack(w, True)
+                if pk is not None:
+                    whi, wlo = pk
+                else:
+                    wc = w.detach().float().contiguous()
+                    nb = lib.syn_conv1d_pack_bytes(cout, cin, stride, 1)
+                    whi = torch.empty(nb, dtype=torch.uint8, device=x.device)
+                    wlo = torch.empty_like(whi)
+                    _lib.check(lib.syn_conv1d_pack_split(wc.data_ptr(), cout, cin, stride, 1, whi.data_ptr(), wlo.data_ptr(),
+                                                         _lib.current_stream(x.device)), "syn_conv1d_pack_split")
                 gx = torch.empty(n, cin, 1, l_in, device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
                 _lib.check(lib.syn_conv1d_train_dgrad_strided(gy.data_ptr(), n, l_in, cin, stride, cout, whi.data_ptr(), wlo.data_ptr(),
                                                               gx.data_ptr(), _lib.current_stream(x.device)), "syn_conv1d_train_dgrad_strided")
@@ -888,6 +949,16 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
             pk.owner = __import__("weakref").ref(m)
         pk.refresh()
         _packs = pk
+        global _conv_packs
+        cp = m.__dict__.get("_syn_conv_packs")
+        if training and (cp is None or cp.owner() is not m or not cp.valid()):
+            cp = m.__dict__["_syn_conv_packs"] = ConvPacks([mod for mod in m.WavEncoder.modules() if isinstance(mod, nn.Conv1d)])
+            cp.owner = __import__("weakref").ref(m)
+        if training and cp.lists:
+            cp.refresh()
+            _conv_packs = cp
+        else:
+            _conv_packs = None
     h3d = m.variant == "h3d"
     te = m.embed_timestep
     e = te.sequence_pos_encoder.pe[timesteps]                                   # (B,1,512)
