@@ -1832,14 +1832,14 @@ int device_cus();
 constexpr int kN128Lds = 128 * 1024;
 // Row tile of the 128-column plain GEMM: the largest of 64 / 32 / 16 that still gives every CU a workgroup (fewer bytes through each CU's L1
 // port: a workgroup pulls (MT + 128) x K x 2) and whose activation block fits the LDS; 0 = the shape does not fit this kernel at all.
-int pick_mt128(int M, int N, int K) {
+int pick_mt128(int M, int N, int K, int chip_parts = 1) {            // chip_parts 2: the GEMM shares the launch (and the chip) with another one
     if (K * 32 > kN128Lds) return 0;
     static int g_force = -1;
     if (g_force < 0) { const char* e = getenv("SYN_GEMM_MT128"); g_force = e ? atoi(e) : 0; }
     if (g_force && g_force * K * 2 <= kN128Lds) return g_force;
     const int cus = device_cus();
     for (int mt = 64; mt > 16; mt >>= 1)
-        if (mt * K * 2 <= kN128Lds && ((M + mt - 1) / mt) * (N / 128) >= cus * 3 / 4) return mt;
+        if (mt * K * 2 <= kN128Lds && ((M + mt - 1) / mt) * (N / 128) >= cus * 3 / (4 * chip_parts)) return mt;
     return 16;
 }
 void n128_setup();
@@ -2478,7 +2478,7 @@ int syn_linear_pair(const void* x1_bf16, const void* w1_packed, int32_t m1, int3
     const bool n128 = g_gemm_resident == 2 && pick_mt128(m1, n1, k1) && pick_mt128(m2, n2, k2);
     if (n128)                                                                  // 128-column tiles, the row tile per shape (half a chip each)
         for (int i = 0; i < 2; ++i) {
-            const int mt = pick_mt128(ms[i] * 2, ns[i], ks[i]);
+            const int mt = pick_mt128(ms[i], ns[i], ks[i], 2);
             p.g[i].mt128 = mt; p.gx[i] = (ms[i] + mt - 1) / mt; p.gy[i] = ns[i] / 128;
             lds128 = mt * ks[i] * 2 > lds128 ? mt * ks[i] * 2 : lds128;
         }

@@ -1100,7 +1100,8 @@ class ClipAdam(torch.optim.Optimizer):
         return ps, step
 
     def _prepare(self, ps):
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+        # (every pointer a prepared list holds is part of its key: load_state_dict replaces the moment tensors, backward the gradients)
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in ps)
         ent = self._lists.get(key)
         if ent is None:
             if len(self._lists) > 4:

@@ -322,6 +322,14 @@ def test_clip_adam_equals_clip_grad_norm_plus_torch_adam():
         a.grad = torch.ones_like(a) * 1e-3
     om2.step()
     assert float(om2.state[mine[0]]["step"]) == 6.0 and om2.state[mine[3]]["step"] is om2.state[mine[0]]["step"]
+    # a second load replaces the moment tensors under an optimizer that has already stepped: the next step must write the NEW ones
+    om2.load_state_dict(sd)
+    before = om2.state[mine[5]]["exp_avg"].clone()
+    for a in mine:
+        a.grad = torch.ones_like(a)
+    om2.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(om2.state[mine[5]]["exp_avg"], before) and float(om2.state[mine[0]]["step"]) == 6.0
     orf2 = torch.optim.Adam(ref, lr=1e-3, betas=(0.5, 0.999), capturable=True, foreach=True)
     orf2.load_state_dict(om.state_dict())
     assert float(orf2.state[ref[0]]["step"]) == 5.0
