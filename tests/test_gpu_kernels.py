@@ -315,15 +315,16 @@ def test_clip_adam_equals_clip_grad_norm_plus_torch_adam():
             assert rel_l2(om.state[a]["exp_avg_sq"].cpu(), orf.state[b]["exp_avg_sq"].cpu()) < 5e-5
         assert float(om.state[mine[0]]["step"]) == 5.0
     # checkpoints travel both ways (same state layout)
+    import copy
     sd = orf.state_dict()
     om2 = training.ClipAdam(mine, lr=1e-3, betas=(0.5, 0.999), max_norm=0.99)
-    om2.load_state_dict(sd)
+    om2.load_state_dict(copy.deepcopy(sd))             # (Optimizer.load_state_dict keeps same-dtype tensors by reference)
     for a in mine:
         a.grad = torch.ones_like(a) * 1e-3
     om2.step()
     assert float(om2.state[mine[0]]["step"]) == 6.0 and om2.state[mine[3]]["step"] is om2.state[mine[0]]["step"]
     # a second load replaces the moment tensors under an optimizer that has already stepped: the next step must write the NEW ones
-    om2.load_state_dict(sd)
+    om2.load_state_dict(copy.deepcopy(sd))
     before = om2.state[mine[5]]["exp_avg"].clone()
     for a in mine:
         a.grad = torch.ones_like(a)
