@@ -10,7 +10,7 @@ from syntalker_amd.resample import create_named_schedule_sampler
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 m = synth.synth_fill_(MDM(synth.default_args()).train(), 0).cuda()
 d = create_gaussian_diffusion(); s = create_named_schedule_sampler("uniform", d)
-opt = torch.optim.Adam(m.parameters(), lr=5e-5, betas=(0.5, 0.999), fused=True)
+opt = training.ClipAdam(m.parameters(), lr=5e-5, betas=(0.5, 0.999), max_norm=0.99)          # (what bench.py --mode train runs)
 y = synth.to_device(synth.synth_clip_inputs(B, seed=1, mask_batch=B), 'cuda')
 y["audio"] = torch.randn(B, 68266, 2, device='cuda')
 x0 = synth.synth_latent(B, seed=1, name="x0").cuda()
