@@ -90,11 +90,8 @@ def main(argv=None) -> dict:
             t0, losses = time.time(), []
             for x0, y in it:
                 if a.graph:
-                    if step_fn is None:
-                        opt = torch.optim.Adam(net.parameters(), lr=torch.tensor(float(t.opt.param_groups[0]["lr"]), device=dev),   # (a device tensor: the captured step reads it)
-                                               betas=t.opt.param_groups[0]["betas"], capturable=True, fused=True)
-                        t.opt = opt
-                        step_fn = training.GraphedTrainStep(net, t.diffusion, opt, x0, {"y": y}, grad_norm=t.grad_norm, warmup=11 if world > 1 else 3)
+                    if step_fn is None:                 # (config.build_trainer's ClipAdam keeps its rate and step count on the device: capturable as it is)
+                        step_fn = training.GraphedTrainStep(net, t.diffusion, t.opt, x0, {"y": y}, grad_norm=t.grad_norm, warmup=11 if world > 1 else 3)
                     losses.append(step_fn(x0, t.schedule_sampler.sample(B, dev)[0], {"y": y}))
                 else:
                     losses.append(training.train_step(net, t.diffusion, t.schedule_sampler, t.opt, x0, {"y": y}, grad_norm=t.grad_norm))

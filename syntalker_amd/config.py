@@ -124,7 +124,14 @@ def build_trainer(args, device="cuda", model_cls=None):
         raise NotImplementedError("only opt == 'adam' (utils/config.py:207, every diffusion_*.yaml) is implemented")
     diffusion = create_gaussian_diffusion()
     betas = tuple(getattr(args, "opt_betas", (0.5, 0.999)))
-    opt = torch.optim.Adam(model.parameters(), lr=step_lr(args, 0), betas=betas, weight_decay=float(getattr(args, "weight_decay", 0.0)),
-                           fused=torch.device(device).type == "cuda")
+    grad_norm, wd = float(getattr(args, "grad_norm", 0.99)), float(getattr(args, "weight_decay", 0.0))
+    if torch.device(device).type == "cuda":
+        # clip_grad_norm_(grad_norm) + Adam as one optimizer step on the hand-written kernels; the rate is a device tensor, so the same
+        # optimizer serves the eager loop and the captured step (the per-epoch scheduler writes it in place)
+        from .training import ClipAdam
+        opt = ClipAdam(model.parameters(), lr=torch.tensor(step_lr(args, 0), dtype=torch.float32, device=device), betas=betas, weight_decay=wd,
+                       max_norm=grad_norm)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=step_lr(args, 0), betas=betas, weight_decay=wd)
     return SimpleNamespace(model=model, diffusion=diffusion, schedule_sampler=create_named_schedule_sampler("uniform", diffusion), opt=opt,
                            grad_norm=float(getattr(args, "grad_norm", 0.99)), latent_scale=float(getattr(args, "vqvae_latent_scale", 5)))

@@ -99,6 +99,15 @@ def test_train_from_config_driver(tmp_path, which):
     sd2 = torch.load(rep2["saved"][0], map_location="cpu")["model_state"]
     assert int(sd2["WavEncoder.feat_extractor.0.bn1.num_batches_tracked"]) == 5   # continued from the loaded state
     assert not torch.equal(sd2["mytimmblocks.0.attn.qkv.weight"], sd["mytimmblocks.0.attn.qkv.weight"])
+    if which == "beatx":
+        # the same loop with the whole step replayed from one hipGraph: config.build_trainer's ClipAdam is captured as it is (rate and step
+        # count on the device), the per-epoch StepLR writes the rate the replays read
+        rep3 = drv.main([str(tmp_path / "cfg.yaml"), "--epochs", "2", "--steps-per-epoch", "3", "--batch-size", "4", "--random-init", "--graph", "--out", out + "3"])
+        assert [e["lr"] for e in rep3["log"]] == pytest.approx([5e-5, 5e-6]) and all(e["loss"] == e["loss"] and e["steps"] == 3 for e in rep3["log"])
+        sd3 = torch.load(rep3["saved"][1], map_location="cpu")["model_state"]
+        assert torch.isfinite(sd3["mytimmblocks.0.attn.qkv.weight"]).all()
+        # (the captured step's 3 eager warm-up iterations run the forward too, the capture itself executes nothing: 3 + 6 replays)
+        assert int(sd3["WavEncoder.feat_extractor.0.bn1.num_batches_tracked"]) == 9
 
 
 @pytest.mark.gpu
