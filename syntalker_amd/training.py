@@ -426,7 +426,7 @@ def _fused_ok(M, *layers) -> bool:
 def _lin_fwd(xb, w, b, res=None, scale=None, rows_per_scale=1, gelu_out=None):
     """bf16 rows [M][K] -> fp32 [M][N] = x W^T + b, or res + scale[row // rows_per_scale] * (x W^T + b); also the x^T fragments the
     weight-gradient GEMM will take (packed by the same launch while M <= 2048)."""
-    pk, _ = _lookup_packs(w)
+    pk, wt = _lookup_packs(w)
     M, K = xb.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=torch.float32, device=xb.device)
@@ -440,12 +440,13 @@ def _lin_fwd(xb, w, b, res=None, scale=None, rows_per_scale=1, gelu_out=None):
                                       y.data_ptr(), xt.data_ptr(), st), "syn_linear_res")
     else:
         _lib.check(lib.syn_linear_and_pack(xb.data_ptr(), pk.data_ptr(), _lib.ptr(b), M, N, K, y.data_ptr(), xt.data_ptr(), st), "syn_linear_and_pack")
-    return y, xt
+    return y, (xt, wt)          # what the backward takes: x^T and W^T fragments as of THIS forward (the step's pack cache may have moved on by then)
 
 
-def _lin_bwd(dy2, xt, w, has_bias, scale=None, rows_per_scale=1, gelu_pre=None):
+def _lin_bwd(dy2, packs, w, has_bias, scale=None, rows_per_scale=1, gelu_pre=None):
     """fp32 dy [M][N] (contiguous) -> dx [M][K], dW [N][K], db [N] of y = x W^T + b; dy is first multiplied by its rows' factors
-    (scale) or by GELU'(gelu_pre) (dy taken behind a GELU of y).  xt: the x^T fragments packed by the forward."""
+    (scale) or by GELU'(gelu_pre) (dy taken behind a GELU of y).  packs: (x^T fragments, W^T fragments) from `_lin_fwd`."""
+    xt, wt = packs
     M, N = dy2.shape
     K = w.shape[1]
     dev = dy2.device
@@ -455,7 +456,6 @@ def _lin_bwd(dy2, xt, w, has_bias, scale=None, rows_per_scale=1, gelu_pre=None):
     part = torch.empty(M // 64, N, dtype=torch.float32, device=dev) if has_bias else None
     _lib.check(lib.syn_linear_bwd_prep(dy2.data_ptr(), M, N, _lib.ptr(scale), rows_per_scale, _lib.ptr(gelu_pre), dyb.data_ptr(), dybt.data_ptr(), _lib.ptr(part),
                                        None, None, st), "syn_linear_bwd_prep")
-    _, wt = _lookup_packs(w)
     dx = torch.empty(M, K, dtype=torch.float32, device=dev)
     dw = torch.empty(N, K, dtype=torch.float32, device=dev)
     in_pair = has_bias and M <= 2048
@@ -498,13 +498,15 @@ class AttnBranchFn(torch.autograd.Function):
         ob = torch.empty(B * T, 512, dtype=torch.bfloat16, device=hc.device)
         _lib.check(_lib.load().syn_attn_fwd(qkv.data_ptr(), None, ob.data_ptr(), B, _lib.current_stream(hc.device)), "syn_attn_fwd")
         out, xt2 = _lin_fwd(ob, wproj, bproj, hc, factor, T)
-        ctx.save_for_backward(hc, gc, mean, rstd, xt1, qkv, xt2, wqkv, wproj, factor)
+        ctx.save_for_backward(hc, gc, mean, rstd, qkv, wqkv, wproj, factor)
+        ctx.packs = (xt1, xt2)
         ctx.bias = (bqkv is not None, bproj is not None)
         return out.view(B, T, 512)
 
     @staticmethod
     def backward(ctx, dout):
-        hc, gc, mean, rstd, xt1, qkv, xt2, wqkv, wproj, factor = ctx.saved_tensors
+        hc, gc, mean, rstd, qkv, wqkv, wproj, factor = ctx.saved_tensors
+        xt1, xt2 = ctx.packs
         B, T, _ = hc.shape
         d = _f32c(dout).view(B * T, 512)
         do, dwp, dbp = _lin_bwd(d, xt2, wproj, ctx.bias[1], factor, T)
@@ -530,13 +532,15 @@ class MlpBranchFn(torch.autograd.Function):
             pre, xt1 = _lin_fwd(zb, w1, b1)
             _lib.check(_lib.load().syn_gelu_fwd(pre.data_ptr(), None, ab.data_ptr(), pre.numel(), _lib.current_stream(hc.device)), "syn_gelu_fwd")
         out, xt2 = _lin_fwd(ab, w2, b2, hc, factor, T)
-        ctx.save_for_backward(hc, gc, mean, rstd, xt1, pre, xt2, w1, w2, factor)
+        ctx.save_for_backward(hc, gc, mean, rstd, pre, w1, w2, factor)
+        ctx.packs = (xt1, xt2)
         ctx.bias = (b1 is not None, b2 is not None)
         return out.view(B, T, 512)
 
     @staticmethod
     def backward(ctx, dout):
-        hc, gc, mean, rstd, xt1, pre, xt2, w1, w2, factor = ctx.saved_tensors
+        hc, gc, mean, rstd, pre, w1, w2, factor = ctx.saved_tensors
+        xt1, xt2 = ctx.packs
         B, T, _ = hc.shape
         d = _f32c(dout).view(B * T, 512)
         da, dw2, db2 = _lin_bwd(d, xt2, w2, ctx.bias[1], factor, T)
