@@ -66,6 +66,78 @@ def test_training_linear_kernels_match_fp32_matmul(lib, m, n, k):
         assert torch.equal(outs[2], outs[0])
 
 
+@pytest.mark.parametrize("m,n,k,rps", [(1024, 512, 1024, 32), (1000, 512, 640, 8), (96, 1024, 4224, 32), (2304, 512, 512, 64)])
+def test_linear_epilogues_residual_droppath_and_gelu(lib, m, n, k, rps):
+    """syn_linear_res (residual + per-sample factor * (x W^T + b), the tail of a pre-LN branch) and syn_linear_gelu (fp32 pre-activation + bf16
+    GELU) against fp32 torch on the same bf16 operands, on every kernel the shapes select: 128-column resident tiles (row tile 64 / 16), the
+    streaming loop (K too long for the LDS) and the large-row-tile path (m > 2048, the x^T pack as a launch of its own)."""
+    import torch.nn.functional as F
+    from syntalker_amd import engine
+    g = torch.Generator().manual_seed(m + n + k)
+    xb = _bf(torch.randn(m, k, generator=g)).cuda().contiguous()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    res = torch.randn(m, n, generator=g).cuda()
+    fac = (torch.rand((m + rps - 1) // rps, generator=g) < 0.8).float().div(0.8).cuda()
+    wp = engine.pack_weight(w)
+    lin = xb.float() @ _bf(w).float().T + b
+    L, st = lib.load(), lib.current_stream()
+    pack = m % 32 == 0 and k % 16 == 0
+    xt = torch.empty(k * m * 2, dtype=torch.uint8, device="cuda") if pack else None
+    y = torch.full((m, n), float("nan"), device="cuda")
+    lib.check(L.syn_linear_res(xb.data_ptr(), wp.data_ptr(), b.data_ptr(), res.data_ptr(), fac.data_ptr(), rps, m, n, k, y.data_ptr(), lib.ptr(xt), st),
+              "syn_linear_res")
+    want = res + lin * fac.repeat_interleave(rps)[:m, None]
+    assert rel_l2(y.cpu(), want.cpu()) < 2e-6
+    y2 = torch.full((m, n), float("nan"), device="cuda")
+    lib.check(L.syn_linear_res(xb.data_ptr(), wp.data_ptr(), None, res.data_ptr(), None, 0, m, n, k, y2.data_ptr(), None, st), "syn_linear_res")
+    assert rel_l2(y2.cpu(), (res + lin - b).cpu()) < 2e-6                 # no bias, no factor: residual + x W^T
+    pre, act = torch.full((m, n), float("nan"), device="cuda"), torch.zeros(m, n, dtype=torch.bfloat16, device="cuda")
+    xt2 = torch.empty_like(xt) if pack else None
+    lib.check(L.syn_linear_gelu(xb.data_ptr(), wp.data_ptr(), b.data_ptr(), m, n, k, pre.data_ptr(), act.data_ptr(), lib.ptr(xt2), st), "syn_linear_gelu")
+    torch.cuda.synchronize()
+    assert rel_l2(pre.cpu(), lin.cpu()) < 2e-6
+    assert rel_l2(act.float().cpu(), _bf(F.gelu(pre)).float().cpu()) < 1e-4      # (bf16 of the exact-erf GELU; erff vs torch's erf: a last-bit flip here and there)
+    if pack:
+        from syntalker_amd import training
+        assert torch.equal(xt, training._pack_t(xb, k, m)) and torch.equal(xt2, xt)     # the x^T fragments of the backward's weight-gradient GEMM
+
+
+def test_linear_backward_operand_pass_and_pair_bias_sum(lib):
+    """syn_linear_bwd_prep (bf16 copy, bf16 transpose, per-64-row column sums of factor * dy or GELU'(pre) * dy) and the bias-gradient sum riding
+    syn_linear_pair, against torch."""
+    from syntalker_amd import engine, training
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 256, 1024, 512
+    dy, pre = torch.randn(M, N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda() * 2
+    fac = (torch.rand(M // 32, generator=g) < 0.7).float().div(0.7).cuda()
+    L, st = lib.load(), lib.current_stream()
+    for scale, gp in ((fac, None), (None, pre), (None, None)):
+        eff = dy.clone()
+        if scale is not None:
+            eff = eff * scale.repeat_interleave(32)[:, None]
+        if gp is not None:
+            x = gp.double()
+            eff = (eff.double() * (0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5)).float()
+        dyb, dybt = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), torch.empty(N, M, dtype=torch.bfloat16, device="cuda")
+        part = torch.empty(M // 64, N, device="cuda")
+        lib.check(L.syn_linear_bwd_prep(dy.data_ptr(), M, N, lib.ptr(scale), 32, lib.ptr(gp), dyb.data_ptr(), dybt.data_ptr(), part.data_ptr(), None, None, st),
+                  "syn_linear_bwd_prep")
+        torch.cuda.synchronize()
+        assert rel_l2(dyb.float().cpu(), eff.cpu()) < 3e-3 and torch.equal(dybt, dyb.t().contiguous())
+        assert rel_l2(part.sum(0).cpu(), eff.sum(0).cpu()) < 2e-5
+        # the pair launch: dx = dy . W, dW = dy^T . x, db = the sum of the partials
+        xb = _bf(torch.randn(M, K, generator=g)).cuda().contiguous()
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+        wt, xt = training._pack_t(w, K, N), training._pack_t(xb, K, M)
+        dx, dw, db = torch.empty(M, K, device="cuda"), torch.empty(N, K, device="cuda"), torch.full((N,), float("nan"), device="cuda")
+        lib.check(L.syn_linear_pair(dyb.data_ptr(), wt.data_ptr(), M, K, N, dx.data_ptr(), dybt.data_ptr(), xt.data_ptr(), N, K, M, dw.data_ptr(),
+                                    part.data_ptr(), M // 64, N, db.data_ptr(), st), "syn_linear_pair")
+        torch.cuda.synchronize()
+        assert rel_l2(db.cpu(), part.sum(0).cpu()) < 1e-6
+        assert rel_l2(dx.cpu(), (dyb.float() @ _bf(w).float()).cpu()) < 2e-6 and rel_l2(dw.cpu(), (dyb.float().T @ xb.float()).cpu()) < 2e-6
+
+
 def test_gemm_tile_sizes_agree_bitwise(lib):
     """The per-element K-summation order does not depend on the M tile."""
     from syntalker_amd import engine
