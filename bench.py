@@ -172,6 +172,13 @@ def small_batch_probe(pm, coef, dev, sizes=(1, 8, 16, 32, 64, 256), reps=300):
             "frac_of_bf16_mfma_peak": {str(B): round(B / t * 1e6 * F_STEP / PEAK_BF16, 4) for B, t in us.items()},
             "whole_step_kernel_us_per_step_B1": round(timed(1, 4), 1)}
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU) through
     torch.distributed.run on a free local port, stream rank 0's JSON line through, return the launcher's exit code."""
@@ -229,10 +236,10 @@ def dry_run(args, rank, world, dist):
     if args.mode == "train":
         from syntalker_amd import synth, training
         from syntalker_amd.denoiser import MDM
-        graph = args.train_graph if args.train_graph is not None else world == 1
+        graph = args.train_graph if args.train_graph is not None else True
         model = synth.synth_fill_(MDM(synth.default_args()).train(), 0)
         n_params = sum(p.numel() for p in model.parameters())
-        if world > 1:
+        if world > 1 or args.force_ddp:
             net = training.make_ddp(model, None, capturable=graph)
             frozen = sorted(n for n, p in net.module.named_parameters() if not p.requires_grad)
             extra["ddp"] = {"find_unused_parameters": bool(net.find_unused_parameters), "frozen": frozen, "bucket_cap_mb": training.DDP_BUCKET_MB,
@@ -273,10 +280,11 @@ def run_train(args, rank, local, world, dev, dist):
     y["audio"] = torch.randn(B, 68266, 2, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + rank))   # training clip length
     x0 = synth.synth_latent(B, seed=1 + rank, name="x0").to(dev)
     model = synth.synth_fill_(MDM(synth.default_args()).train(), 0).to(dev)
-    graph = args.train_graph if args.train_graph is not None else world == 1
+    graph = args.train_graph if args.train_graph is not None else True
+    ddp = world > 1 or args.force_ddp          # --force-ddp: the wrapper (and RCCL, one rank) on a 1-GPU box - what the N-GPU run will use
     net = model
     side = torch.cuda.Stream(device=dev) if graph else torch.cuda.current_stream(dev)
-    if world > 1:
+    if ddp:
         with torch.cuda.stream(side):                           # DDP is built on the stream its iterations run on
             net = training.make_ddp(model, local, capturable=graph)
         torch.cuda.current_stream(dev).wait_stream(side)
@@ -287,7 +295,7 @@ def run_train(args, rank, local, world, dev, dist):
     else:
         opt = training.ClipAdam(net.parameters(), lr=5e-5, betas=(0.5, 0.999), max_norm=0.99)
     if graph:
-        g = training.GraphedTrainStep(net, diff, opt, x0, {"y": y}, warmup=11 if world > 1 else 3, stream=side)
+        g = training.GraphedTrainStep(net, diff, opt, x0, {"y": y}, warmup=11 if ddp else 3, stream=side)
         last = {}
         def step():
             last["loss"] = g(x0, sampler.sample(B, x0.device)[0], {"y": y})
@@ -298,9 +306,13 @@ def run_train(args, rank, local, world, dev, dist):
     dt = timed_region(step, K, W, world, dist, torch.cuda.synchronize)
     loss = float(last["loss"])
     assert loss == loss, "non-finite training loss"
-    # forward / backward / clip+Adam split of one eager step (hipEvents on the current stream; rank 0 only reports it)
+    # forward / backward / clip+Adam split of one EAGER step (hipEvents on the current stream; rank 0 only reports it).  After a captured
+    # run the same three eager steps follow the timed region: issued from Python the step is host-bound, so these are upper bounds of the
+    # device time of each part (the rocprofv3 kernel-time split of the replayed step is profiles/r04_train_step_split.txt)
     split = None
-    if not graph:
+    if graph:
+        g.close()
+    if True:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         acc = [0.0, 0.0, 0.0]
         for _ in range(3):
@@ -319,9 +331,7 @@ def run_train(args, rank, local, world, dev, dist):
             for i in range(3):
                 acc[i] += ev[i].elapsed_time(ev[i + 1]) / 3
         split = {"forward_ms": round(acc[0], 3), "backward_ms" + ("_incl_allreduce" if world > 1 else ""): round(acc[1], 3),
-                 "clip_adam_ms": round(acc[2], 3)}
-    if graph:
-        g.close()
+                 "clip_adam_ms": round(acc[2], 3), "issued": "eager, from Python (host-bound upper bounds)"}
     if rank != 0:
         return None
     value = world * B * K / dt
@@ -331,8 +341,8 @@ def run_train(args, rank, local, world, dev, dist):
             "config": {"workload": f"diffusion_rvqvae_128.yaml training step: {B} clips/GPU (global {world * B}), training_losses fwd+bwd, "
                                    "clip 0.99, Adam 5e-5 (0.5, 0.999), MDM denoiser 8x512 + trained WavEncoder, random-init",
                        "clips_per_gpu": B, "global_batch": world * B,
-                       "parallelism": f"dp{world}: one process per GPU, DDP bucketed all-reduce of 29.6 M gradients over RCCL" if world > 1 else "single GPU",
-                       "graph_replayed": graph},
+                       "parallelism": f"dp{world}: one process per GPU, DDP bucketed all-reduce of 29.6 M gradients over RCCL" if ddp else "single GPU",
+                       "graph_replayed": graph, "ddp_wrapper": ddp},
             "loss": round(loss, 5), "step_split": split,
             "roofline": {"bound": "mfma", "achieved": round(value / world * F_TRAIN / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(value / world * F_TRAIN / PEAK_BF16, 4), "traffic": None,
@@ -420,6 +430,62 @@ def run_guided(args, rank, local, world, dev, dist):
             "ddim50": d50, "bodypart_twocfg": body}
 
 
+def extras(args, local, dev) -> dict:
+    """BASELINE configs[2] - [4] on the default 1-GPU line: `train_step` (the captured training step of --mode train, 20 timed steps; plus
+    the SAME step under the DDP wrapper over a 1-rank RCCL group, run as a child process so that a collective that aborts cannot take
+    the line with it) and `guided` (--mode guided's three workloads, 20 timed steps each).  Same code paths as the modes themselves."""
+    import subprocess
+    out = {}
+    sub = argparse.Namespace(**vars(args))
+    sub.batch, sub.steps, sub.warmup, sub.prime, sub.force_ddp = None, 20, 10, 0, False
+    torch.cuda.empty_cache()
+    try:
+        tr = run_train(sub, 0, local, 1, dev, None)
+        out["train_step"] = {"workload": tr["config"]["workload"], "ms_per_step": tr["ms_per_step"], "samples_per_s": tr["value"], "steps": tr["steps"],
+                             "warmup": tr["warmup"], "graph_replayed": tr["config"]["graph_replayed"], "loss": tr["loss"],
+                             "frac": tr["roofline"]["frac"], "achieved_tflops": tr["roofline"]["achieved"], "roofline_note": tr["roofline"]["note"],
+                             "eager_step_split_ms": tr["step_split"]}
+    except Exception as e:                                   # the headline line survives a failure of an extra
+        out["train_step"] = {"error": f"{type(e).__name__}: {e}"}
+    torch.cuda.empty_cache()
+    try:
+        cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--force-ddp", "--steps", "200", "--warmup", "10"]
+        env = dict(os.environ)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env)
+        line = next((l for l in r.stdout.splitlines() if l.startswith("{")), None)
+        if r.returncode == 0 and line:
+            d = json.loads(line)
+            out["train_step_ddp_1rank"] = {"ms_per_step": d["ms_per_step"], "samples_per_s": d["value"], "steps": d["steps"], "warmup": d["warmup"],
+                                           "graph_replayed": d["config"]["graph_replayed"], "ddp_wrapper": d["config"]["ddp_wrapper"],
+                                           "rccl_ranks": d.get("rccl_ranks"), "loss": d["loss"],
+                                           "note": "the captured step under training.make_ddp(capturable=True) over a 1-rank RCCL group "
+                                                   "(bucketed all-reduces inside the graph): the wrapper the N-GPU run uses; child process"}
+        else:
+            out["train_step_ddp_1rank"] = {"error": f"rc {r.returncode}", "stderr_tail": r.stderr[-600:]}
+    except Exception as e:
+        out["train_step_ddp_1rank"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        gd = run_guided(sub, 0, local, 1, dev, None)
+        keep = ("workload", "clips_per_gpu", "variants", "reference_evaluations_per_step", "guided_clip_steps_per_s", "ms_per_step",
+                "reference_evaluation_equivalents_per_s", "steady_state_ms_per_step")
+        def brief(d):
+            b = {k: d[k] for k in keep if k in d}
+            rf = d.get("roofline") or {}
+            b.update(frac=rf.get("frac"), whole_step_frac=rf.get("whole_step_frac"), kernel=rf.get("kernel"))
+            return b
+        main_ = {"workload": gd["config"]["workload"], "clips_per_gpu": gd["config"]["clips_per_gpu"], "variants": gd["config"]["variants"],
+                 "reference_evaluations_per_step": 2, "guided_clip_steps_per_s": gd["value"], "ms_per_step": gd["ms_per_step"],
+                 "reference_evaluation_equivalents_per_s": gd["reference_evaluation_equivalents_per_s"],
+                 "steady_state_ms_per_step": gd.get("steady_state_ms_per_step"), "roofline": gd["roofline"]}
+        out["guided"] = {"steps": gd["steps"], "warmup": gd["warmup"], "cfg_ddpm": brief(main_), "cfg_ddim50": brief(gd["ddim50"]),
+                         "bodypart_twocfg_ddim50": brief(gd["bodypart_twocfg"])}
+    except Exception as e:
+        out["guided"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -435,8 +501,12 @@ def main():
                          "guided: configs[3] / [4] (classifier-free guidance as one fused batch, h3d-style denoiser)")
     ap.add_argument("--prime", type=int, default=0, help="untimed 10-step replays in front of the --warmup steps (default 0: W is the only warm-up)")
     ap.add_argument("--train-graph", action=argparse.BooleanOptionalAction, default=None,
-                    help="train mode: replay the whole step (incl. the all-reduces) from one hipGraph; default: on with one GPU (8.4 ms per step "
-                         "against 11.9 ms issued from Python, host-bound), off with several (the captured DDP step has only run with one RCCL rank)")
+                    help="train mode: replay the whole step (incl. DDP's bucketed all-reduces) from one hipGraph; default on at every world size "
+                         "(the step is ~1000 launches: issued from Python it is host-bound, 10-12 ms against 6.4 ms replayed); --no-train-graph = the eager step")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="train mode with one GPU: still wrap the model in DDP over a 1-rank RCCL process group, i.e. time the wrapper the multi-GPU run uses")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="sample mode: skip the train_step / guided sub-objects (BASELINE configs[2]-[4]) the default 1-GPU line carries")
     ap.add_argument("--torch-adam", action="store_true", help="train mode: torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(fused) instead of training.ClipAdam (A/B)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: exercises rank start-up, rendezvous (gloo), the barrier / max-over-ranks timing and the JSON line on CPU")
@@ -459,15 +529,15 @@ def main():
             sys.exit("bench.py: no GPU visible (the hot path has no CPU fallback; --dry-run exercises the launch path only)")
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or (args.force_ddp and args.mode == "train"):
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()) if world == 1 else "29533")
         if args.dry_run:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            if args.mode == "train" and args.train_graph:                       # (explicitly asked for: never the default with several ranks)
+            if args.mode == "train" and args.train_graph is not False:
                 os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")   # whole-step capture: no watchdog thread on the stream
-            dist.init_process_group("nccl", device_id=dev)          # backend "nccl" = RCCL on ROCm
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)          # backend "nccl" = RCCL on ROCm
     ranks_seen = dist.get_world_size() if dist is not None else 1
     if args.dry_run:
         out = dry_run(args, rank, world, dist)
@@ -477,10 +547,12 @@ def main():
         out = run_guided(args, rank, local, world, dev, dist)
     else:
         out = run_sample(args, rank, local, world, dev, dist)
+    if rank == 0 and world == 1 and args.mode == "sample" and not args.dry_run and not args.no_extras:
+        out.update(extras(args, local, dev))
     if rank == 0:
         out["rccl_ranks" if not args.dry_run else "gloo_ranks"] = ranks_seen
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist is not None:
         dist.barrier()                 # ranks leave together (rank 0 may still have been timing the CPU baseline)
         dist.destroy_process_group()
 

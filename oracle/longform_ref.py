@@ -1,20 +1,22 @@
 """Oracle (test infrastructure only) for the chunked long-sequence loop: CPU restatement of
 diffusion_rvqvae_trainer.py:413-476 on top of oracle.process_ref / oracle.denoiser_ref.
-Pinned like the rest of the oracle: the per-window sampler is the one checked against the reference goldens;
-the window arithmetic (slices, seeding, concatenation) is restated line by line below."""
+Pinned to a run of the reference's own `_g_test`: tests/golden/make_longform_golden.py executes the reference method (lifted
+from its file, on a stand-in `self`) over a 3-window take and `tests/test_longform.py::test_longform_oracle_vs_reference_g_test`
+holds this restatement - window slices, seed carry, stitching, decode - to what it wrote (tests/golden/longform_outputs.npz)."""
 import torch
 
 from .process_ref import RefProcess
 
 
 def sample_long_ref(model_fn, audio, word, seed_latent, n_pose, x_T, step_noise, use_ddim=False, skip_timesteps=0,
-                    pose_length=128, pre_frames=4, squeeze=4, style_dim=512):
-    """x_T: list of (B,1536,1,32) per window; step_noise: list of per-step noise tensors per window."""
+                    pose_length=128, pre_frames=4, squeeze=4, style_dim=512, ancestral=False):
+    """x_T: list of (B,1536,1,32) per window; step_noise: list of per-step noise tensors per window.
+    ancestral: `p_sample_loop` even on the respaced (use_ddim) process - what `_g_test` calls, whatever `self.diffusion` is (:361)."""
     overlap = pre_frames * squeeze
     round_l = pose_length - overlap                                     # :416
     roundt = (n_pose - overlap) // round_l                              # :414
     proc = RefProcess(use_ddim)
-    loop = proc.ddim_sample_loop if use_ddim else proc.p_sample_loop
+    loop = proc.ddim_sample_loop if (use_ddim and not ancestral) else proc.p_sample_loop
     bs = word.shape[0]
     out, last = [], None
     for i in range(roundt):                                              # :419

@@ -70,6 +70,8 @@ def main(argv=None) -> dict:
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
+        if a.graph:                                     # whole-step capture with the all-reduces inside: no watchdog thread on the stream
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")    # (GraphedTrainStep's protocol, training.py)
         dist.init_process_group("nccl", device_id=dev)
     torch.manual_seed(a.seed + rank); np.random.seed(a.seed + rank)          # the schedule sampler draws from numpy's global RNG
     t = config.build_trainer(args, dev)
@@ -78,8 +80,14 @@ def main(argv=None) -> dict:
     if a.resume:
         checkpoint.load_checkpoints(t.model, a.resume)
     net = t.model
+    side = torch.cuda.Stream(device=dev) if (a.graph and world > 1) else None
     if world > 1:
-        net = training.make_ddp(t.model, local, capturable=a.graph)
+        if side is not None:                            # DDP is built on the stream its captured iterations run on
+            with torch.cuda.stream(side):
+                net = training.make_ddp(t.model, local, capturable=True)
+            torch.cuda.current_stream(dev).wait_stream(side)
+        else:
+            net = training.make_ddp(t.model, local)
     os.makedirs(a.out, exist_ok=True)
     step_fn, log, saved = None, [], []
     for epoch in range(epochs + 1):                                           # train.py:270: range(args.epochs + 1), the last one only saves
@@ -91,7 +99,8 @@ def main(argv=None) -> dict:
             for x0, y in it:
                 if a.graph:
                     if step_fn is None:                 # (config.build_trainer's ClipAdam keeps its rate and step count on the device: capturable as it is)
-                        step_fn = training.GraphedTrainStep(net, t.diffusion, t.opt, x0, {"y": y}, grad_norm=t.grad_norm, warmup=11 if world > 1 else 3)
+                        step_fn = training.GraphedTrainStep(net, t.diffusion, t.opt, x0, {"y": y}, grad_norm=t.grad_norm, warmup=11 if world > 1 else 3,
+                                                            stream=side)
                     losses.append(step_fn(x0, t.schedule_sampler.sample(B, dev)[0], {"y": y}))
                 else:
                     losses.append(training.train_step(net, t.diffusion, t.schedule_sampler, t.opt, x0, {"y": y}, grad_norm=t.grad_norm))

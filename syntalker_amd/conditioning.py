@@ -215,6 +215,7 @@ class ClipConditioner:
         self.sd, self.fw, self.variant, self.use_style, self.pool = sd, folded, variant, use_style, pool
         self.wav_blocks = fold_wav_encoder(sd)
         self._hip_wav = None
+        self._word_checked, self._word_ref = None, None
         if pool != 4:
             raise NotImplementedError("the conditioning kernel pools 4 audio frames per latent frame (vqvae_squeeze_scale = 4)")
         self.weights = CondWeights(sd, folded, use_style, sd["mix_audio_text.weight"].device)
@@ -281,9 +282,13 @@ class ClipConditioner:
             raise _lib.SynHipError("style_feature given to a model without a style input (or missing for one that has it)")
         if feat.shape[0] != bs or word.device != dev or seed.device != dev or (style is not None and style.device != dev):
             raise _lib.SynHipError("conditioning inputs disagree on batch size or device")
-        lo, hi = int(word.min()), int(word.max())
-        if lo < 0 or hi >= w.vocab:
-            raise IndexError(f"word id out of range: [{lo}, {hi}] for a vocabulary of {w.vocab} (nn.Embedding would raise too)")
+        src = y["word"]
+        wkey = (id(src), src._version, bool(uncond_audio))
+        if self._word_checked != wkey:          # one device reduction + one host read per word tensor, not two per call
+            lo, hi = torch.stack(torch.aminmax(word)).tolist()
+            if lo < 0 or hi >= w.vocab:
+                raise IndexError(f"word id out of range: [{lo}, {hi}] for a vocabulary of {w.vocab} (nn.Embedding would raise too)")
+            self._word_checked, self._word_ref = wkey, src          # (the reference keeps the id unique while the key is alive)
         out = torch.empty(bs, 32, D, dtype=torch.float32, device=dev)
         d = torch.empty(8, bs, D, dtype=torch.float32, device=dev)        # SYN_COND_SCRATCH_ROWS partial sums per clip (include/syn_hip.h)
         _lib.check(_lib.load().syn_cond_encode(C.byref(w.c_struct()), feat.data_ptr(), word.data_ptr(), seed.data_ptr(), _lib.ptr(style),

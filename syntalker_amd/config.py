@@ -104,12 +104,17 @@ def build_sampler(args, device="cuda", model_cls=None):
     return s
 
 
+# what the reference's parser falls back to when the YAML omits the key (utils/config.py:204 `--grad_norm` default 0 = no clipping,
+# :208 `--lr_base` default 2.5e-4); every shipped diffusion_*.yaml sets both (0.99, 5e-5)
+GRAD_NORM_DEFAULT, LR_BASE_DEFAULT = 0.0, 2.5e-4
+
+
 def step_lr(args, epoch: int) -> float:
     """optimizers/timm/step_lr.py:46-51 as `create_scheduler` configures it for lr_policy 'step' (scheduler_factory.py:58-69; defaults
     of utils/config.py:207-217): lr_base * decay_rate ** (epoch // decay_epochs), no warm-up unless warmup_epochs > 0."""
     if getattr(args, "lr_policy", "step") != "step":
         raise NotImplementedError("only lr_policy == 'step' (the default every diffusion_*.yaml uses) is implemented")
-    base, t = float(getattr(args, "lr_base", 5e-5)), int(getattr(args, "decay_epochs", 9999))
+    base, t = float(getattr(args, "lr_base", LR_BASE_DEFAULT)), int(getattr(args, "decay_epochs", 9999))
     w, w0 = int(getattr(args, "warmup_epochs", 0)), float(getattr(args, "warmup_lr", 5e-4))
     if epoch < w:
         return w0 + epoch * (base - w0) / w
@@ -124,7 +129,7 @@ def build_trainer(args, device="cuda", model_cls=None):
         raise NotImplementedError("only opt == 'adam' (utils/config.py:207, every diffusion_*.yaml) is implemented")
     diffusion = create_gaussian_diffusion()
     betas = tuple(getattr(args, "opt_betas", (0.5, 0.999)))
-    grad_norm, wd = float(getattr(args, "grad_norm", 0.99)), float(getattr(args, "weight_decay", 0.0))
+    grad_norm, wd = float(getattr(args, "grad_norm", GRAD_NORM_DEFAULT)), float(getattr(args, "weight_decay", 0.0))
     if torch.device(device).type == "cuda":
         # clip_grad_norm_(grad_norm) + Adam as one optimizer step on the hand-written kernels; the rate is a device tensor, so the same
         # optimizer serves the eager loop and the captured step (the per-epoch scheduler writes it in place)
@@ -134,4 +139,4 @@ def build_trainer(args, device="cuda", model_cls=None):
     else:
         opt = torch.optim.Adam(model.parameters(), lr=step_lr(args, 0), betas=betas, weight_decay=wd)
     return SimpleNamespace(model=model, diffusion=diffusion, schedule_sampler=create_named_schedule_sampler("uniform", diffusion), opt=opt,
-                           grad_norm=float(getattr(args, "grad_norm", 0.99)), latent_scale=float(getattr(args, "vqvae_latent_scale", 5)))
+                           grad_norm=grad_norm, latent_scale=float(getattr(args, "vqvae_latent_scale", 5)))

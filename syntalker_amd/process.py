@@ -275,17 +275,21 @@ class GaussianDiffusion:
         if noise is None:
             noise = torch.randn(*shape, device=dev)                             # (the single draw `_start` would make)
         cut = lambda t, lo, hi: None if t is None else t[lo:hi]
+        with torch.no_grad():
+            # conditioning once for the whole batch, cached on the identity of the caller's tensors like the unsliced path's (the
+            # slices' y are fresh views: keyed on them the cache would never hit and the slices would evict each other)
+            conds = mdm.variant_conds(model_kwargs["y"], plan_fn(model_kwargs["y"]).variants)           # (V, B, 32, 512)
         outs = []
         for lo, hi in slices:
             kw = dict(model_kwargs, y=shard_kwargs(model_kwargs["y"], lo, hi, B))
             outs.append(self._fused_slice(kind, mdm, plan_fn, (hi - lo,) + tuple(shape[1:]), cut(noise, lo, hi), kw, eta,
                                           skip_timesteps, cut(init_image, lo, hi),
                                           None if step_noise is None else step_noise[:, lo:hi], seed, False, None,
-                                          first_clip + lo))
+                                          first_clip + lo, conds=conds[:, lo:hi]))
         return torch.cat(outs, 0)
 
     def _fused_slice(self, kind, mdm, plan_fn, shape, noise, model_kwargs, eta, skip_timesteps, init_image, step_noise,
-                     seed, progress, each=None, first_clip=0):
+                     seed, progress, each=None, first_clip=0, conds=None):
         """x stays on the device in the step kernel's layout for the whole loop; one graph replay per step (ten steps per
         replay where nothing happens in between)."""
         dev = next(mdm.parameters()).device
@@ -295,7 +299,7 @@ class GaussianDiffusion:
             plan = plan_fn(y)
             V = len(plan.variants)
             pm, sb = mdm.packed(), mdm.buffers(B, V, want_x0=each is not None)
-            sb.cond.copy_(mdm.variant_conds(y, plan.variants).reshape(-1, engine.D))
+            sb.cond.copy_((mdm.variant_conds(y, plan.variants) if conds is None else conds).reshape(-1, engine.D))
             if V > 1:
                 sb.cfg_w.copy_(plan.tensor(dev))
             img, indices = self._start(shape, None if noise is None else noise.to(dev), dev, skip_timesteps, init_image)

@@ -135,3 +135,42 @@ def synth_vq_rec_latent(sd: dict, part: str, n: int = 2, t: int = 16) -> torch.T
         idx = torch.randint(0, NB_CODE, (n, t), generator=g)
         rec = rec + sd[f"quantizer.layers.{q}.codebook"].cpu()[idx]
     return rec
+
+
+# ---- a long take for the chunked driver (diffusion_rvqvae_trainer.py:359-541): what `_load_data` hands `_g_test` ---------------
+def synth_long_take(n_pose: int, seed: int = 21) -> dict:
+    """One take (batch 1, as the reference's test loader delivers it): axis-angle pose (1, n, 165), audio (1, n*533, 2),
+    word ids (1, n), ground-truth latents (1, n/4, 1536) (only their first `pre_frames` rows are ever read)."""
+    g = _gen("long_take", seed)
+    return {"pose": 0.3 * torch.randn(1, n_pose, 165, generator=g),
+            "audio": torch.randn(1, n_pose * (16000 // 30), 2, generator=g),
+            "word": torch.randint(0, VOCAB, (1, n_pose), generator=g),
+            "latent": torch.randn(1, n_pose // 4, LATENT_C, generator=g)}
+
+
+def synth_long_noise(window: int, steps: int, seed: int = 22):
+    """(x_T (1,1536,1,32), per-step noise (steps,1,1536,1,32)) of window `window` of a long take."""
+    g = _gen(f"long_noise.{window}", seed)
+    return torch.randn(1, LATENT_C, 1, LATENT_T, generator=g), torch.randn(steps, 1, LATENT_C, 1, LATENT_T, generator=g)
+
+
+def synth_joint_masks() -> dict:
+    """0/1 masks over the 165 axis-angle channels with the reference's counts per body part (13 / 30 / 9 joints,
+    diffusion_rvqvae_trainer.py:52-60); which joints they are does not matter to the path under test."""
+    import numpy as np
+    m = {k: np.zeros(165) for k in ("upper", "hands", "lower")}
+    for j in (3, 6, 9, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21):
+        m["upper"][3 * j:3 * j + 3] = 1
+    m["hands"][75:165] = 1
+    for j in (0, 1, 2, 4, 5, 7, 8, 10, 11):
+        m["lower"][3 * j:3 * j + 3] = 1
+    return m
+
+
+def synth_pose_stats(seed: int = 23) -> dict:
+    """(mean, std) per body part and for the root velocity: seeded stand-ins for mean_std/*.npy (trainer :187-224)."""
+    g = _gen("pose_stats", seed)
+    out = {}
+    for name, dim in (("upper", 78), ("hands", 180), ("lower", 54), ("trans", 3)):
+        out[name] = (0.2 * torch.randn(dim, generator=g), 0.5 + torch.rand(dim, generator=g))
+    return out

@@ -1024,7 +1024,12 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     return out.reshape(T, bs, C, 1).permute(1, 2, 3, 0)
 
 
-UNUSED_IN_FORWARD = ("embed_style", "uncon_audio_embeddings", "uncon_text_embeddings")
+def unused_in_forward(model) -> tuple:
+    """Top-level parameter groups the training forward never reads: `embed_style` in both variants and the h3d
+    `uncon_audio_embeddings` (denoiser_h3d.py:63).  `uncon_text_embeddings` IS read by the h3d forward - the null prompt of its
+    cond-mask dropout (denoiser_h3d.py:119-122; `train_forward` above) - and is trained."""
+    m = getattr(model, "module", model)
+    return ("embed_style", "uncon_audio_embeddings") if getattr(m, "variant", "beatx") == "h3d" else ("embed_style",)
 
 
 DDP_BUCKET_MB = 32      # 118 MB of fp32 gradients -> 4 all-reduces (+ PyTorch's small first bucket, which starts the stream of collectives
@@ -1036,7 +1041,7 @@ DDP_BUCKET_MB = 32      # 118 MB of fp32 gradients -> 4 all-reduces (+ PyTorch's
 
 def make_ddp(model, local_rank: int | None = None, sync_bn: bool = False, capturable: bool = False):
     """One process per GPU, gradients all-reduced over RCCL (backend "nccl"); `embed_style` and the h3d
-    `uncon_*_embeddings` never receive gradients (unused in forward), hence find_unused_parameters.
+    `uncon_audio_embeddings` never receive gradients (`unused_in_forward`), hence find_unused_parameters.
     capturable=True prepares the wrapper for `GraphedTrainStep`: the unused-parameter search is a host-side walk plus
     a blocking all-reduce in every backward, which cannot be captured, so those parameters are frozen instead and the
     search is switched off (same gradients: they are None either way)."""
@@ -1044,8 +1049,9 @@ def make_ddp(model, local_rank: int | None = None, sync_bn: bool = False, captur
     if sync_bn:
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
     if capturable:
+        frozen = unused_in_forward(model)
         for n, p in model.named_parameters():
-            if n.split(".")[0] in UNUSED_IN_FORWARD:
+            if n.split(".")[0] in frozen:
                 p.requires_grad_(False)
     dev_ids = None if local_rank is None else [local_rank]
     return DDP(model, device_ids=dev_ids, broadcast_buffers=False, find_unused_parameters=not capturable,
@@ -1163,8 +1169,16 @@ class ClipAdam(torch.optim.Optimizer):
         return loss
 
 
+def _check_clip(optimizer, grad_norm):
+    """A ClipAdam clips inside its step with ITS max_norm; a `grad_norm` argument that says something else must not pass silently."""
+    if isinstance(optimizer, ClipAdam) and abs(float(grad_norm or 0.0) - optimizer.max_norm) > 1e-12:
+        raise ValueError(f"grad_norm={grad_norm} but the ClipAdam optimizer was built with max_norm={optimizer.max_norm or None}: "
+                         "construct it with max_norm=grad_norm (the clip is part of its step), or pass grad_norm=optimizer.max_norm")
+
+
 def train_step(model, diffusion, sampler, optimizer, x0, model_kwargs, grad_norm: float = 0.99):
     """The body of the reference's hot training loop (diffusion_rvqvae_trainer.py:339-356, 555-560)."""
+    _check_clip(optimizer, grad_norm)
     t, _ = sampler.sample(x0.shape[0], x0.device)
     optimizer.zero_grad(set_to_none=True)
     loss = diffusion.training_losses(model, x0, t, model_kwargs=model_kwargs)["loss"].mean()
@@ -1195,8 +1209,10 @@ class GraphedTrainStep:
     launch variants that used to trip the same abort.  SYN_TORCH_EMBEDDING_GRAD=1 brings the op back to reproduce it.)
     Call `close()` (or let the object die) before interpreter shutdown."""
 
-    def __init__(self, model, diffusion, optimizer, x0, model_kwargs, grad_norm: float = 0.99, warmup: int = 3, stream=None):
+    def __init__(self, model, diffusion, optimizer, x0, model_kwargs, grad_norm: float = 0.99, warmup: int = 3, stream=None,
+                 keep_warmup_updates: bool = False):
         engine._require_cuda(x0, "x0")
+        _check_clip(optimizer, grad_norm)
         self.model, self.opt, self.grad_norm, self.diffusion = model, optimizer, grad_norm, diffusion
         self.sync = bool(_os.environ.get("SYN_TRAIN_GRAPH_SYNC"))   # wait for every replay (not needed: see the class docstring)
         self.wrapped = diffusion._wrap_model(model)          # its timestep map is uploaded once, outside the capture
@@ -1205,13 +1221,41 @@ class GraphedTrainStep:
         self.y = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in model_kwargs["y"].items()}
         side = stream if stream is not None else torch.cuda.Stream(device=x0.device)   # DDP: the stream the wrapper was built on
         side.wait_stream(torch.cuda.current_stream(x0.device))
-        with torch.cuda.stream(side):                         # warm-up: MIOpen solver selection, lazy state, Adam state
+        with torch.cuda.stream(side):                         # warm-up: lazy state, Adam state, DDP's bucket rebuild
+            # The warm-up iterations are real optimizer steps on the construction batch at t = 0.  They must not count as training:
+            # parameters, buffers (BatchNorm statistics) and the optimizer's state are put back IN PLACE afterwards (the capture
+            # holds their addresses), so the first replay is update number 1 of the run - or number n + 1 after a resume.
+            snap = None if keep_warmup_updates else self._snapshot()
             for _ in range(warmup):
                 self._body()
         torch.cuda.current_stream(x0.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=side):
             self.loss = self._body()
+        if snap is not None:
+            with torch.cuda.stream(side):
+                self._restore(snap)
+            torch.cuda.current_stream(x0.device).wait_stream(side)
+
+    def _snapshot(self):
+        tensors = [p for p in self.model.parameters()] + [b for b in self.model.buffers()]
+        state = {}
+        for group in self.opt.param_groups:
+            for p in group["params"]:
+                st = self.opt.state.get(p)
+                if st:
+                    state[p] = {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)}
+        return [(t, t.detach().clone()) for t in tensors], state
+
+    @torch.no_grad()
+    def _restore(self, snap):
+        for t, saved in snap[0]:
+            t.copy_(saved)
+        for group in self.opt.param_groups:
+            for p in group["params"]:
+                for k, v in self.opt.state.get(p, {}).items():
+                    if torch.is_tensor(v):               # state born during the warm-up goes back to its initial value: zero
+                        v.copy_(snap[1][p][k]) if p in snap[1] and k in snap[1][p] else v.zero_()
 
     def _body(self):
         self.opt.zero_grad(set_to_none=True)

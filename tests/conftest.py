@@ -26,8 +26,8 @@ def pytest_collection_modifyitems(config, items):
 
 
 def rel_l2(a, b):
-    a = torch.as_tensor(a).double().flatten()
-    b = torch.as_tensor(b).double().flatten()
+    a = torch.as_tensor(a).detach().double().flatten()
+    b = torch.as_tensor(b).detach().double().flatten()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Golden vectors for the chunked long-sequence driver, produced by EXECUTING the reference's own
+`CustomTrainer._g_test` (diffusion_rvqvae_trainer.py:359-541) in the build container.
+
+The trainer module cannot be imported here (pynvml, smplx, wandb, librosa, clip ... are absent), so the script lifts the
+two methods it needs - `_g_test` and `inverse_selection_tensor` - out of the reference file with `ast`, compiles them as
+they stand (no edit, no copy into this repository: the code object is built from /root/reference at run time) and calls
+`_g_test` on a stand-in `self` that carries what `CustomTrainer.__init__` would have put there:
+
+  * `model`      the reference `models.denoiser.MDM` with the name-keyed synthetic weights of syntalker_amd.synth
+  * `diffusion`  the reference `create_gaussian_diffusion(use_ddim=True)`: `_g_test` calls its `p_sample_loop`, i.e. the
+                 ancestral sampler over the 50 kept timesteps (150 denoiser evaluations for 3 windows instead of 3000)
+  * `vq_model_*` the reference `models.vq.model.RVQVAE` (synthetic weights, `Tensor.cuda` = identity)
+  * joint masks, normalisation statistics, `args`: synthetic, seeded (syntalker_amd.synth / this file)
+
+x_T of every window (`th.randn`, gaussian_diffusion.py:703) and every step's noise (`th.randn_like`, :541) are replaced
+by seeded draws the tests regenerate.  Stored: the OUTPUTS only - per-window samples, the stitched latents handed to
+`latent2origin` (trainer :476-478), its three outputs after de-normalisation (:494-496) and `rec_trans` (:485-491).
+    python tests/golden/make_longform_golden.py
+"""
+import ast
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+from make_golden import REF, import_reference  # noqa: E402  (also puts /root/reference on sys.path)
+from make_vq_golden import PARTS, vq_args  # noqa: E402
+from syntalker_amd import synth  # noqa: E402
+
+WINDOWS = 3
+N_POSE = 128 + (WINDOWS - 1) * 112 + 5            # 357: `remain = n % 8` (trainer :378-388) trims the take to 352 frames
+
+
+def lift_methods(*names):
+    """The reference's own method bodies, compiled from its file (no import of the trainer module)."""
+    path = os.path.join(REF, "diffusion_rvqvae_trainer.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "CustomTrainer")
+    fns = [f for f in cls.body if isinstance(f, ast.FunctionDef) and f.name in names]
+    assert sorted(f.name for f in fns) == sorted(names)
+    from utils import rotation_conversions as rc
+    ns = {"torch": torch, "np": np, "rc": rc}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+class SeededDraws:
+    """`th.randn(*shape, device=...)` and `th.randn_like(x)` inside the reference's loop pop the next pre-drawn tensor."""
+
+    def __init__(self, draws):
+        self.draws, self.k = draws, 0
+
+    def _pop(self, shape):
+        r = self.draws[self.k]
+        self.k += 1
+        assert tuple(r.shape) == tuple(shape), (r.shape, shape)
+        return r.clone()
+
+    def __enter__(self):
+        self._randn, self._like = torch.randn, torch.randn_like
+        torch.randn = lambda *shape, **kw: self._pop(shape[0] if len(shape) == 1 and not isinstance(shape[0], int) else shape)
+        torch.randn_like = lambda x, *a, **kw: self._pop(x.shape)
+        return self
+
+    def __exit__(self, *a):
+        torch.randn, torch.randn_like = self._randn, self._like
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    torch.set_grad_enabled(False)
+    RefMDM, _, make_diff, _, data_path = import_reference()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from models.vq.model import RVQVAE
+    g_test, inverse_selection_tensor = lift_methods("_g_test", "inverse_selection_tensor")
+
+    me = types.SimpleNamespace()
+    me.args = types.SimpleNamespace(vqvae_squeeze_scale=4, pre_frames=4, pose_length=128, pose_dims=330, batch_size=1, pose_norm=True)
+    me.joints = 55
+    masks = synth.synth_joint_masks()
+    me.joint_mask_upper, me.joint_mask_hands, me.joint_mask_lower = masks["upper"], masks["hands"], masks["lower"]
+    me.inverse_selection_tensor = lambda *a: inverse_selection_tensor(me, *a)
+    me.model = synth.synth_fill_(RefMDM(synth.default_args(data_path=data_path)).eval(), seed=0)
+    me.diffusion = make_diff(use_ddim=True)
+    me.vqvae_latent_scale = 5.0
+    me.use_trans = True
+    stats = synth.synth_pose_stats()
+    me.trans_mean, me.trans_std = stats["trans"]
+    (me.mean_upper, me.std_upper), (me.mean_hands, me.std_hands), (me.mean_lower, me.std_lower) = stats["upper"], stats["hands"], stats["lower"]
+    rec = {}
+    for part, dim in PARTS:
+        vq = synth.synth_fill_(RVQVAE(vq_args(), dim, 512, 512, 512, 2, 2, 512, 3, 3, "relu", None).eval(), seed=11)
+        orig = vq.latent2origin
+
+        def tapped(x, part=part, orig=orig):
+            rec[f"{part}.latent_in"] = x.clone()
+            out = orig(x)
+            rec[f"{part}.latent2origin"] = out[0].clone()
+            return out
+        vq.latent2origin = tapped
+        setattr(me, f"vq_model_{part}", vq)
+
+    take = synth.synth_long_take(N_POSE, seed=21)
+    data = {"tar_pose": take["pose"], "tar_beta": torch.zeros(1, N_POSE, 300), "tar_exps": torch.zeros(1, N_POSE, 100),
+            "tar_contact": torch.zeros(1, N_POSE, 4), "tar_trans": torch.zeros(1, N_POSE, 3), "in_word": take["word"],
+            "in_audio": take["audio"], "latent_in": take["latent"], "tar_id": torch.zeros(1, N_POSE, 1, dtype=torch.long)}
+    K = me.diffusion.num_timesteps
+    draws, samples = [], []
+    for w in range(WINDOWS):
+        xT, sn = synth.synth_long_noise(w, K, seed=22)
+        draws += [xT] + list(sn)
+    loop = me.diffusion.p_sample_loop
+    me.diffusion.p_sample_loop = lambda *a, **kw: (samples.append(loop(*a, **kw)), samples[-1])[1]
+    with SeededDraws(draws) as sd:
+        res = g_test(me, data)
+    assert sd.k == len(draws) == WINDOWS * (K + 1) and len(samples) == WINDOWS
+    out = {"n_pose": np.int64(N_POSE), "steps": np.int64(K), "windows": np.int64(WINDOWS),
+           "samples": torch.stack(samples).numpy(),                                               # (W, 1, 1536, 1, 32)
+           "rec_trans": res["rec_trans"].numpy()}
+    for part, _ in PARTS:
+        out[f"{part}.latent_in"] = rec[f"{part}.latent_in"].numpy()                               # (1, 88, 512), already x latent scale
+        out[f"{part}.latent2origin"] = rec[f"{part}.latent2origin"].numpy()                       # (1, 352, dim) before de-normalisation
+    out["rec_pose"] = res["rec_pose"].numpy()                                                     # (1, 352, 330): the post-processing (out of scope) ran
+    for k, v in out.items():
+        print(k, getattr(v, "shape", v), float(np.abs(v).mean()) if getattr(v, "ndim", 0) else "")
+    np.savez_compressed(os.path.join(HERE, "longform_outputs.npz"), **out)
+    print("wrote longform_outputs.npz", sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

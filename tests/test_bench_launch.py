@@ -29,9 +29,11 @@ def test_bench_starts_its_own_ranks(mode):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["gloo_ranks"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and out["dry_run"] is True and out["mode"] == mode
     if mode == "train":
-        # what the real run builds before its first step: the product MDM under make_ddp, eager by default with several ranks
-        assert out["parameters"] == 29_607_012 and out["graph_replayed"] is False
-        assert out["ddp"]["find_unused_parameters"] is True and out["ddp"]["frozen"] == [] and out["ddp"]["bucket_cap_mb"] == 32
+        # what the real run builds before its first step: the product MDM under make_ddp, prepared for the captured step (the default at
+        # every world size: unused parameters frozen, no unused-parameter search)
+        assert out["parameters"] == 29_607_012 and out["graph_replayed"] is True
+        assert out["ddp"]["find_unused_parameters"] is False and out["ddp"]["frozen"] == ["embed_style.bias", "embed_style.weight"]
+        assert out["ddp"]["bucket_cap_mb"] == 32
     if mode == "guided":
         # BASELINE configs[3]: cond + uncond = 2 variants; configs[4]: the body-part wrapper's 9 evaluations de-duplicate to 4
         assert out["plans"]["cfg"]["variants"] == 2 and out["plans"]["bodypart_twocfg"]["variants"] == 4
@@ -39,13 +41,21 @@ def test_bench_starts_its_own_ranks(mode):
             assert all(abs(sum(row) - 1.0) < 1e-6 for row in plan["weights"])          # a guidance formula's weights sum to 1 per block
 
 
-def test_bench_train_dry_run_with_the_captured_step_wiring():
-    """--train-graph with several ranks: the wrapper is built for capture (unused parameters frozen, no search)."""
-    r, lines = _run("--gpus", "2", "--mode", "train", "--train-graph")
+def test_bench_train_dry_run_with_the_eager_step_wiring():
+    """--no-train-graph with several ranks: the eager step, the wrapper searches for unused parameters (nothing frozen)."""
+    r, lines = _run("--gpus", "2", "--mode", "train", "--no-train-graph")
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(lines[0])
-    assert out["graph_replayed"] is True and out["ddp"]["find_unused_parameters"] is False
-    assert out["ddp"]["frozen"] == ["embed_style.bias", "embed_style.weight"]
+    assert out["graph_replayed"] is False and out["ddp"]["find_unused_parameters"] is True and out["ddp"]["frozen"] == []
+
+
+def test_bench_force_ddp_on_one_rank():
+    """--force-ddp: one rank still builds the process group and the wrapper (what the driver's 1-GPU box times)."""
+    r, lines = _run("--mode", "train", "--force-ddp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["gloo_ranks"] == 1 and out["graph_replayed"] is True
+    assert out["ddp"]["find_unused_parameters"] is False and out["ddp"]["frozen"] == ["embed_style.bias", "embed_style.weight"]
 
 
 def test_bench_single_rank_and_launcher_mismatch():

@@ -566,10 +566,59 @@ def test_train_mode_step_runs_and_updates(beatx):
     assert torch.isfinite(l1) and torch.isfinite(l2)
     assert not torch.equal(before, m.mytimmblocks[0].attn.qkv.weight)            # parameters moved
     assert not torch.equal(rm, m.WavEncoder.feat_extractor[0].bn1.running_mean)  # BatchNorm used batch statistics
+    # the h3d forward reads the learned null prompt (denoiser_h3d.py:119-122): it trains; the null audio embedding is never read
+    assert m.uncon_text_embeddings.grad is not None and m.uncon_audio_embeddings.grad is None and m.embed_style.weight.grad is None
+    assert training.unused_in_forward(m) == ("embed_style", "uncon_audio_embeddings")
+    assert training.unused_in_forward(_model("beatx")) == ("embed_style",)
     m.eval()
     with torch.no_grad():                                                         # packed weights follow the update
         out = m(x0, torch.tensor([5, 6, 7, 8], device=DEV), y)
     assert torch.isfinite(out).all()
+
+
+def test_two_forwards_then_one_backward_and_two_models_alive():
+    """The fused residual branches carry the W^T fragments their forward saw on the autograd node - views of the model's per-step
+    pack buffers, which the NEXT forward rewrites in place (training.WeightPacks.refresh).  Gradient accumulation (two forwards, then
+    one backward through both) and a second model's forward between a forward and its backward must give the gradients of the
+    plain sequence forward-backward, forward-backward."""
+    from syntalker_amd.process import create_gaussian_diffusion
+    d = create_gaussian_diffusion()
+    t4 = torch.tensor([3, 170, 500, 998], device=DEV)
+
+    def case(seed):
+        y = synth.to_device(synth.synth_clip_inputs(4, seed=seed), DEV)
+        return synth.synth_latent(4, seed=seed, name="x0").to(DEV), synth.synth_latent(4, seed=seed + 1, name="eps").to(DEV), y
+
+    def loss(m, c):
+        return d.training_losses(m, c[0], t4, model_kwargs={"y": c[2]}, noise=c[1])["loss"].mean()
+
+    def grads(m):
+        g = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        m.zero_grad(set_to_none=True)
+        return g
+    m = _model("beatx")
+    m.differentiable_eval = True
+    a, b = case(71), case(73)
+    loss(m, a).backward(); ga = grads(m)
+    loss(m, b).backward(); gb = grads(m)
+    la, lb = loss(m, a), loss(m, b)                   # two forwards (the second refreshes the pack buffers the first one's nodes hold)
+    (la + lb).backward()
+    both = grads(m)
+    assert set(both) == set(ga) == set(gb) and "mytimmblocks.0.attn.qkv.weight" in both
+    for n in both:
+        assert rel_l2(both[n], ga[n] + gb[n]) < 1e-5, n
+    from syntalker_amd.denoiser import MDM
+    other = MDM(synth.default_args()).eval()
+    other.load_state_dict({k: v * 1.5 if v.is_floating_point() and v.dim() == 2 else v for k, v in synth_state_dict("beatx").items()}, strict=False)
+    other = other.to(DEV)
+    other.differentiable_eval = True
+    la = loss(m, a)
+    lo = loss(other, b)                               # another model's forward (its own packs become the module-level current ones)
+    la.backward()
+    for n, g in grads(m).items():
+        assert rel_l2(g, ga[n]) < 1e-6, n
+    lo.backward()
+    assert all(torch.isfinite(p.grad).all() for p in other.parameters() if p.grad is not None)
 
 
 def test_guided_small_batch_both_group_layouts(h3d):
@@ -645,32 +694,6 @@ def test_captured_train_step_at_the_bench_size_replays_back_to_back(beatx):
     step.close()
     losses = [float(v) for v in losses]
     assert all(np.isfinite(losses)) and np.mean(losses[-5:]) < np.mean(losses[:5])
-
-
-def test_ddp_wrapper_inside_the_captured_training_step():
-    """One rank over RCCL under torchrun (the GPU boxes have one GPU): `make_ddp(capturable=True)` + `GraphedTrainStep`
-    capture the whole step with the wrapper's bucketed all-reduces inside the graph, and replays keep training
-    (finite, decreasing-ish loss is not asserted: only that eager and replayed steps both run to completion)."""
-    import os
-    import subprocess
-    import sys
-    from tests.conftest import REPO
-    import socket
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    for attempt in range(2):               # one retry: process-group start-up on a busy box has failed once in ~10 suite runs
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.join(REPO, "scripts", "bench_train_ddp.py"), "4", "3"]
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-        if r.returncode == 0:
-            break
-        print("attempt", attempt, "failed:", r.stdout[-1500:], r.stderr[-1500:])
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "eager DDP step" in r.stdout and "graph-replayed DDP step" in r.stdout, r.stdout[-2000:]
-    loss = float(r.stdout.strip().splitlines()[-1].rsplit("loss", 1)[1])
-    assert loss == loss and abs(loss) < 1e3
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -65,6 +65,87 @@ def test_sample_long_cpu_generic_path_equals_manual_loop():
     assert torch.equal(got, torch.cat(pieces, 1))
 
 
+# ---------------------------------------------------------------------------------------------------------
+# the reference's own `_g_test` (diffusion_rvqvae_trainer.py:359-541), executed by tests/golden/make_longform_golden.py:
+# 3 windows of one take, its p_sample_loop over the 50 kept timesteps, x_T and step noise from seeded generators
+def _g_test_fixture():
+    import numpy as np
+    return np.load(os.path.join(REPO, "tests", "golden", "longform_outputs.npz"))
+
+
+def _g_test_inputs(fx):
+    n, K, W = int(fx["n_pose"]), int(fx["steps"]), int(fx["windows"])
+    take = synth.synth_long_take(n, seed=21)
+    draws = [synth.synth_long_noise(w, K, seed=22) for w in range(W)]
+    return n, K, W, take, [d[0] for d in draws], [d[1] for d in draws]
+
+
+def test_longform_oracle_vs_reference_g_test():
+    """oracle/longform_ref.py (window slices, seed carry, stitching, decode) against what the reference's `_g_test` produced."""
+    from oracle import denoiser_ref as dr
+    from oracle.longform_ref import decode_take_ref, sample_long_ref
+    from tests.conftest import rel_l2
+    from tests.refmodel import synth_state_dict
+    fx = _g_test_fixture()
+    n, K, W, take, xs, sn = _g_test_inputs(fx)
+    assert (n, K, W) == (357, 50, 3)
+    sd = synth_state_dict("beatx")
+    with torch.no_grad():
+        lat = sample_long_ref(lambda a, b, c: dr.mdm_forward(sd, a, b, c), take["audio"], take["word"], take["latent"], n, xs, sn,
+                              use_ddim=True, ancestral=True)
+    assert lat.shape == (1, 88, 1536)
+    for k, part in enumerate(("upper", "hands", "lower")):
+        assert rel_l2(lat[..., 512 * k:512 * (k + 1)] * 5.0, fx[f"{part}.latent_in"]) < 5e-6, part
+    # the decode either side of it, fed the reference's own stitched latents (a code flip would be a 1e-1 event, not a 1e-6 one)
+    stats = synth.synth_pose_stats()
+    ref_lat = torch.cat([torch.from_numpy(fx[f"{p}.latent_in"]) for p in ("upper", "hands", "lower")], dim=-1) / 5.0
+    vq_sds = {p: synth.synth_vq_state_dict(d) for p, d in (("upper", 78), ("hands", 180), ("lower", 57))}
+    with torch.no_grad():
+        parts = decode_take_ref(vq_sds, ref_lat, 5.0, True, *stats["trans"])
+    assert rel_l2(parts["trans"], fx["rec_trans"]) < 5e-6
+    for p in ("upper", "hands"):
+        assert rel_l2(parts[p], fx[f"{p}.latent2origin"]) < 5e-6, p
+    assert rel_l2(parts["lower"], fx["lower.latent2origin"][..., :-3]) < 5e-6
+
+
+@pytest.mark.gpu
+def test_sample_long_and_decode_vs_reference_g_test():
+    """The product's `sample_long` + `decode_take` against the fixture the reference's `_g_test` wrote: same take, same x_T and
+    step noise, the ancestral sampler over the 50 kept timesteps (`create_gaussian_diffusion(use_ddim=True).p_sample_loop`)."""
+    from syntalker_amd import rvqvae
+    from syntalker_amd.denoiser import MDM
+    from syntalker_amd.process import create_gaussian_diffusion
+    from tests.conftest import rel_l2
+    from tests.refmodel import synth_state_dict
+    dev = "cuda"
+    fx = _g_test_fixture()
+    n, K, W, take, xs, sn = _g_test_inputs(fx)
+    m = MDM(synth.default_args()).eval()
+    m.load_state_dict(synth_state_dict("beatx"), strict=False)
+    m = m.to(dev)
+    d = create_gaussian_diffusion(use_ddim=True)
+    got = longform.sample_long(d, m, take["audio"].to(dev), take["word"].to(dev), take["latent"].to(dev), n,
+                               noise_fn=lambda i: xs[i].to(dev), step_noise_fn=lambda i: sn[i]).cpu()
+    assert got.shape == (1, 88, 1536)
+    want = torch.cat([torch.from_numpy(fx[f"{p}.latent_in"]) for p in ("upper", "hands", "lower")], dim=-1) / 5.0
+    e = rel_l2(got, want)
+    print(f"3-window take vs the reference's _g_test: stitched latents rel-L2 {e:.3e}")
+    assert e < 3e-2
+    vqs = []
+    for p, dim in (("upper", 78), ("hands", 180), ("lower", 57)):
+        vq = rvqvae.build(dim).eval()
+        vq.load_state_dict(synth.synth_vq_state_dict(dim))
+        vqs.append(vq.to(dev))
+    stats = synth.synth_pose_stats()
+    parts = longform.decode_take(want.to(dev), *vqs, 5.0, use_trans=True, trans_mean=stats["trans"][0].to(dev), trans_std=stats["trans"][1].to(dev))
+    for p in ("upper", "hands"):
+        e = rel_l2(parts[p].cpu(), fx[f"{p}.latent2origin"])
+        print(f"  decode {p}: {e:.3e}")
+        assert e < 3e-2, p
+    assert rel_l2(parts["lower"].cpu(), fx["lower.latent2origin"][..., :-3]) < 3e-2
+    assert rel_l2(parts["trans"].cpu(), fx["rec_trans"]) < 3e-2
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("use_ddim", [False, True])
 def test_sample_long_vs_oracle(use_ddim):
