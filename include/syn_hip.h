@@ -461,6 +461,22 @@ int syn_test_handoff(uint32_t* sync_320_zeroed, uint32_t* buf_8x4096, const floa
 /* attention over ws_q/ws_k/ws_vt -> ws_o for n_seq sequences of 32 tokens, 4 heads x 128. */
 int syn_test_attention(const void* q, const void* k, const void* vt, int32_t n_seq, void* o, void* stream);
 
+/* ---- diagnostics (scripts/diag_*.py, scripts/ubench_*.py; never called by the product path) ------------------------------
+ * Process-wide switches of the library, not thread-safe, no status to return.  They replace nothing in the reference. */
+/* per-phase cycle counters of the step kernels: the attention / MLP phases write s_memtime stamps into these device buffers (NULL: off) */
+void syn_debug_timing(long long* attn_buf, long long* mlp_buf);
+/* 16-row plain GEMMs of the training step: 1 (default) = activation block resident in the LDS, 0 = the streaming loop (A/B, bitwise equal) */
+void syn_debug_gemm_resident(int on);
+/* pin syn_linear's row tile (16 / 32 / 64 / 128); 0 = automatic */
+void syn_debug_linear_tile(int rows);
+/* training-mode convolutions (syn_conv1d_train_*): which cross products of the hi / lo operand split the NEXT launches issue - bit 0: A_lo . B_hi
+ * (A = weights, or dy in the weight gradient), bit 1: A_hi . B_lo (B = the activations: x, or dy in the data gradient); 3 (default) = both, fp32-grade */
+void syn_debug_conv_terms(int mask);
+/* k_seq: delay workgroup i by (i % 8) * units_of_64_cycles * 64 cycles at launch (phase experiments); -1 = off */
+void syn_debug_seq_skew(int units_of_64_cycles);
+/* k_seq: which step of a multi-step launch syn_debug_timing's stamps are taken in */
+void syn_debug_seq_step(int step);
+
 #ifdef __cplusplus
 }
 #endif

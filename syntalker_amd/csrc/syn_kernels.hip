@@ -2003,8 +2003,12 @@ int launch_conv(const wav::CArgs& a, int n_clips, hipStream_t s) {
     return e == hipSuccess ? 0 : fail("k_conv launch", e);
 }
 
+// diagnostics (syn_debug_conv_terms): which of the two cross products of the split-operand convolutions are issued (3 = both)
+static int g_conv_terms = 3;
+
 template <int CINP, int KT, int RF>
-int launch_conv_train_ks(const wav::TArgs& a, int n_clips, hipStream_t s) {
+int launch_conv_train_ks(const wav::TArgs& a0, int n_clips, hipStream_t s) {
+    wav::TArgs a = a0; a.terms = g_conv_terms;
     constexpr int MW = RF * 16, lds = 2 * (MW + KT - 1) * (CINP * 2 + 16);
     static_assert(lds <= 160 * 1024, "two bf16 planes of the input tile must fit the LDS");
     static OncePerDevice once;
@@ -2015,7 +2019,8 @@ int launch_conv_train_ks(const wav::TArgs& a, int n_clips, hipStream_t s) {
 }
 
 template <int CINP, int KT, int WN, int WM, int RF>
-int launch_conv_train(const wav::TArgs& a, int n_clips, hipStream_t s) {
+int launch_conv_train(const wav::TArgs& a0, int n_clips, hipStream_t s) {
+    wav::TArgs a = a0; a.terms = g_conv_terms;
     constexpr int MW = WM * RF * 16, lds = 2 * (MW + KT - 1) * (CINP * 2 + 16);
     static_assert(lds <= 160 * 1024, "two bf16 planes of the input tile must fit the LDS");
     static OncePerDevice once;
@@ -2026,7 +2031,8 @@ int launch_conv_train(const wav::TArgs& a, int n_clips, hipStream_t s) {
 }
 
 template <int CO_T, int TAPS>
-int launch_wgrad_s(const wav::WArgs& a, hipStream_t s) {
+int launch_wgrad_s(const wav::WArgs& a0, hipStream_t s) {
+    wav::WArgs a = a0; a.terms = g_conv_terms;
     static_assert(wav::wgrad_s_lds(CO_T) <= 160 * 1024, "dy and x' tiles must fit the LDS");
     static OncePerDevice once;
     if (once.first()) { allow_lds(wav::k_conv_wgrad_s<CO_T, TAPS>, wav::wgrad_s_lds(CO_T)); }
@@ -2036,7 +2042,8 @@ int launch_wgrad_s(const wav::WArgs& a, hipStream_t s) {
 }
 
 template <int CO, int TAPS>
-int launch_wgrad(const wav::WArgs& a, hipStream_t s) {
+int launch_wgrad(const wav::WArgs& a0, hipStream_t s) {
+    wav::WArgs a = a0; a.terms = g_conv_terms;
     static OncePerDevice once;
     constexpr int CB = wav::wgrad_cb(CO);
     if (once.first()) { allow_lds(wav::k_conv_wgrad<CO, TAPS, CB>, wav::wgrad_lds(CO)); }
@@ -3275,6 +3282,7 @@ int syn_denoise_step(const syn_model* md, const syn_step* st, void* stream) {
     return step_impl(md, st, (hipStream_t)stream, nullptr);
 }
 
+void syn_debug_conv_terms(int mask) { g_conv_terms = mask & 3; }   /* diagnostics: cross products of the split-operand training convolutions (3 = all) */
 void syn_debug_seq_skew(int units_of_64_cycles) { g_seq_skew = units_of_64_cycles; }
 void syn_debug_seq_step(int step) { g_seq_dbg_step = step; }
 

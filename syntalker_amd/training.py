@@ -624,6 +624,15 @@ def _unsupported_conv(what, cin, stride, pad, cout):
                             "encoder (covered: the reference's WavEncoder, models/denoiser.py:304-322); there is no library fallback")
 
 
+# Which cross products of the hi / lo operand split each convolution role issues (`syn_debug_conv_terms`; bit 0: A_lo . B_hi, bit 1: A_hi . B_lo,
+# 3 = both = fp32-grade).  "forward,data-gradient,weight-gradient"; A / B = (W, x), (W^T, dy), (dy, x).  An A/B switch.
+CONV_TERMS = tuple(int(v) for v in _os.environ.get("SYN_CONV_TERMS", "3,3,3").split(","))
+
+
+def _conv_terms(role: int):
+    _lib.load().syn_debug_conv_terms(CONV_TERMS[role])
+
+
 class ConvSplitFn(torch.autograd.Function):
     """(N, C, 1, L) channels_last convolution of the audio encoder, forward on the hand-written implicit-GEMM kernel with
     operands split into bf16 hi + lo halves (`syn_conv1d_train_fwd`: three MFMAs per product, fp32-grade - the plain bf16
@@ -660,6 +669,7 @@ class ConvSplitFn(torch.autograd.Function):
             # BatchNorm's per-channel sums from the convolution's accumulators: the BatchNorm that follows skips its pass over y
             tiles = lib.syn_conv1d_train_fwd_tiles(n, l_in, cin, stride, pad, cout)
             part = torch.empty(tiles, 2, cout, device=x.device, dtype=torch.float32)
+        _conv_terms(1 if transposed else 0)
         _lib.check(lib.syn_conv1d_train_fwd(xc.data_ptr(), n, l_in, cin, stride, pad, whi.data_ptr(), wlo.data_ptr(), None, cout,
                                                     y.data_ptr(), _lib.ptr(part), _lib.current_stream(x.device)), "syn_conv1d_train_fwd")
         if part is not None:
@@ -701,6 +711,7 @@ class ConvSplitFn(torch.autograd.Function):
                     _lib.check(lib.syn_conv1d_pack_split(wc.data_ptr(), cout, cin, stride, 1, whi.data_ptr(), wlo.data_ptr(),
                                                          _lib.current_stream(x.device)), "syn_conv1d_pack_split")
                 gx = torch.empty(n, cin, 1, l_in, device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+                _conv_terms(1)
                 _lib.check(lib.syn_conv1d_train_dgrad_strided(gy.data_ptr(), n, l_in, cin, stride, cout, whi.data_ptr(), wlo.data_ptr(),
                                                               gx.data_ptr(), _lib.current_stream(x.device)), "syn_conv1d_train_dgrad_strided")
             else:
@@ -714,6 +725,7 @@ class ConvSplitFn(torch.autograd.Function):
                 l_out, kts = gy.shape[-1], -(-15 // stride) * stride
                 ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l_out, stride * cin) * cout * kts * cin, device=x.device, dtype=torch.float32)
                 gw = torch.empty(cout, cin, 1, 15, device=x.device, dtype=torch.float32)
+                _conv_terms(2)
                 _lib.check(lib.syn_conv1d_train_wgrad(x.data_ptr(), gy.data_ptr(), n, l, cin, stride, pad, cout, ws.data_ptr(), gw.data_ptr(),
                                                       _lib.current_stream(x.device)), "syn_conv1d_train_wgrad")
                 gw = gw.to(w.dtype)
@@ -1229,8 +1241,17 @@ class GraphedTrainStep:
             for _ in range(warmup):
                 self._body()
         torch.cuda.current_stream(x0.device).wait_stream(side)
+        mode = "global"
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # A process group's watchdog thread polls the events of the warm-up's collectives (hipEventQuery, then their release).  Let it
+            # retire them before the capture starts - the device is drained, the thread sweeps every ~100 ms - and keep other threads'
+            # runtime calls out of this capture's error domain (thread-local mode: launches on the capturing stream are captured whichever
+            # thread issues them - the autograd engine's do - but a foreign thread's query cannot invalidate the capture).
+            torch.cuda.synchronize(x0.device)
+            __import__("time").sleep(0.3)
+            mode = "thread_local"
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side):
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode=mode):
             self.loss = self._body()
         if snap is not None:
             with torch.cuda.stream(side):
@@ -1238,7 +1259,7 @@ class GraphedTrainStep:
             torch.cuda.current_stream(x0.device).wait_stream(side)
 
     def _snapshot(self):
-        tensors = [p for p in self.model.parameters()] + [b for b in self.model.buffers()]
+        tensors = [p for p in self.model.parameters()] + [b for _, b in self.model.named_buffers()]     # (MDM.buffers is the step-buffer factory)
         state = {}
         for group in self.opt.param_groups:
             for p in group["params"]:

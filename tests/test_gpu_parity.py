@@ -663,9 +663,18 @@ def test_graph_replayed_train_step(beatx):
     y = synth.to_device(synth.synth_clip_inputs(4, seed=61), DEV)
     x0 = synth.synth_latent(4, seed=61, name="x0").to(DEV)
     t = torch.tensor([100, 300, 500, 700], device=DEV)
+    w0 = m.mytimmblocks[0].attn.qkv.weight.detach().clone()
+    bn = m.WavEncoder.feat_extractor[0].bn1
+    rm0, nb0 = bn.running_mean.clone(), int(bn.num_batches_tracked)
     step = training.GraphedTrainStep(m, d, opt, x0, {"y": y})
+    # the warm-up iterations in front of the capture are real optimizer steps (construction batch, t = 0): they are undone, so the
+    # first replay is update number 1 of the run (Adam's bias correction included) and BatchNorm's statistics start where they were
+    assert torch.equal(w0, m.mytimmblocks[0].attn.qkv.weight) and torch.equal(rm0, bn.running_mean) and int(bn.num_batches_tracked) == nb0
+    st = opt.state[m.mytimmblocks[0].attn.qkv.weight]
+    assert float(st["step"]) == 0.0 and float(st["exp_avg"].abs().max()) == 0.0 and float(st["exp_avg_sq"].abs().max()) == 0.0
     before = m.mytimmblocks[0].attn.qkv.weight.detach().clone()
     losses = [float(step(x0, t, {"y": y})) for _ in range(25)]
+    assert float(st["step"]) == 25.0 and int(bn.num_batches_tracked) == nb0 + 25
     step.close()
     assert all(np.isfinite(losses)) and not torch.equal(before, m.mytimmblocks[0].attn.qkv.weight)
     assert np.mean(losses[-5:]) < np.mean(losses[:5])

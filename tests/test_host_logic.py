@@ -206,6 +206,12 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), name
+    # ... and nothing is exported that the header does not declare (the diagnostics switches are `void`, declared in their own section)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in nm.splitlines() if " T syn_" in l}
+    diagnostics = set(re.findall(r"^\s*void\s+(syn_debug_[a-z_0-9]+)\s*\(", header, flags=re.M))
+    assert len(diagnostics) == 6 and exported == declared | diagnostics, exported ^ (declared | diagnostics)
     assert lib.syn_version() == 5 == _lib.ABI_VERSION
     # struct sizes exactly as the C compiler lays out include/syn_hip.h (gcc, same ABI as hipcc's host side)
     import subprocess, tempfile
