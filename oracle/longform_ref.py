@@ -9,9 +9,11 @@ from .process_ref import RefProcess
 
 
 def sample_long_ref(model_fn, audio, word, seed_latent, n_pose, x_T, step_noise, use_ddim=False, skip_timesteps=0,
-                    pose_length=128, pre_frames=4, squeeze=4, style_dim=512, ancestral=False):
+                    pose_length=128, pre_frames=4, squeeze=4, style_dim=512, ancestral=False, y_extra=None):
     """x_T: list of (B,1536,1,32) per window; step_noise: list of per-step noise tensors per window.
-    ancestral: `p_sample_loop` even on the respaced (use_ddim) process - what `_g_test` calls, whatever `self.diffusion` is (:361)."""
+    ancestral: `p_sample_loop` even on the respaced (use_ddim) process - what `_g_test` calls, whatever `self.diffusion` is (:361).
+    y_extra: entries that replace / extend every window's y (the text-prompt trainer's style_feature and scales,
+    h3d_diffusion_new_trainer.py:553-558)."""
     overlap = pre_frames * squeeze
     round_l = pose_length - overlap                                     # :416
     roundt = (n_pose - overlap) // round_l                              # :414
@@ -26,6 +28,7 @@ def sample_long_ref(model_fn, audio, word, seed_latent, n_pose, x_T, step_noise,
         s = s[:, :pre_frames] if i == 0 else last[:, -pre_frames:]       # :428-431
         y = {"audio": a, "word": w, "seed": s, "mask": torch.ones(bs, 1, 1, pose_length, dtype=torch.bool),
              "style_feature": torch.zeros(bs, style_dim)}                # :433-442
+        y.update(y_extra or {})
         sample = loop(model_fn, (bs, 1536, 1, pose_length // squeeze), y, noise=x_T[i], step_noise=step_noise[i],
                       skip_timesteps=skip_timesteps)
         last = sample[:, :, 0, :].permute(0, 2, 1)                       # :458 (batched form of squeeze().permute(1,0))

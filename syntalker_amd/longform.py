@@ -28,10 +28,11 @@ def window_plan(n_pose: int, pose_length: int = 128, pre_frames: int = 4, squeez
 
 
 def window_inputs(i: int, audio, word, seed_latent, last_sample, round_l: int, pre_frames: int = 4, squeeze: int = 4,
-                  style_dim: int = 512):
+                  style_dim: int = 512, y_extra: dict | None = None):
     """model_kwargs['y'] of window i (trainer lines 419-442).  audio (B, n*533[, 2]), word (B, n) int64,
     seed_latent (B, n/squeeze, 1536) ground-truth latents (only its first pre_frames rows are ever used),
-    last_sample (B, 32, 1536) previous window's output or None."""
+    last_sample (B, 32, 1536) previous window's output or None.  y_extra: entries that replace / extend the window's y - the
+    text-prompt trainer's `style_feature` (a tensor or the per-body-part dict) and guidance scales (h3d_diffusion_new_trainer.py:553-558)."""
     bs = word.shape[0]
     lo, hi = i * round_l, (i + 1) * round_l + pre_frames * squeeze
     y = {
@@ -41,12 +42,13 @@ def window_inputs(i: int, audio, word, seed_latent, last_sample, round_l: int, p
         "mask": torch.ones(bs, 1, 1, hi - lo, dtype=torch.bool, device=word.device),
         "style_feature": torch.zeros(bs, style_dim, device=word.device),
     }
+    y.update(y_extra or {})
     return y
 
 
 def sample_long(diffusion, model, audio, word, seed_latent, n_pose: int | None = None, *, pose_length: int = 128,
                 pre_frames: int = 4, squeeze: int = 4, use_ddim: bool = False, style_dim: int = 512, noise_fn=None,
-                step_noise_fn=None, seed: int | None = None, skip_timesteps: int = 0, progress: bool = False):
+                step_noise_fn=None, seed: int | None = None, skip_timesteps: int = 0, progress: bool = False, y_extra: dict | None = None):
     """Returns latents (B, rounds*round_l/squeeze + pre_frames, 1536): window 0 whole, later windows without their
     first pre_frames rows (trainer lines 468-476).
     noise_fn(i) -> x_T of window i or None (library draws it); step_noise_fn(i) -> injected per-step noise or None;
@@ -57,7 +59,7 @@ def sample_long(diffusion, model, audio, word, seed_latent, n_pose: int | None =
     loop = diffusion.ddim_sample_loop if use_ddim else diffusion.p_sample_loop
     pieces, last = [], None
     for i in range(rounds):
-        y = window_inputs(i, audio, word, seed_latent, last, round_l, pre_frames, squeeze, style_dim)
+        y = window_inputs(i, audio, word, seed_latent, last, round_l, pre_frames, squeeze, style_dim, y_extra)
         kw = {}
         if step_noise_fn is not None:
             kw["step_noise"] = step_noise_fn(i)

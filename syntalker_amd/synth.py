@@ -174,3 +174,18 @@ def synth_pose_stats(seed: int = 23) -> dict:
     for name, dim in (("upper", 78), ("hands", 180), ("lower", 54), ("trans", 3)):
         out[name] = (0.2 * torch.randn(dim, generator=g), 0.5 + torch.rand(dim, generator=g))
     return out
+
+
+# ---- the text-prompt (h3d) trainer's test scenario (h3d_diffusion_new_trainer.py:465-615) ---------------------------------------
+H3D_PROMPTS = {"upper": "a person waves the right hand", "lower": "a person walks forward"}
+
+
+def synth_prompt_vector(prompt: str) -> torch.Tensor:
+    """(1, 256) stand-in for `textencoder(prompt).loc` (the TMR text encoder's mean, :489-511), seeded by the prompt's text."""
+    return torch.randn(1, 256, generator=_gen("prompt:" + prompt, 25))
+
+
+def synth_h3d_part_index() -> dict:
+    """Disjoint index sets over the 623 HumanML3D-style pose channels with the reference's counts per body part (156 / 360 / 107)."""
+    perm = torch.randperm(623, generator=_gen("h3d_parts", 26))
+    return {"upper": perm[:156].sort().values, "hands": perm[156:516].sort().values, "lower": perm[516:].sort().values}

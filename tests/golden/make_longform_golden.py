@@ -38,15 +38,15 @@ WINDOWS = 3
 N_POSE = 128 + (WINDOWS - 1) * 112 + 5            # 357: `remain = n % 8` (trainer :378-388) trims the take to 352 frames
 
 
-def lift_methods(*names):
+def lift_methods(*names, trainer="diffusion_rvqvae_trainer.py", extra_globals=None):
     """The reference's own method bodies, compiled from its file (no import of the trainer module)."""
-    path = os.path.join(REF, "diffusion_rvqvae_trainer.py")
+    path = os.path.join(REF, trainer)
     tree = ast.parse(open(path).read(), filename=path)
     cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "CustomTrainer")
     fns = [f for f in cls.body if isinstance(f, ast.FunctionDef) and f.name in names]
     assert sorted(f.name for f in fns) == sorted(names)
     from utils import rotation_conversions as rc
-    ns = {"torch": torch, "np": np, "rc": rc}
+    ns = {"torch": torch, "np": np, "rc": rc, **(extra_globals or {})}
     exec(compile(ast.Module(body=fns, type_ignores=[]), path, "exec"), ns)
     return [ns[n] for n in names]
 
@@ -135,5 +135,78 @@ def main():
     print("wrote longform_outputs.npz", sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB")
 
 
+def main_h3d():
+    """The text-prompt trainer's `_g_test` (h3d_diffusion_new_trainer.py:465-615): DDIM-50 (hard-coded there, :468-471) through
+    `TwoClassifierFreeSampleModel_Bodypart` (test(), :834) with an upper-body and a lower-body prompt - 9 denoiser evaluations per step -
+    over the same 3-window take, on a stand-in `self`: reference `denoiser_h3d.MDM` + reference wrapper, a `textencoder` that returns the
+    seeded (1, 256) vector of synth.synth_prompt_vector(prompt) as `.loc`, the 156 / 360 / 107-channel RVQ-VAEs, index masks over the 623 pose
+    channels.  Stored: per-window samples, the stitched latents handed to `latent2origin` and `rec_pose`."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    torch.set_grad_enabled(False)
+    _, RefMDMH3D, make_diff, cfgmod, data_path = import_reference()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from models.vq.model import RVQVAE
+    (g_test,) = lift_methods("_g_test", trainer="h3d_diffusion_new_trainer.py", extra_globals={
+        "create_gaussian_diffusion": make_diff, "ClassifierFreeSampleModel": cfgmod.ClassifierFreeSampleModel,
+        "TwoClassifierFreeSampleModel": cfgmod.TwoClassifierFreeSampleModel,
+        "ClassifierFreeSampleModel_Bodypart": cfgmod.ClassifierFreeSampleModel_Bodypart,
+        "TwoClassifierFreeSampleModel_Bodypart": cfgmod.TwoClassifierFreeSampleModel_Bodypart})
+    me = types.SimpleNamespace()
+    me.args = types.SimpleNamespace(pre_frames=4, pose_length=128, pose_dims=330, batch_size=1, prompt_scale=1.0, audio_scale=1.0,
+                                    upper_prompt=synth.H3D_PROMPTS["upper"], hands_prompt=None, lower_prompt=synth.H3D_PROMPTS["lower"])
+    me.joints = 55
+    me.model = cfgmod.TwoClassifierFreeSampleModel_Bodypart(synth.synth_fill_(RefMDMH3D(synth.default_args(data_path=data_path)).eval(), seed=0))
+    me.diffusion = make_diff()                                                       # (replaced by the DDIM-50 one inside _g_test)
+    vectors = {p: synth.synth_prompt_vector(p) for p in synth.H3D_PROMPTS.values()}       # (drawn before torch.randn is replaced)
+    me.textencoder = lambda prompt: types.SimpleNamespace(loc=vectors[prompt].clone())
+    me.vqvae_latent_scale = 10.0
+    idx = synth.synth_h3d_part_index()
+    me.joint_mask_upper, me.joint_mask_hands, me.joint_mask_lower = idx["upper"], idx["hands"], idx["lower"]
+    rec = {}
+    for part, dim in (("upper", 156), ("hands", 360), ("lower", 107)):
+        vq = synth.synth_fill_(RVQVAE(vq_args(), dim, 512, 512, 512, 2, 2, 512, 3, 3, "relu", None).eval(), seed=11)
+        orig = vq.latent2origin
+
+        def tapped(x, part=part, orig=orig):
+            rec[f"{part}.latent_in"] = x.clone()
+            out = orig(x)
+            rec[f"{part}.latent2origin"] = out[0].clone()
+            return out
+        vq.latent2origin = tapped
+        setattr(me, f"vq_model_{part}", vq)
+    take = synth.synth_long_take(N_POSE, seed=21)
+    data = {"tar_pose": torch.zeros(1, N_POSE, 623), "in_word": take["word"], "in_audio": take["audio"], "latent_in": take["latent"],
+            "tar_id": torch.zeros(1, N_POSE, 1, dtype=torch.long)}
+    K = 50
+    draws, samples = [], []
+    for w in range(WINDOWS):
+        xT, sn = synth.synth_long_noise(w, K, seed=24)
+        draws += [xT] + list(sn)                                   # (ddim_sample still DRAWS its noise at eta = 0, gaussian_diffusion.py:782)
+    real_make = make_diff
+
+    def tapped_make(**kw):
+        d = real_make(**kw)
+        loop = d.ddim_sample_loop
+        d.ddim_sample_loop = lambda *a, **k: (samples.append(loop(*a, **k)), samples[-1])[1]
+        return d
+    g_test.__globals__["create_gaussian_diffusion"] = tapped_make
+    with SeededDraws(draws) as sd:
+        res = g_test(me, data)
+    assert sd.k == len(draws) == WINDOWS * (K + 1) and len(samples) == WINDOWS, (sd.k, len(draws), len(samples))
+    out = {"n_pose": np.int64(N_POSE), "steps": np.int64(K), "windows": np.int64(WINDOWS), "samples": torch.stack(samples).numpy(),
+           "rec_pose": res["rec_pose"].numpy()}
+    for part in ("upper", "hands", "lower"):
+        out[f"{part}.latent_in"] = rec[f"{part}.latent_in"].numpy()
+        out[f"{part}.latent2origin"] = rec[f"{part}.latent2origin"].numpy()
+    for k, v in out.items():
+        print(k, getattr(v, "shape", v), float(np.abs(v).mean()) if getattr(v, "ndim", 0) else "")
+    np.savez_compressed(os.path.join(HERE, "longform_h3d_outputs.npz"), **out)
+    print("wrote longform_h3d_outputs.npz", sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    if "h3d" in sys.argv[1:] or len(sys.argv) == 1:
+        main_h3d()
+    if "beatx" in sys.argv[1:] or len(sys.argv) == 1:
+        main()

@@ -108,6 +108,78 @@ def test_longform_oracle_vs_reference_g_test():
     assert rel_l2(parts["lower"], fx["lower.latent2origin"][..., :-3]) < 5e-6
 
 
+# the text-prompt trainer's `_g_test` (h3d_diffusion_new_trainer.py:465-615): DDIM-50 through TwoClassifierFreeSampleModel_Bodypart, upper + lower prompts
+def _h3d_fixture():
+    import numpy as np
+    fx = np.load(os.path.join(REPO, "tests", "golden", "longform_h3d_outputs.npz"))
+    n, K, W = int(fx["n_pose"]), int(fx["steps"]), int(fx["windows"])
+    take = synth.synth_long_take(n, seed=21)
+    draws = [synth.synth_long_noise(w, K, seed=24) for w in range(W)]
+    parts = {"upper_mask": synth.synth_prompt_vector(synth.H3D_PROMPTS["upper"]), "hands_mask": None,
+             "lower_mask": synth.synth_prompt_vector(synth.H3D_PROMPTS["lower"])}
+    return fx, n, take, [d[0] for d in draws], [d[1] for d in draws], parts
+
+
+def test_h3d_longform_oracle_vs_reference_g_test():
+    """Guided long-form sampling of the text-prompt configuration: the oracle (guidance_ref + longform_ref over the folded h3d forward)
+    against what the reference's own `_g_test` produced (9 evaluations per DDIM step, three windows, seed carried between them)."""
+    from oracle import denoiser_ref as dr
+    from oracle import guidance_ref as gr
+    from oracle.longform_ref import sample_long_ref
+    from tests.conftest import rel_l2
+    from tests.refmodel import synth_state_dict
+    fx, n, take, xs, sn, parts = _h3d_fixture()
+    sd = synth_state_dict("h3d")
+    fw = dr.fold_weights(sd, variant="h3d")
+    te = dr.time_table(sd, fw)
+    cache = {}
+
+    def fn(x, t, y):                     # conditioning per (flags, style, window), hoisted like the build does: the loop's 1350 calls share 15
+        st = y["style_feature"]
+        key = (bool(y.get("uncond")), bool(y.get("uncond_audio")), None if y.get("uncond") else tuple(st.flatten()[:3].tolist()),
+               float(y["seed"].flatten()[:16].sum()), float(y["audio"][0, :64].sum()))
+        if key not in cache:
+            cache[key] = dr.clip_conditioning(sd, y, fw, variant="h3d")
+        return dr.mdm_forward_folded(sd, fw, cache[key], te, x, t)
+    with torch.no_grad():
+        lat = sample_long_ref(lambda x, t, y: gr.two_cfg_bodypart(fn, x, t, y), take["audio"], take["word"], take["latent"], n, xs, sn,
+                              use_ddim=True, y_extra={"style_feature": parts, "scale": torch.ones(1)})
+    assert lat.shape == (1, 88, 1536) and len(cache) == 15          # 5 distinct (flags, style) sets x 3 windows; the reference evaluates 9 per step
+    for k, part in enumerate(("upper", "hands", "lower")):
+        assert rel_l2(lat[..., 512 * k:512 * (k + 1)] * 10.0, fx[f"{part}.latent_in"]) < 2e-5, part
+
+
+@pytest.mark.gpu
+def test_h3d_guided_sample_long_vs_reference_g_test():
+    """The product on the same scenario: `sample_long` with the body-part wrapper (4 unique variants as one fused batch per step),
+    DDIM-50, the 156 / 360 / 107-channel RVQ-VAE decode - against the reference's `_g_test` fixture."""
+    from syntalker_amd import guidance, rvqvae
+    from syntalker_amd.denoiser_h3d import MDM
+    from syntalker_amd.process import create_gaussian_diffusion
+    from tests.conftest import rel_l2
+    from tests.refmodel import synth_state_dict
+    dev = "cuda"
+    fx, n, take, xs, sn, parts = _h3d_fixture()
+    m = MDM(synth.default_args()).eval()
+    m.load_state_dict(synth_state_dict("h3d"), strict=False)
+    m = m.to(dev)
+    wrapped = guidance.TwoClassifierFreeSampleModel_Bodypart(m)
+    d = create_gaussian_diffusion(use_ddim=True)
+    dparts = {k: (None if v is None else v.to(dev)) for k, v in parts.items()}
+    got = longform.sample_long(d, wrapped, take["audio"].to(dev), take["word"].to(dev), take["latent"].to(dev), n, use_ddim=True,
+                               noise_fn=lambda i: xs[i].to(dev), step_noise_fn=lambda i: sn[i],
+                               y_extra={"style_feature": dparts, "scale": torch.ones(1, device=dev)}).cpu()
+    want = torch.cat([torch.from_numpy(fx[f"{p}.latent_in"]) for p in ("upper", "hands", "lower")], dim=-1) / 10.0
+    e = rel_l2(got, want)
+    print(f"guided 3-window take vs the reference's h3d _g_test: stitched latents rel-L2 {e:.3e}")
+    assert got.shape == (1, 88, 1536) and e < 3e-2
+    for k, (p, dim) in enumerate((("upper", 156), ("hands", 360), ("lower", 107))):
+        vq = rvqvae.build(dim).eval()
+        vq.load_state_dict(synth.synth_vq_state_dict(dim))
+        pose = vq.to(dev).latent2origin(torch.from_numpy(fx[f"{p}.latent_in"]).to(dev))[0].cpu()
+        assert rel_l2(pose, fx[f"{p}.latent2origin"]) < 3e-2, p
+
+
 @pytest.mark.gpu
 def test_sample_long_and_decode_vs_reference_g_test():
     """The product's `sample_long` + `decode_take` against the fixture the reference's `_g_test` wrote: same take, same x_T and
