@@ -20,6 +20,7 @@ scale-by-keep (timm_transformer/transformer.py:21-38), h3d Bernoulli(0.3) style 
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import torch
 import torch.nn as nn
@@ -170,6 +171,7 @@ class HipLinearFn(torch.autograd.Function):
             y = hip_matmul_nt(xb, w, b)
         ctx.xt = xt
         ctx.save_for_backward(xb, w)
+        ctx.owners = (w, b)
         ctx.has_bias = b is not None
         ctx.in_shape = x.shape
         return y.reshape(*x.shape[:-1], w.shape[0])
@@ -205,10 +207,10 @@ class HipLinearFn(torch.autograd.Function):
             # dy . W and dy^T . x - independent, half a chip each - as one launch, which also adds the bias gradient's partial sums up
             wt = ctx.pack_t if ctx.pack_t is not None else _pack_t(w, K, N)
             dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
-            dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+            dw = _grad_out(ctx.owners[0], (N, K))
             sum_here = part is not None and db is None
             if sum_here:
-                db = torch.empty(N, dtype=torch.float32, device=dy.device)
+                db = _grad_out(ctx.owners[1], (N,))
             _lib.check(_lib.load().syn_linear_pair(dyb.data_ptr(), wt.data_ptr(), M, K, N, dx.data_ptr(),
                                                    dybt.data_ptr(), (ctx.xt if ctx.xt is not None else _pack_t(xb, K, M)).data_ptr(), N, K, M, dw.data_ptr(),
                                                    _lib.ptr(part) if sum_here else None, M // 64, N, _lib.ptr(db) if sum_here else None,
@@ -244,6 +246,7 @@ class EmbeddingFn(torch.autograd.Function):
     def forward(ctx, ids, weight):
         ctx.save_for_backward(ids)
         ctx.wshape, ctx.wdtype = weight.shape, weight.dtype
+        ctx.owner = weight
         return weight.detach()[ids]
 
     @staticmethod
@@ -252,7 +255,7 @@ class EmbeddingFn(torch.autograd.Function):
         V, D = ctx.wshape
         idc = ids.reshape(-1).to(torch.int64).contiguous()
         dyc = dy.reshape(-1, D).float().contiguous()
-        dw = torch.empty(V, D, device=dy.device, dtype=torch.float32)
+        dw = _grad_out(ctx.owner, (V, D))
         lib = _lib.load()
         first = True
         for lo in range(0, idc.numel(), 8192):                  # (the bench's 32 clips x 128 frames are one call)
@@ -292,6 +295,40 @@ def lin(x, module: nn.Linear):
 
 # (the fp32 block ops - LayerNorm, attention, GELU - run on the hand-written kernels below; their PyTorch-op twins live in
 # tests/test_gpu_kernels.py::test_training_block_ops_vs_torch_autograd, which checks them against each other to 1e-5)
+
+
+def _grad_out(param, shape=None):
+    """The tensor a parameter's gradient is written into.  Normally a fresh buffer.  When the parameter carries a bound gradient buffer
+    (`bind_grad_buffers`: DDP's bucket view of it, inside `GraphedTrainStep`) and holds no gradient yet, a NEW tensor object over that
+    buffer: autograd's AccumulateGrad adopts it without a copy, and DDP's reducer, finding the gradient already inside its bucket, skips its
+    per-parameter copy-and-divide launch (169 launches of ~2 us per step; the division moves into the collective, `_avg_comm_hook`)."""
+    shape = tuple(shape if shape is not None else param.shape)
+    buf = getattr(param, "_syn_grad_buf", None) if param is not None else None
+    if (buf is not None and param.grad is None and buf.dtype is torch.float32 and buf.is_contiguous() and buf.numel() == math.prod(shape)
+            and torch.is_grad_enabled() is False):
+        return buf.view(shape)
+    dev = param.device if param is not None else None
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+def bind_grad_buffers(model) -> int:
+    """Make the CURRENT gradient tensors of the model's parameters the buffers their next gradients are written into (see `_grad_out`).
+    Under `make_ddp(..., capturable=True)` those are views of the reducer's buckets once it has rebuilt them (after its second iteration).
+    Only valid while every step starts from `zero_grad(set_to_none=True)` - `GraphedTrainStep` - since a bound buffer is overwritten, not
+    accumulated into (a parameter that still holds a gradient is never given its bound buffer).  Returns the number of parameters bound."""
+    n = 0
+    for p in model.parameters():
+        g = p.grad
+        if g is not None and g.dtype is torch.float32 and g.is_contiguous() and g.shape == p.shape:
+            p._syn_grad_buf = g
+            n += 1
+    return n
+
+
+def unbind_grad_buffers(model):
+    for p in model.parameters():
+        if hasattr(p, "_syn_grad_buf"):
+            del p._syn_grad_buf
 
 
 def _f32c(t):
@@ -443,7 +480,7 @@ def _lin_fwd(xb, w, b, res=None, scale=None, rows_per_scale=1, gelu_out=None):
     return y, (xt, wt)          # what the backward takes: x^T and W^T fragments as of THIS forward (the step's pack cache may have moved on by then)
 
 
-def _lin_bwd(dy2, packs, w, has_bias, scale=None, rows_per_scale=1, gelu_pre=None):
+def _lin_bwd(dy2, packs, w, has_bias, scale=None, rows_per_scale=1, gelu_pre=None, owners=(None, None)):
     """fp32 dy [M][N] (contiguous) -> dx [M][K], dW [N][K], db [N] of y = x W^T + b; dy is first multiplied by its rows' factors
     (scale) or by GELU'(gelu_pre) (dy taken behind a GELU of y).  packs: (x^T fragments, W^T fragments) from `_lin_fwd`."""
     xt, wt = packs
@@ -457,9 +494,9 @@ def _lin_bwd(dy2, packs, w, has_bias, scale=None, rows_per_scale=1, gelu_pre=Non
     _lib.check(lib.syn_linear_bwd_prep(dy2.data_ptr(), M, N, _lib.ptr(scale), rows_per_scale, _lib.ptr(gelu_pre), dyb.data_ptr(), dybt.data_ptr(), _lib.ptr(part),
                                        None, None, st), "syn_linear_bwd_prep")
     dx = torch.empty(M, K, dtype=torch.float32, device=dev)
-    dw = torch.empty(N, K, dtype=torch.float32, device=dev)
+    dw = _grad_out(owners[0], (N, K)) if owners[0] is not None else torch.empty(N, K, dtype=torch.float32, device=dev)
     in_pair = has_bias and M <= 2048
-    db = torch.empty(N, dtype=torch.float32, device=dev) if in_pair else None
+    db = (_grad_out(owners[1], (N,)) if owners[1] is not None else torch.empty(N, dtype=torch.float32, device=dev)) if in_pair else None
     _lib.check(lib.syn_linear_pair(dyb.data_ptr(), wt.data_ptr(), M, K, N, dx.data_ptr(), dybt.data_ptr(), xt.data_ptr(), N, K, M, dw.data_ptr(),
                                    _lib.ptr(part) if in_pair else None, M // 64, N, _lib.ptr(db), st), "syn_linear_pair")
     if has_bias and db is None:
@@ -476,10 +513,11 @@ def _ln_rows_bf16(hc, g, b):
     return zb, mean, rstd
 
 
-def _ln_bwd_rows(dz, hc, g, mean, rstd, add):
+def _ln_bwd_rows(dz, hc, g, mean, rstd, add, owners=(None, None)):
     rows = hc.numel() // 512
     dh = torch.empty_like(hc)
-    dg, db = torch.empty(512, device=hc.device), torch.empty(512, device=hc.device)
+    dg = _grad_out(owners[0], (512,)) if owners[0] is not None else torch.empty(512, device=hc.device)
+    db = _grad_out(owners[1], (512,)) if owners[1] is not None else torch.empty(512, device=hc.device)
     scratch = torch.empty((rows + 15) // 16 * 1024, device=hc.device)
     _lib.check(_lib.load().syn_ln_bwd(dz.data_ptr(), hc.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(), add.data_ptr(), dh.data_ptr(),
                                       dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), rows, _lib.current_stream(hc.device)), "syn_ln_bwd")
@@ -501,6 +539,7 @@ class AttnBranchFn(torch.autograd.Function):
         ctx.save_for_backward(hc, gc, mean, rstd, qkv, wqkv, wproj, factor)
         ctx.packs = (xt1, xt2)
         ctx.bias = (bqkv is not None, bproj is not None)
+        ctx.owners = (g, b, wqkv, bqkv, wproj, bproj)       # the parameter objects (their bound gradient buffers, `_grad_out`)
         return out.view(B, T, 512)
 
     @staticmethod
@@ -509,11 +548,12 @@ class AttnBranchFn(torch.autograd.Function):
         xt1, xt2 = ctx.packs
         B, T, _ = hc.shape
         d = _f32c(dout).view(B * T, 512)
-        do, dwp, dbp = _lin_bwd(d, xt2, wproj, ctx.bias[1], factor, T)
+        og, ob, owq, obq, owp, obp = ctx.owners
+        do, dwp, dbp = _lin_bwd(d, xt2, wproj, ctx.bias[1], factor, T, owners=(owp, obp))
         dqkv = torch.empty_like(qkv)
         _lib.check(_lib.load().syn_attn_bwd(qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), B, _lib.current_stream(d.device)), "syn_attn_bwd")
-        dz, dwq, dbq = _lin_bwd(dqkv, xt1, wqkv, ctx.bias[0])
-        dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d)
+        dz, dwq, dbq = _lin_bwd(dqkv, xt1, wqkv, ctx.bias[0], owners=(owq, obq))
+        dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d, owners=(og, ob))
         return dh.view(B, T, 512), dg, db, dwq, dbq, dwp, dbp, None
 
 
@@ -535,6 +575,7 @@ class MlpBranchFn(torch.autograd.Function):
         ctx.save_for_backward(hc, gc, mean, rstd, pre, w1, w2, factor)
         ctx.packs = (xt1, xt2)
         ctx.bias = (b1 is not None, b2 is not None)
+        ctx.owners = (g, b, w1, b1, w2, b2)
         return out.view(B, T, 512)
 
     @staticmethod
@@ -543,14 +584,15 @@ class MlpBranchFn(torch.autograd.Function):
         xt1, xt2 = ctx.packs
         B, T, _ = hc.shape
         d = _f32c(dout).view(B * T, 512)
-        da, dw2, db2 = _lin_bwd(d, xt2, w2, ctx.bias[1], factor, T)
+        og, ob, ow1, ob1, ow2, ob2 = ctx.owners
+        da, dw2, db2 = _lin_bwd(d, xt2, w2, ctx.bias[1], factor, T, owners=(ow2, ob2))
         if GELU_FUSED & 2:
-            dz, dw1, db1 = _lin_bwd(da, xt1, w1, ctx.bias[0], gelu_pre=pre)    # GELU' in the operand pass of fc1's backward
+            dz, dw1, db1 = _lin_bwd(da, xt1, w1, ctx.bias[0], gelu_pre=pre, owners=(ow1, ob1))    # GELU' in the operand pass of fc1's backward
         else:
             dpre = torch.empty_like(pre)
             _lib.check(_lib.load().syn_gelu_bwd(pre.data_ptr(), da.data_ptr(), dpre.data_ptr(), pre.numel(), _lib.current_stream(d.device)), "syn_gelu_bwd")
-            dz, dw1, db1 = _lin_bwd(dpre, xt1, w1, ctx.bias[0])
-        dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d)
+            dz, dw1, db1 = _lin_bwd(dpre, xt1, w1, ctx.bias[0], owners=(ow1, ob1))
+        dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d, owners=(og, ob))
         return dh.view(B, T, 512), dg, db, dw1, db1, dw2, db2, None
 
 
@@ -681,6 +723,7 @@ class ConvSplitFn(torch.autograd.Function):
         xc, y = ConvSplitFn.run(x, w, stride, pad, want_stats=True)
         ctx.save_for_backward(xc, w)
         ctx.geom = (stride, pad)
+        ctx.owner = getattr(w, "_syn_owner", None)        # the Conv1d's (Cout, Cin, 15) parameter behind the 4-d view (`_conv_raw`)
         return y
 
     @staticmethod
@@ -724,7 +767,7 @@ class ConvSplitFn(torch.autograd.Function):
                 n, _, _, l = x.shape
                 l_out, kts = gy.shape[-1], -(-15 // stride) * stride
                 ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l_out, stride * cin) * cout * kts * cin, device=x.device, dtype=torch.float32)
-                gw = torch.empty(cout, cin, 1, 15, device=x.device, dtype=torch.float32)
+                gw = _grad_out(ctx.owner, (cout, cin, 1, 15)) if ctx.owner is not None else torch.empty(cout, cin, 1, 15, device=x.device, dtype=torch.float32)
                 _conv_terms(2)
                 _lib.check(lib.syn_conv1d_train_wgrad(x.data_ptr(), gy.data_ptr(), n, l, cin, stride, pad, cout, ws.data_ptr(), gw.data_ptr(),
                                                       _lib.current_stream(x.device)), "syn_conv1d_train_wgrad")
@@ -750,6 +793,7 @@ class ConvFirstFn(torch.autograd.Function):
                                             _lib.current_stream(wav.device)), "syn_conv1d_first_fwd")
         ctx.save_for_backward(wavc)
         ctx.geom = (stride, pad, w.shape, w.dtype)
+        ctx.owner = w
         return y
 
     @staticmethod
@@ -762,7 +806,7 @@ class ConvFirstFn(torch.autograd.Function):
         n, l_in, cin = wavc.shape
         gy = gy.contiguous(memory_format=torch.channels_last)
         ws = torch.empty(lib.syn_conv1d_first_parts(n, gy.shape[-1]) * 64 * cin * 15, device=gy.device, dtype=torch.float32)
-        gw = torch.empty(64, cin, 15, device=gy.device, dtype=torch.float32)
+        gw = _grad_out(ctx.owner, (64, cin, 15))
         _lib.check(lib.syn_conv1d_first_wgrad(wavc.data_ptr(), gy.data_ptr(), n, l_in, cin, stride, pad, ws.data_ptr(), gw.data_ptr(),
                                               _lib.current_stream(gy.device)), "syn_conv1d_first_wgrad")
         return None, gw.reshape(wshape).to(wdtype), None, None
@@ -903,7 +947,9 @@ def _conv_raw(conv, x):
     if x.dim() != 4 or conv.kernel_size[0] != 15 or conv.dilation[0] != 1:
         raise _unsupported_conv("forward", cin, stride, pad, cout)
     if (cin, stride, cout) in ConvSplitFn.SUPPORTED and pad % stride == 0:
-        return ConvSplitFn.apply(x, conv.weight.unsqueeze(2), stride, pad)
+        w4 = conv.weight.unsqueeze(2)
+        w4._syn_owner = conv.weight
+        return ConvSplitFn.apply(x, w4, stride, pad)
     if cin in (1, 2) and cout == 64 and 1 <= stride <= 8 and not x.requires_grad:
         n, _, _, l = x.shape                                                 # channels_last (N, cin, 1, L) = the waveform (N, L, cin)
         return ConvFirstFn.apply(x.permute(0, 2, 3, 1).reshape(n, l, cin), conv.weight, stride, pad)
@@ -1044,6 +1090,8 @@ def unused_in_forward(model) -> tuple:
     return ("embed_style", "uncon_audio_embeddings") if getattr(m, "variant", "beatx") == "h3d" else ("embed_style",)
 
 
+DDP_AVG_HOOK = bool(int(_os.environ.get("SYN_DDP_AVG_HOOK", "1")))
+DIRECT_GRADS = bool(int(_os.environ.get("SYN_DDP_DIRECT_GRADS", "1")))     # captured DDP step: gradients written into the buckets (A/B: 0)
 DDP_BUCKET_MB = 32      # 118 MB of fp32 gradients -> 4 all-reduces (+ PyTorch's small first bucket, which starts the stream of collectives
                         # as soon as the output projection's gradients exist).  xGMI is point-to-point, a ring all-reduce is per-link
                         # bound (7 links x ~153 GB/s per GPU): at 8 GPUs a 32 MB bucket is ~0.4 ms on the wire, short enough to overlap
@@ -1066,8 +1114,26 @@ def make_ddp(model, local_rank: int | None = None, sync_bn: bool = False, captur
             if n.split(".")[0] in frozen:
                 p.requires_grad_(False)
     dev_ids = None if local_rank is None else [local_rank]
-    return DDP(model, device_ids=dev_ids, broadcast_buffers=False, find_unused_parameters=not capturable,
-               gradient_as_bucket_view=True, bucket_cap_mb=DDP_BUCKET_MB)
+    ddp = DDP(model, device_ids=dev_ids, broadcast_buffers=False, find_unused_parameters=not capturable,
+              gradient_as_bucket_view=True, bucket_cap_mb=DDP_BUCKET_MB)
+    if capturable and DDP_AVG_HOOK:
+        ddp.register_comm_hook(None, _avg_comm_hook)
+    return ddp
+
+
+def _avg_comm_hook(state, bucket):
+    """DDP communication hook of the captured step: ONE collective per bucket that also averages (RCCL's `ncclAvg`), so the reducer neither
+    divides a gradient as it copies it into the bucket nor - for a gradient that was written into the bucket directly (`_grad_out`) -
+    launches anything per parameter.  Backends without an averaging reduction (gloo, the CPU tests): torch's default hook (divide the
+    bucket, all-reduce)."""
+    import torch.distributed as dist
+    buf = bucket.buffer()
+    if dist.get_backend() == "nccl":
+        op = dist.ReduceOp.AVG if dist.get_world_size() > 1 else dist.ReduceOp.SUM      # (one rank: RCCL's in-place SUM launches nothing, AVG a pre-multiply kernel)
+        fut = dist.all_reduce(buf, op=op, async_op=True).get_future()
+        return fut.then(lambda f: f.value()[0])
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+    return default_hooks.allreduce_hook(dist.group.WORLD, bucket)
 
 
 def ddp_bucket_sizes(ddp) -> list[int]:
@@ -1238,8 +1304,13 @@ class GraphedTrainStep:
             # parameters, buffers (BatchNorm statistics) and the optimizer's state are put back IN PLACE afterwards (the capture
             # holds their addresses), so the first replay is update number 1 of the run - or number n + 1 after a resume.
             snap = None if keep_warmup_updates else self._snapshot()
-            for _ in range(warmup):
+            self.bound = 0
+            for i in range(warmup):
                 self._body()
+                if i == 2 and hasattr(model, "reducer") and DIRECT_GRADS and DDP_AVG_HOOK:
+                    # DDP has rebuilt its buckets by now and every parameter's .grad is a view of one: from here on the backward kernels
+                    # write weight gradients straight into those views (the remaining warm-up iterations already run that way)
+                    self.bound = bind_grad_buffers(model)
         torch.cuda.current_stream(x0.device).wait_stream(side)
         mode = "global"
         if torch.distributed.is_available() and torch.distributed.is_initialized():
@@ -1302,6 +1373,8 @@ class GraphedTrainStep:
         if getattr(self, "graph", None) is not None:
             torch.cuda.synchronize()
             self.graph, self.loss = None, None
+            if getattr(self, "bound", 0):
+                unbind_grad_buffers(self.model)
 
     def __del__(self):
         try:
