@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define SYN_ABI_VERSION 5     /* 5: training block entry points - bf16 outputs of syn_ln_fwd / syn_gelu_fwd / syn_attn_fwd, syn_linear_res (residual + DropPath factor
+#define SYN_ABI_VERSION 6     /* 6: pose formats either side of the RVQ-VAEs - syn_axis_angle_to_rot6d, syn_rot6d_to_axis_angle;
+                                * 5: training block entry points - bf16 outputs of syn_ln_fwd / syn_gelu_fwd / syn_attn_fwd, syn_linear_res (residual + DropPath factor
                                 * in the GEMM's epilogue), syn_linear_bwd_prep row_scale, syn_linear_pair bias_grad;
                                 * 4: syn_model.tape carries its first 4 chunks again behind the last (no wrap test in k_seq's weight stream);
                                 * 3: training entry points reworked (syn_ln_bwd add, syn_bn_act_* ws_chunks / beta, syn_conv1d_train_fwd bn_part,
@@ -404,6 +405,15 @@ int syn_vq_latent2origin(const syn_vq_model* m, const float* latent, int32_t cli
 /* RVQVAE.forward_decoder (:86-93): indices [clips][t_lat][n_q] -> pose fp32 [clips][4 t_lat][pose_dim] */
 int syn_vq_forward_decoder(const syn_vq_model* m, const int32_t* idx, int32_t n_q, int32_t clips, int32_t t_lat, void* workspace,
                            float* pose_out, void* stream);
+
+/* ---- pose formats either side of the RVQ-VAEs (diffusion_rvqvae_trainer.py:257-272 `_load_data`, :503-531 `_g_test`) ---------------------------
+ * SMPL-X joint rotations: axis-angle fp32 [n_joints][3] <-> the 6D representation fp32 [n_joints][6] (first two rows of the rotation matrix).
+ * syn_axis_angle_to_rot6d replaces rc.matrix_to_rotation_6d(rc.axis_angle_to_matrix(x)) (utils/rotation_conversions.py:416-430, 448-477, 36-64,
+ * 535-550); syn_rot6d_to_axis_angle replaces rc.matrix_to_axis_angle(rc.rotation_6d_to_matrix(x)) (:511-533, 96-118, 432-446, 480-508).  The
+ * reference's arithmetic operation for operation (small-angle series below 1e-6 rad, sqrt-of-positive-part + copysign quaternion); in and
+ * out may not alias; n_joints = 0 is a no-op. */
+int syn_axis_angle_to_rot6d(const float* axis_angle, int64_t n_joints, float* rot6d, void* stream);
+int syn_rot6d_to_axis_angle(const float* rot6d, int64_t n_joints, float* axis_angle, void* stream);
 
 /* ResidualVQ.forward in eval mode (models/vq/residual_vq.py:91-140 over quantizer.py:62-69,143-171), fp32, 6 layers
  * of 512 codes x 512 dims: x [rows][512] -> q_f32 / q_bf16 [rows][512] (sum of the straight-through outputs), idx

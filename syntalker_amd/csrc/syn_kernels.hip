@@ -1967,6 +1967,7 @@ int launch_stack(const SArgs& a, int mt, hipStream_t s) {
 #include "syn_wavenc.inc"
 #include "syn_train.inc"
 #include "syn_rvq.inc"
+#include "syn_pose.inc"
 
 // ---- WavEncoder forward: lengths, workspace layout and the 12 launches ----------------------------------------
 struct WavPlan {
@@ -2383,6 +2384,22 @@ int syn_randn(float* out, int64_t n, uint64_t seed, uint64_t stream_id, int64_t 
                        stream_id, (long)(first_index / 4));
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_randn launch", e);
+}
+
+int syn_axis_angle_to_rot6d(const float* axis_angle, int64_t n_joints, float* rot6d, void* stream) {
+    if (!axis_angle || !rot6d || n_joints < 0) return fail_msg("syn_axis_angle_to_rot6d: null pointer / negative count");
+    if (n_joints == 0) return 0;
+    hipLaunchKernelGGL(pose::k_aa_to_rot6d, dim3((unsigned)((n_joints + 255) / 256)), dim3(256), 0, (hipStream_t)stream, axis_angle, (long)n_joints, rot6d);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_aa_to_rot6d launch", e);
+}
+
+int syn_rot6d_to_axis_angle(const float* rot6d, int64_t n_joints, float* axis_angle, void* stream) {
+    if (!axis_angle || !rot6d || n_joints < 0) return fail_msg("syn_rot6d_to_axis_angle: null pointer / negative count");
+    if (n_joints == 0) return 0;
+    hipLaunchKernelGGL(pose::k_rot6d_to_aa, dim3((unsigned)((n_joints + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rot6d, (long)n_joints, axis_angle);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_rot6d_to_aa launch", e);
 }
 
 int syn_test_gemm(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k,

@@ -189,3 +189,12 @@ def synth_h3d_part_index() -> dict:
     """Disjoint index sets over the 623 HumanML3D-style pose channels with the reference's counts per body part (156 / 360 / 107)."""
     perm = torch.randperm(623, generator=_gen("h3d_parts", 26))
     return {"upper": perm[:156].sort().values, "hands": perm[156:516].sort().values, "lower": perm[516:].sort().values}
+
+
+def synth_pose_clip(batch: int, n_pose: int, seed: int = 27) -> dict:
+    """What the dataloader hands `_load_data` (diffusion_rvqvae_trainer.py:245-249): axis-angle poses (B, n, 165) - rotations up to ~1.5 rad,
+    a few exactly zero (the small-angle branch of the conversion) - and the root velocity (B, n, 3)."""
+    g = _gen("pose_clip", seed)
+    pose = 0.5 * torch.randn(batch, n_pose, 165, generator=g)
+    pose[:, ::7, 9:12] = 0.0
+    return {"pose": pose, "trans_v": 0.05 * torch.randn(batch, n_pose, 3, generator=g)}

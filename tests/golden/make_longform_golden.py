@@ -205,7 +205,40 @@ def main_h3d():
     print("wrote longform_h3d_outputs.npz", sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB")
 
 
+def main_loaddata():
+    """`CustomTrainer._load_data` (diffusion_rvqvae_trainer.py:244-295), lifted and run the same way: axis-angle poses -> 6D per body part ->
+    normalised -> `RVQVAE.map2latent` x 3 -> `latent_in`, the x_0 the diffusion trains on and the seed rows the sampler starts from."""
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    import_reference()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from models.vq.model import RVQVAE
+    (load_data,) = lift_methods("_load_data")
+    me = types.SimpleNamespace(rank="cpu", joints=55, use_trans=True)
+    me.args = types.SimpleNamespace(pose_norm=True, vqvae_latent_scale=5.0, use_motionclip=False)
+    masks = synth.synth_joint_masks()
+    me.joint_mask_upper, me.joint_mask_hands, me.joint_mask_lower = masks["upper"], masks["hands"], masks["lower"]
+    stats = synth.synth_pose_stats()
+    me.trans_mean, me.trans_std = stats["trans"]
+    (me.mean_upper, me.std_upper), (me.mean_hands, me.std_hands), (me.mean_lower, me.std_lower) = stats["upper"], stats["hands"], stats["lower"]
+    me.vq_model_face = types.SimpleNamespace(map2latent=lambda x: torch.zeros(x.shape[0], x.shape[1] // 4, 256))     # (not part of latent_in)
+    for part, dim in PARTS:
+        setattr(me, f"vq_model_{part}", synth.synth_fill_(RVQVAE(vq_args(), dim, 512, 512, 512, 2, 2, 512, 3, 3, "relu", None).eval(), seed=11))
+    n = 64
+    clip = synth.synth_pose_clip(2, n, seed=27)
+    res = load_data(me, {"pose": torch.cat([clip["pose"], torch.zeros(2, n, 4)], dim=-1), "trans": torch.zeros(2, n, 3), "trans_v": clip["trans_v"],
+                         "facial": torch.zeros(2, n, 100), "audio": torch.zeros(2, n * 533, 2), "word": torch.zeros(2, n, dtype=torch.long),
+                         "beta": torch.zeros(2, n, 300), "id": torch.zeros(2, n, 1)})
+    out = {k: res[k].numpy() for k in ("tar_pose_upper", "tar_pose_hands", "tar_pose_lower", "latent_in", "tar_pose_6d")}
+    for k, v in out.items():
+        print(k, v.shape, float(np.abs(v).mean()))
+    np.savez_compressed(os.path.join(HERE, "loaddata_outputs.npz"), **out)
+    print("wrote loaddata_outputs.npz", sum(v.nbytes for v in out.values()) // 1024, "KiB")
+
+
 if __name__ == "__main__":
+    if "loaddata" in sys.argv[1:] or len(sys.argv) == 1:
+        main_loaddata()
     if "h3d" in sys.argv[1:] or len(sys.argv) == 1:
         main_h3d()
     if "beatx" in sys.argv[1:] or len(sys.argv) == 1:

@@ -212,7 +212,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     exported = {l.split()[-1] for l in nm.splitlines() if " T syn_" in l}
     diagnostics = set(re.findall(r"^\s*void\s+(syn_debug_[a-z_0-9]+)\s*\(", header, flags=re.M))
     assert len(diagnostics) == 6 and exported == declared | diagnostics, exported ^ (declared | diagnostics)
-    assert lib.syn_version() == 5 == _lib.ABI_VERSION
+    assert lib.syn_version() == 6 == _lib.ABI_VERSION
     # struct sizes exactly as the C compiler lays out include/syn_hip.h (gcc, same ABI as hipcc's host side)
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as td:

@@ -168,6 +168,79 @@ def test_two_rank_ddp_prepared_for_graph_capture(tmp_path):
         assert torch.allclose(got["grads"][k], ref, atol=1e-6), k
 
 
+def _ddp_direct_grad_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from syntalker_amd import training
+
+        class LinFn(torch.autograd.Function):                       # a backward that asks `training._grad_out` where to write, like the HIP ones
+            @staticmethod
+            def forward(ctx, x, w):
+                ctx.save_for_backward(x)
+                ctx.owner = w
+                return x @ w.detach().t()
+
+            @staticmethod
+            def backward(ctx, dy):
+                (x,) = ctx.saved_tensors
+                dw = training._grad_out(ctx.owner, ctx.owner.shape)
+                torch.mm(dy.t(), x, out=dw)
+                return dy @ ctx.owner.detach(), dw
+
+        class Net(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                torch.manual_seed(0)
+                self.w1, self.w2 = torch.nn.Parameter(torch.randn(5, 6) * 0.3), torch.nn.Parameter(torch.randn(3, 5) * 0.3)
+                self.embed_style = torch.nn.Linear(6, 4)
+
+            def forward(self, x):
+                return LinFn.apply(torch.tanh(LinFn.apply(x, self.w1)), self.w2)
+        data = torch.randn(8, 6, generator=torch.Generator().manual_seed(7))
+        lo, hi = shard_range(8, rank, world)
+        w = make_ddp_net = training.make_ddp(Net(), capturable=True)      # averaging comm hook registered (gloo: torch's divide + all-reduce)
+        log = []
+        for it in range(5):
+            w.zero_grad(set_to_none=True)                                 # what GraphedTrainStep does in front of every backward
+            (w(data[lo:hi]) ** 2).mean().backward()
+            if it == 2:
+                assert training.bind_grad_buffers(w) == 2                 # buckets rebuilt: .grad is a bucket view from here on
+            bufs = {k: getattr(p, "_syn_grad_buf", None) for k, p in w.module.named_parameters()}
+            log.append({"grads": {k: p.grad.clone() for k, p in w.module.named_parameters() if p.grad is not None},
+                        "aliased": all(bufs[k] is not None and p.grad.data_ptr() == bufs[k].data_ptr()
+                                       for k, p in w.module.named_parameters() if p.grad is not None)})
+        # a parameter that still HOLDS a gradient is never handed its bound buffer (accumulation must not overwrite)
+        (w(data[lo:hi]) ** 2).mean().backward()
+        acc = {k: p.grad.clone() for k, p in w.module.named_parameters() if p.grad is not None}
+        training.unbind_grad_buffers(w)
+        if rank == 0:
+            torch.save({"log": log, "acc": acc, "left": [k for k, p in w.module.named_parameters() if hasattr(p, "_syn_grad_buf")]}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_ddp_with_gradients_written_into_the_buckets(tmp_path):
+    """`training.bind_grad_buffers` + `_grad_out` + the averaging comm hook (the captured DDP step's gradient path, on gloo): the
+    rank-averaged gradients are the full-batch ones before and after binding, after binding every .grad IS its bucket view, and a
+    backward on top of existing gradients accumulates instead of overwriting."""
+    out = str(tmp_path / "dg.pt")
+    mp.spawn(_ddp_direct_grad_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.manual_seed(0)
+    w1, w2 = torch.nn.Parameter(torch.randn(5, 6) * 0.3), torch.nn.Parameter(torch.randn(3, 5) * 0.3)
+    data = torch.randn(8, 6, generator=torch.Generator().manual_seed(7))
+    ((torch.tanh(data @ w1.t()) @ w2.t()) ** 2).mean().backward()
+    for it, rec in enumerate(got["log"]):
+        assert sorted(rec["grads"]) == ["w1", "w2"]
+        for k, ref in (("w1", w1.grad), ("w2", w2.grad)):
+            assert torch.allclose(rec["grads"][k], ref, atol=1e-6), (it, k)
+        assert rec["aliased"] == (it >= 2), it
+    for k, ref in (("w1", w1.grad), ("w2", w2.grad)):
+        assert torch.allclose(got["acc"][k], 2 * ref, atol=1e-6), k
+    assert got["left"] == []
+
+
 # ---- the product MDM through process._fused, clip-sharded over 2 ranks (engine = tests/cpu_engine.py) -------------------------
 def _mdm_case(variant):
     from syntalker_amd import synth
