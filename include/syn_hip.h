@@ -235,6 +235,11 @@ int syn_ln_bwd(const float* dy, const float* x, const float* gamma, const float*
 /* (ABI 5) y fp32 and / or y_bf16 (either may be NULL), as syn_ln_fwd. */
 int syn_gelu_fwd(const float* x, float* y, void* y_bf16, int64_t n, void* stream);
 int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* (ABI 6) Rotary position embedding on the hidden state (models/denoiser.py:178-186, 324-343: SinusoidalEmbeddings + apply_rotary_pos_emb on the
+ * (B x 8, 32, 64) view): x, y fp32 [n_seq][32][512] (may alias), a token's features = 8 groups of 64, (u, v) = (first, last 32 of a group) ->
+ * (u cos - v sin, v cos + u sin); cos_t / sin_t fp32 [32 positions][32] = cos / sin(position x inv_freq[j]).  inverse != 0: the transposed
+ * rotation, i.e. the gradient with respect to x. */
+int syn_rotary(const float* x, const float* cos_t, const float* sin_t, int32_t n_seq, int32_t inverse, float* y, void* stream);
 /* nn.BatchNorm1d in training mode (batch statistics, running statistics updated as PyTorch does) [+ shortcut] [+ LeakyReLU(0.01)]
  * of the audio encoder's BasicBlock (models/utils/layer.py:171-184) on channels-last fp32 [rows][channels], rows = clips x
  * positions: z = act(gamma (y - mean) rstd + beta [+ shortcut]).  ws: 2 * syn_bn_chunks(rows) * channels floats; stats

@@ -2571,6 +2571,14 @@ int syn_gelu_fwd(const float* x, float* y, void* y_bf16, int64_t n, void* stream
     return e == hipSuccess ? 0 : fail("k_gelu_fwd launch", e);
 }
 
+int syn_rotary(const float* x, const float* cos_t, const float* sin_t, int32_t n_seq, int32_t inverse, float* y, void* stream) {
+    if (!x || !cos_t || !sin_t || !y || n_seq <= 0) return fail_msg("syn_rotary: null pointer / empty batch");
+    const long n_tok = (long)n_seq * SYN_T;
+    hipLaunchKernelGGL(trn::k_rotary, dim3((unsigned)((n_tok * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, cos_t, sin_t, n_tok, inverse, y);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_rotary launch", e);
+}
+
 int32_t syn_bn_chunks(int64_t rows) { const int cr = trn::bn_chunk_rows((long)rows); return (int32_t)((rows + cr - 1) / cr); }
 
 int syn_bn_act_fwd(const float* y, const float* shortcut, int64_t rows, int32_t channels, const float* gamma, const float* beta, float eps,

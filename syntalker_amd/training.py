@@ -596,9 +596,41 @@ class MlpBranchFn(torch.autograd.Function):
         return dh.view(B, T, 512), dg, db, dw1, db1, dw2, db2, None
 
 
+class RotaryFn(torch.autograd.Function):
+    """The rotary embedding of the hidden state as one launch each way (`syn_rotary`); the backward is the transposed rotation."""
+
+    @staticmethod
+    def forward(ctx, h, cs, sn):
+        hc = _f32c(h)
+        y = torch.empty_like(hc)
+        _lib.check(_lib.load().syn_rotary(hc.data_ptr(), cs.data_ptr(), sn.data_ptr(), hc.shape[0], 0, y.data_ptr(), _lib.current_stream(hc.device)), "syn_rotary")
+        ctx.save_for_backward(cs, sn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cs, sn = ctx.saved_tensors
+        d = _f32c(dy)
+        dx = torch.empty_like(d)
+        _lib.check(_lib.load().syn_rotary(d.data_ptr(), cs.data_ptr(), sn.data_ptr(), d.shape[0], 1, dx.data_ptr(), _lib.current_stream(d.device)), "syn_rotary")
+        return dx, None, None
+
+
+ROTARY_FUSED = bool(int(_os.environ.get("SYN_TRAIN_ROTARY_FUSED", "1")))
+
+
 def _rotary(m, h):
     """models/denoiser.py:178-186,324-343 on (B, T, 512)."""
     B, T, _ = h.shape
+    if ROTARY_FUSED and h.is_cuda and T == 32 and h.shape[2] == 512:
+        inv = m.rel_pos.inv_freq
+        key = (inv.data_ptr(), inv._version, inv.device)
+        tab = m.__dict__.get("_syn_rotary_tables")
+        if tab is None or tab[0] != key:                     # (T, 32) tables: cos / sin(position x inv_freq), fp32 like the reference's buffer
+            with torch.no_grad():
+                fr = torch.einsum("i,j->ij", torch.arange(T, device=h.device).type_as(inv), inv)
+                tab = m.__dict__["_syn_rotary_tables"] = (key, fr.cos().contiguous(), fr.sin().contiguous())
+        return RotaryFn.apply(h, tab[1], tab[2])
     g = h.view(B, T, 8, -1).permute(0, 2, 1, 3).reshape(B * 8, T, -1)
     pos = torch.arange(T, device=h.device).type_as(m.rel_pos.inv_freq)
     fr = torch.einsum("i,j->ij", pos, m.rel_pos.inv_freq)

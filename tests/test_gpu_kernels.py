@@ -738,3 +738,23 @@ def test_sync_batchnorm_over_two_emulated_ranks_vs_torch_autograd(C, L, short, a
         assert torch.allclose(rm, rm2, rtol=1e-5, atol=1e-6) and torch.allclose(rv, rv2, rtol=1e-4, atol=1e-6)      # global statistics on every rank
         assert float(dcb.abs().max()) == 0.0
     assert rel_l2(dg.cpu(), g2.grad.cpu()) < 1e-4 and rel_l2(db.cpu(), b2.grad.cpu()) < 1e-4
+
+
+def test_fused_rotary_equals_the_op_by_op_chain(monkeypatch):
+    """`syn_rotary` (training.RotaryFn) against the reference's own chain of views / cat / mul / add on the hidden state
+    (models/denoiser.py:178-186, 324-343), forward and gradient."""
+    from syntalker_amd import synth, training
+    from syntalker_amd.denoiser import MDM
+    m = MDM(synth.default_args()).cuda()
+    g = torch.Generator().manual_seed(3)
+    h = torch.randn(5, 32, 512, generator=g).cuda().requires_grad_(True)
+    w = torch.randn(5, 32, 512, generator=g).cuda()
+    outs = []
+    for fused in (False, True):
+        monkeypatch.setattr(training, "ROTARY_FUSED", fused)
+        h.grad = None
+        y = training._rotary(m, h)
+        (y * w).sum().backward()
+        outs.append((y.detach().clone(), h.grad.clone()))
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-6 and float((outs[0][1] - outs[1][1]).abs().max()) < 2e-6
+    assert float((outs[1][0].norm(dim=-1) - h.detach().norm(dim=-1)).abs().max()) < 1e-3          # a rotation

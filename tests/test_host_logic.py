@@ -213,6 +213,11 @@ def test_c_abi_library_exports_every_declared_symbol():
     diagnostics = set(re.findall(r"^\s*void\s+(syn_debug_[a-z_0-9]+)\s*\(", header, flags=re.M))
     assert len(diagnostics) == 6 and exported == declared | diagnostics, exported ^ (declared | diagnostics)
     assert lib.syn_version() == 6 == _lib.ABI_VERSION
+    # every entry point that takes arguments has its ctypes signature declared (ctypes' default passes a 64-bit pointer or count as a C int)
+    loaded = _lib.load()
+    no_args = {"syn_version", "syn_last_error"}
+    missing = [n for n in _lib.EXPORTS if n not in no_args and getattr(loaded, n).argtypes is None]
+    assert not missing, missing
     # struct sizes exactly as the C compiler lays out include/syn_hip.h (gcc, same ABI as hipcc's host side)
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as td:
