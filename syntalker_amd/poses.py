@@ -20,6 +20,8 @@ def axis_angle_to_rotation_6d(aa: torch.Tensor) -> torch.Tensor:
         raise ValueError(f"axis_angle_to_rotation_6d: the last dimension must be 3, got {tuple(aa.shape)}")
     x = aa.detach().float().contiguous()
     out = torch.empty(*x.shape[:-1], 6, dtype=torch.float32, device=x.device)
+    if x.numel() == 0:
+        return out
     _lib.check(_lib.load().syn_axis_angle_to_rot6d(x.data_ptr(), x.numel() // 3, out.data_ptr(), _lib.current_stream(x.device)),
                "syn_axis_angle_to_rot6d")
     return out
@@ -32,6 +34,8 @@ def rotation_6d_to_axis_angle(d6: torch.Tensor) -> torch.Tensor:
         raise ValueError(f"rotation_6d_to_axis_angle: the last dimension must be 6, got {tuple(d6.shape)}")
     x = d6.detach().float().contiguous()
     out = torch.empty(*x.shape[:-1], 3, dtype=torch.float32, device=x.device)
+    if x.numel() == 0:
+        return out
     _lib.check(_lib.load().syn_rot6d_to_axis_angle(x.data_ptr(), x.numel() // 6, out.data_ptr(), _lib.current_stream(x.device)),
                "syn_rot6d_to_axis_angle")
     return out
