@@ -617,6 +617,7 @@ def timed_loop(pm, sb, coef, noisy, K, W, prime, world, dist, dev, want_steady):
     replay_ms = sum(a.elapsed_time(b) for a, b, _ in ev) / K   # average per-step duration of the replays inside the timed region
     big = [(a, b) for a, b, k in ev if k == CH]
     launch_ms = sum(a.elapsed_time(b) for a, b in big) / len(big) if big else replay_ms   # average duration of a CH-step replay
+    timed_loop.last_replays_ms = [round(a.elapsed_time(b) / k, 4) for a, b, k in ev][:64]    # per-step ms of every replay of the timed region, in order
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -741,6 +742,7 @@ def run_sample(args, rank, local, world, dev, dist):
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": d["launches"] / spl, "steps_per_launch": spl,
                     "whole_step_frac": round(value / world * F_STEP / PEAK_BF16, 4),
                     "timed_region_replay_ms": round(replay_ms, 4),
+                    "timed_region_replays_ms_per_step": getattr(timed_loop, "last_replays_ms", None),
                     "eager_stage_ms_per_step": {rename.get(k, k): round(v, 4) for k, v in stage_ms.items()}}
         out = {
             "metric": "denoising-steps/sec (128-frame clips)", "value": round(value, 1), "unit": "clip-steps/s",

@@ -240,6 +240,15 @@ int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* st
  * (u cos - v sin, v cos + u sin); cos_t / sin_t fp32 [32 positions][32] = cos / sin(position x inv_freq[j]).  inverse != 0: the transposed
  * rotation, i.e. the gradient with respect to x. */
 int syn_rotary(const float* x, const float* cos_t, const float* sin_t, int32_t n_seq, int32_t inverse, float* y, void* stream);
+/* (ABI 6) Weight / bias gradient of an nn.Linear whose input has few rows (the timestep MLP and embed_text see one row per clip, models/denoiser.py:92,
+ * 231-245): dw fp32 [n][k] = sum_m dy[m][n] x[m][k], db [n] = sum_m dy[m][n] (NULL to skip); dy fp32 [m_rows][n], x bf16 [m_rows][k] (the operand
+ * the forward GEMM took), m_rows <= 64, n % 16 == 0.  fp32 FMAs in row order. */
+int syn_linear_wgrad_rows(const float* dy, const void* x_bf16, int32_t m_rows, int32_t n, int32_t k, float* dw, float* db, void* stream);
+/* (ABI 6) masked_l2 of training_losses (gaussian_diffusion.py:202-215, 1307-1314: SmoothL1(beta 1) x mask, summed, / (sum(mask) x C)) and its gradient
+ * in one pass: target, out, dout fp32 [batch][per_sample] with the frame index innermost (per_sample = C x 1 x t_len), mask bytes [batch][t_len];
+ * loss [batch]; dout = d loss[b] / d out (the caller scales it by the incoming gradient of loss[b]). */
+int syn_masked_smooth_l1(const float* target, const float* out, const uint8_t* mask, int32_t batch, int32_t per_sample, int32_t t_len, float* loss,
+                         float* dout, void* stream);
 /* nn.BatchNorm1d in training mode (batch statistics, running statistics updated as PyTorch does) [+ shortcut] [+ LeakyReLU(0.01)]
  * of the audio encoder's BasicBlock (models/utils/layer.py:171-184) on channels-last fp32 [rows][channels], rows = clips x
  * positions: z = act(gamma (y - mean) rstd + beta [+ shortcut]).  ws: 2 * syn_bn_chunks(rows) * channels floats; stats

@@ -20,7 +20,7 @@ EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_ste
            "syn_vq_conv1d", "syn_vq_quantize", "syn_vq_quantize_groups", "syn_vq_codes",
            "syn_vq_workspace_bytes", "syn_vq_map2latent", "syn_vq_latent2origin", "syn_vq_forward_decoder",
            "syn_step_advance", "syn_steps_advance", "syn_prefers_fragment_order", "syn_x_to_fragment", "syn_x_from_fragment", "syn_ln_fwd", "syn_ln_bwd", "syn_gelu_fwd", "syn_gelu_bwd", "syn_attn_fwd", "syn_attn_bwd",
-           "syn_axis_angle_to_rot6d", "syn_rot6d_to_axis_angle", "syn_rotary")
+           "syn_axis_angle_to_rot6d", "syn_rot6d_to_axis_angle", "syn_rotary", "syn_linear_wgrad_rows", "syn_masked_smooth_l1")
 
 vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
 
@@ -136,6 +136,8 @@ def load():
     lib.syn_ln_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.syn_gelu_fwd.argtypes = [vp, vp, vp, i64, vp]
     lib.syn_gelu_bwd.argtypes = [vp, vp, vp, i64, vp]
+    lib.syn_linear_wgrad_rows.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.syn_masked_smooth_l1.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.syn_rotary.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.syn_axis_angle_to_rot6d.argtypes = [vp, i64, vp, vp]
     lib.syn_rot6d_to_axis_angle.argtypes = [vp, i64, vp, vp]

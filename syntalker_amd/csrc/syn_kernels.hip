@@ -2571,6 +2571,23 @@ int syn_gelu_fwd(const float* x, float* y, void* y_bf16, int64_t n, void* stream
     return e == hipSuccess ? 0 : fail("k_gelu_fwd launch", e);
 }
 
+int syn_linear_wgrad_rows(const float* dy, const void* x_bf16, int32_t m_rows, int32_t n, int32_t k, float* dw, float* db, void* stream) {
+    if (!dy || !x_bf16 || !dw || m_rows <= 0 || m_rows > 64 || n <= 0 || n % 16 || k <= 0)
+        return fail_msg("syn_linear_wgrad_rows: 1 .. 64 rows, n a multiple of 16");
+    hipLaunchKernelGGL(trn::k_linear_wgrad_rows, dim3((k + 255) / 256, n / 16), dim3(256), 0, (hipStream_t)stream, dy, (const __bf16*)x_bf16, m_rows, n, k, dw, db);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_linear_wgrad_rows launch", e);
+}
+
+int syn_masked_smooth_l1(const float* target, const float* out, const uint8_t* mask, int32_t batch, int32_t per_sample, int32_t t_len, float* loss,
+                         float* dout, void* stream) {
+    if (!target || !out || !mask || !loss || !dout || batch <= 0 || per_sample <= 0 || per_sample % 4 || t_len <= 0 || t_len > 64 || per_sample % t_len)
+        return fail_msg("syn_masked_smooth_l1: per_sample must be a multiple of 4 and of t_len <= 64");
+    hipLaunchKernelGGL(trn::k_masked_smooth_l1, dim3(batch), dim3(256), 0, (hipStream_t)stream, target, out, mask, per_sample, t_len, loss, dout);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_masked_smooth_l1 launch", e);
+}
+
 int syn_rotary(const float* x, const float* cos_t, const float* sin_t, int32_t n_seq, int32_t inverse, float* y, void* stream) {
     if (!x || !cos_t || !sin_t || !y || n_seq <= 0) return fail_msg("syn_rotary: null pointer / empty batch");
     const long n_tok = (long)n_seq * SYN_T;

@@ -435,6 +435,11 @@ class GaussianDiffusion:
     # ---- training objective ------------------------------------------------------------------------------
     def masked_l2(self, a, b, mask):
         """gaussian_diffusion.py:202-215: despite the name, a masked SmoothL1 (beta = 1)."""
+        if b.is_cuda:                        # device tensors: loss and its gradient from one launch (training.MaskedSmoothL1Fn)
+            from . import training
+            fused = training.masked_smooth_l1(a, b, mask)
+            if fused is not None:
+                return fused
         loss = torch.nn.functional.smooth_l1_loss(a, b, reduction="none") * mask.float()
         loss = loss.sum(dim=list(range(1, loss.dim())))
         return loss / (mask.sum(dim=list(range(1, mask.dim()))) * (a.shape[1] * a.shape[2]))

@@ -183,6 +183,22 @@ class HipLinearFn(torch.autograd.Function):
         M = xb.shape[0]
         dy2 = dy.reshape(-1, N)
         dx = dw = db = dybt = None
+        if SMALL_M_WGRAD and M <= 64 and N % 16 == 0 and dy2.is_cuda and ctx.needs_input_grad[1] and w.dtype is torch.float32:
+            # a Linear that saw one row per clip (timestep MLP, embed_text): weight + bias gradient in ONE fp32 launch instead of the GEMM path's
+            # pads / transposes / packs around a nearly empty MFMA tile
+            dyc, xc = _f32c(dy2), xb.contiguous()
+            dw = _grad_out(ctx.owners[0], (N, K))
+            want_db = ctx.has_bias and ctx.needs_input_grad[2]
+            db = _grad_out(ctx.owners[1], (N,)) if want_db else None
+            _lib.check(_lib.load().syn_linear_wgrad_rows(dyc.data_ptr(), xc.data_ptr(), M, N, K, dw.data_ptr(), _lib.ptr(db), _lib.current_stream(dy.device)),
+                       "syn_linear_wgrad_rows")
+            if ctx.needs_input_grad[0]:
+                dyb = dyc.to(torch.bfloat16)
+                if K % 512 == 0 and N % 128 == 0 and w.is_contiguous():
+                    dx = _gemm_packed(dyb, ctx.pack_t if ctx.pack_t is not None else _pack_t(w, K, N), K, N).reshape(ctx.in_shape)
+                else:
+                    dx = hip_matmul_nt(dyb, w.t()).reshape(ctx.in_shape)
+            return dx, dw, db
         pair = (LINEAR_BWD_PAIR and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and K % 512 == 0 and N % 128 == 0
                 and M % 128 == 0 and w.dtype is torch.float32 and w.is_contiguous() and xb.is_contiguous())
         part = None
@@ -278,6 +294,7 @@ def _embed(module: nn.Embedding, ids):
 
 
 import os as _os
+SMALL_M_WGRAD = bool(int(_os.environ.get("SYN_SMALL_M_WGRAD", "1")))          # Linears with <= 64 input rows: weight / bias gradient on syn_linear_wgrad_rows
 LINEAR_FWD_PACK = bool(int(_os.environ.get("SYN_LINEAR_FWD_PACK", "1")))   # x^T fragments for the weight gradient from the forward GEMM's launch
 LINEAR_BWD_PAIR = bool(int(_os.environ.get("SYN_LINEAR_BWD_PAIR", "1")))   # a Linear's two backward GEMMs as one launch (syn_linear_pair)
 LINEAR_BWD_PREP = int(_os.environ.get("SYN_LINEAR_BWD_PREP", "2"))    # 0: PyTorch cast / transpose / sum; 1: fused cast + transpose (syn_linear_bwd_prep);
@@ -594,6 +611,41 @@ class MlpBranchFn(torch.autograd.Function):
             dz, dw1, db1 = _lin_bwd(dpre, xt1, w1, ctx.bias[0], owners=(ow1, ob1))
         dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d, owners=(og, ob))
         return dh.view(B, T, 512), dg, db, dw1, db1, dw2, db2, None
+
+
+class MaskedSmoothL1Fn(torch.autograd.Function):
+    """`masked_l2` of the reference's training_losses (gaussian_diffusion.py:202-215: SmoothL1 x mask, summed per sample, / (sum(mask) x C)) with its
+    gradient from the same launch (`syn_masked_smooth_l1`): (target, out (B, C, 1, T), mask (B, 1, 1, T) bool) -> (B,)."""
+
+    @staticmethod
+    def forward(ctx, target, out, mask):
+        B = out.shape[0]
+        T = out.shape[-1]
+        tc, oc = _f32c(target), _f32c(out)
+        mk = mask.detach().reshape(B, T).to(torch.uint8).contiguous()
+        loss = torch.empty(B, dtype=torch.float32, device=out.device)
+        dout = torch.empty_like(oc)
+        _lib.check(_lib.load().syn_masked_smooth_l1(tc.data_ptr(), oc.data_ptr(), mk.data_ptr(), B, oc.numel() // B, T, loss.data_ptr(), dout.data_ptr(),
+                                                    _lib.current_stream(out.device)), "syn_masked_smooth_l1")
+        ctx.save_for_backward(dout)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dout,) = ctx.saved_tensors
+        return None, dout * g.reshape(-1, *([1] * (dout.dim() - 1))), None
+
+
+LOSS_FUSED = bool(int(_os.environ.get("SYN_TRAIN_LOSS_FUSED", "1")))
+
+
+def masked_smooth_l1(target, out, mask):
+    """The fused loss when it applies (device fp32 tensors, one mask row per sample, no gradient asked for the target), else None."""
+    if not (LOSS_FUSED and out.is_cuda and out.dim() == 4 and out.dtype is torch.float32 and target.shape == out.shape and not target.requires_grad
+            and torch.is_tensor(mask) and mask.is_cuda and mask.dtype is torch.bool and tuple(mask.shape) == (out.shape[0], 1, 1, out.shape[-1])
+            and out.shape[-1] <= 64 and (out.numel() // out.shape[0]) % 4 == 0):
+        return None
+    return MaskedSmoothL1Fn.apply(target, out, mask)
 
 
 class RotaryFn(torch.autograd.Function):

@@ -758,3 +758,47 @@ def test_fused_rotary_equals_the_op_by_op_chain(monkeypatch):
         outs.append((y.detach().clone(), h.grad.clone()))
     assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-6 and float((outs[0][1] - outs[1][1]).abs().max()) < 2e-6
     assert float((outs[1][0].norm(dim=-1) - h.detach().norm(dim=-1)).abs().max()) < 1e-3          # a rotation
+
+
+def test_small_row_linear_gradients_vs_torch(monkeypatch):
+    """`syn_linear_wgrad_rows` through HipLinearFn (the timestep MLP / embed_text case: one row per clip) against fp32 autograd on the same
+    bf16-rounded input, and against the GEMM path it replaces."""
+    from syntalker_amd import training
+    g = torch.Generator().manual_seed(4)
+    for M, K, N in ((32, 512, 512), (4, 6144, 512), (64, 512, 1536)):
+        x = torch.randn(M, K, generator=g).cuda().requires_grad_(True)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().requires_grad_(True)
+        b = torch.randn(N, generator=g).cuda().requires_grad_(True)
+        dy = torch.randn(M, N, generator=g).cuda()
+        got = {}
+        for small in (True, False):
+            monkeypatch.setattr(training, "SMALL_M_WGRAD", small)
+            for t in (x, w, b):
+                t.grad = None
+            training.HipLinearFn.apply(x, w, b).backward(dy)
+            got[small] = (x.grad.clone(), w.grad.clone(), b.grad.clone())
+        xr = _bf(x.detach()).float()
+        want_w, want_b = dy.t() @ xr, dy.sum(0)
+        assert rel_l2(got[True][1], want_w) < 1e-6 and rel_l2(got[True][2], want_b) < 1e-6          # fp32 FMAs on the operand the forward took
+        assert rel_l2(got[False][1], want_w) < 1e-2                                                 # (the MFMA path rounds dy to bf16 as well)
+        assert rel_l2(got[True][0], got[False][0]) < 1e-6                                           # the data gradient is the same launch either way
+
+
+def test_fused_masked_smooth_l1_vs_torch(monkeypatch):
+    """`syn_masked_smooth_l1` (loss + gradient in one launch) against the reference's masked_l2 composition (gaussian_diffusion.py:202-215)."""
+    from syntalker_amd import training
+    from syntalker_amd.process import create_gaussian_diffusion
+    d = create_gaussian_diffusion()
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(6, 1536, 1, 32, generator=g).cuda()
+    b = (a + 1.5 * torch.randn(6, 1536, 1, 32, generator=g).cuda()).requires_grad_(True)          # both branches of the SmoothL1
+    mask = (torch.rand(6, 1, 1, 32, generator=g) < 0.8).cuda()
+    wgt = torch.rand(6, generator=g).cuda()
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(training, "LOSS_FUSED", fused)
+        b.grad = None
+        loss = d.masked_l2(a, b, mask)
+        (loss * wgt).sum().backward()
+        res[fused] = (loss.detach().clone(), b.grad.clone())
+    assert res[True][0].shape == (6,) and rel_l2(res[True][0], res[False][0]) < 1e-6 and rel_l2(res[True][1], res[False][1]) < 1e-6
