@@ -57,6 +57,7 @@ def main(argv=None) -> dict:
     ap.add_argument("--resume")
     ap.add_argument("--data")
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true", help="wrap the model in DDP (RCCL process group) even with one rank: what a multi-GPU run uses")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--random-init", action="store_true", help="name-keyed synthetic weights instead of the modules' own initialisation")
     a = ap.parse_args(argv)
@@ -68,11 +69,18 @@ def main(argv=None) -> dict:
     world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    ddp = world > 1 or a.force_ddp
+    if ddp:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if a.graph:                                     # whole-step capture with the all-reduces inside: no watchdog thread on the stream
             os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")    # (GraphedTrainStep's protocol, training.py)
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     torch.manual_seed(a.seed + rank); np.random.seed(a.seed + rank)          # the schedule sampler draws from numpy's global RNG
     t = config.build_trainer(args, dev)
     if a.random_init:
@@ -80,8 +88,8 @@ def main(argv=None) -> dict:
     if a.resume:
         checkpoint.load_checkpoints(t.model, a.resume)
     net = t.model
-    side = torch.cuda.Stream(device=dev) if (a.graph and world > 1) else None
-    if world > 1:
+    side = torch.cuda.Stream(device=dev) if (a.graph and ddp) else None
+    if ddp:
         if side is not None:                            # DDP is built on the stream its captured iterations run on
             with torch.cuda.stream(side):
                 net = training.make_ddp(t.model, local, capturable=True)
@@ -89,6 +97,7 @@ def main(argv=None) -> dict:
         else:
             net = training.make_ddp(t.model, local)
     os.makedirs(a.out, exist_ok=True)
+    watch = {n: p.detach().clone() for n, p in t.model.named_parameters() if n.split(".")[0] in ("uncon_text_embeddings", "uncon_audio_embeddings", "embed_style")}
     step_fn, log, saved = None, [], []
     for epoch in range(epochs + 1):                                           # train.py:270: range(args.epochs + 1), the last one only saves
         if epoch != epochs:
@@ -99,7 +108,7 @@ def main(argv=None) -> dict:
             for x0, y in it:
                 if a.graph:
                     if step_fn is None:                 # (config.build_trainer's ClipAdam keeps its rate and step count on the device: capturable as it is)
-                        step_fn = training.GraphedTrainStep(net, t.diffusion, t.opt, x0, {"y": y}, grad_norm=t.grad_norm, warmup=11 if world > 1 else 3,
+                        step_fn = training.GraphedTrainStep(net, t.diffusion, t.opt, x0, {"y": y}, grad_norm=t.grad_norm, warmup=11 if ddp else 3,
                                                             stream=side)
                     losses.append(step_fn(x0, t.schedule_sampler.sample(B, dev)[0], {"y": y}))
                 else:
@@ -121,10 +130,14 @@ def main(argv=None) -> dict:
             saved.append(path)
     if step_fn is not None:
         step_fn.close()
-    if world > 1:
+    if ddp:
         torch.distributed.destroy_process_group()
-    return {"log": log, "saved": saved, "model": type(t.model).__module__ + "." + type(t.model).__name__}
+    moved = {n: bool((p.detach() != watch[n]).any()) for n, p in t.model.named_parameters() if n in watch}      # which of the rarely-read parameters trained
+    return {"log": log, "saved": saved, "model": type(t.model).__module__ + "." + type(t.model).__name__, "moved": moved,
+            "frozen": sorted(n for n, p in t.model.named_parameters() if not p.requires_grad), "ddp": ddp, "graph": bool(a.graph)}
 
 
 if __name__ == "__main__":
-    main()
+    rep = main()
+    if int(os.environ.get("RANK", 0)) == 0:
+        print("REPORT " + json.dumps({k: rep[k] for k in ("model", "moved", "frozen", "ddp", "graph", "saved")} | {"epochs": len(rep["log"])}), flush=True)

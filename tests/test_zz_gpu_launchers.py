@@ -43,3 +43,22 @@ def test_ddp_wrapper_inside_the_captured_training_step():
     assert "eager DDP step" in r.stdout and "graph-replayed DDP step" in r.stdout, r.stdout + r.stderr
     loss = float(r.stdout.strip().splitlines()[-1].rsplit("loss", 1)[1])
     assert loss == loss and abs(loss) < 1e3
+
+
+def test_h3d_training_loop_under_the_captured_ddp_step(tmp_path):
+    """`scripts/train_from_config.py --graph --force-ddp` on the text-prompt configuration: the `train_h3d.py -c <yaml>` loop with the model under
+    `make_ddp(capturable=True)` over RCCL (one rank) and the whole step - DDP's all-reduces included - replayed from one hipGraph.  The learned null
+    prompt `uncon_text_embeddings` is read by the h3d forward (denoiser_h3d.py:119-122) and must TRAIN; `uncon_audio_embeddings` and `embed_style`
+    are never read and are frozen instead of searched for."""
+    import json
+    from tests.test_config import H3D_YAML
+    cfg = tmp_path / "h3d.yaml"
+    cfg.write_text(H3D_YAML.replace("test_period: 20", "test_period: 1"))
+    r = _launch("h3d_train_ddp_graph", [os.path.join(REPO, "scripts", "train_from_config.py"), str(cfg), "--epochs", "1", "--steps-per-epoch", "6",
+                                        "--batch-size", "4", "--random-init", "--graph", "--force-ddp", "--out", str(tmp_path / "run")])
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = json.loads(next(l for l in r.stdout.splitlines() if l.startswith("REPORT "))[7:])
+    assert rep["model"] == "syntalker_amd.denoiser_h3d.MDM" and rep["ddp"] and rep["graph"] and rep["epochs"] == 1 and len(rep["saved"]) == 1
+    assert rep["moved"]["uncon_text_embeddings"] is True and rep["moved"]["uncon_audio_embeddings"] is False
+    assert rep["moved"]["embed_style.weight"] is False
+    assert rep["frozen"] == ["embed_style.bias", "embed_style.weight", "uncon_audio_embeddings"]
