@@ -35,6 +35,10 @@ Extra objects on the JSON line:
                 stream around every graph replay of the timed region, divided by the steps it holds; the step is one
                 kernel) vs the dense bf16 MFMA peak; one eager launch afterwards only names the kernel.
   cpu_baseline  the as-written CPU restatement of the reference forward (oracle/) timed on the host cores.
+  train_step / train_step_ddp_1rank / guided   (default sample-mode line, one GPU; --no-extras skips them) BASELINE configs[2] - [4] through the same
+                code paths --mode train | guided time: the captured training step (20 timed steps), the same step under the DDP wrapper over a 1-rank
+                RCCL group (child process, 200 steps), CFG V = 2 with DDPM / DDIM-50 steps and the body-part wrapper V = 4 (20 timed steps each).
+  small_batch   step time at B = 1 .. 256 (the reference's own sampling scripts run B = 1).
 """
 import argparse
 import ctypes as C
