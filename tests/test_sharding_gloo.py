@@ -199,7 +199,7 @@ def _ddp_direct_grad_worker(rank, world, port, out):
                 return LinFn.apply(torch.tanh(LinFn.apply(x, self.w1)), self.w2)
         data = torch.randn(8, 6, generator=torch.Generator().manual_seed(7))
         lo, hi = shard_range(8, rank, world)
-        w = make_ddp_net = training.make_ddp(Net(), capturable=True)      # averaging comm hook registered (gloo: torch's divide + all-reduce)
+        w = training.make_ddp(Net(), capturable=True)      # averaging comm hook registered (gloo: torch's divide + all-reduce)
         log = []
         for it in range(5):
             w.zero_grad(set_to_none=True)                                 # what GraphedTrainStep does in front of every backward
