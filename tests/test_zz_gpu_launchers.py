@@ -62,3 +62,35 @@ def test_h3d_training_loop_under_the_captured_ddp_step(tmp_path):
     assert rep["moved"]["uncon_text_embeddings"] is True and rep["moved"]["uncon_audio_embeddings"] is False
     assert rep["moved"]["embed_style.weight"] is False
     assert rep["frozen"] == ["embed_style.bias", "embed_style.weight", "uncon_audio_embeddings"]
+
+
+def test_native_host_calls_the_c_abi_without_python(tmp_path):
+    """tests/native/abi_host.cpp - a C++ program that includes include/syn_hip.h and links libsyn_hip.so, no Python or torch in its process -
+    gets the same bits from `syn_randn` and the pose-format kernels as this process does through ctypes, and sees errors as status + text."""
+    import ctypes as C
+    import re
+    import shutil
+    import torch
+    from syntalker_amd import _lib
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "abi_host")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    b = subprocess.run([hipcc, "--offload-arch=gfx950", "-w", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "tests", "native", "abi_host.cpp"),
+                        "-L", libdir, "-lsyn_hip", f"-Wl,-rpath,{libdir}", "-o", exe], capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    vals = {k: float(v) for k, v in re.findall(r"(\w+) ([-+0-9.e]+)", r.stdout.splitlines()[0])}
+    assert "multiples of 4" in r.stdout.splitlines()[1]
+    lib = _lib.load()
+    noise = torch.empty(4096, device="cuda")
+    _lib.check(lib.syn_randn(noise.data_ptr(), 4096, 1234, 999, 8, _lib.current_stream()), "syn_randn")
+    aa = torch.tensor([0.001 * ((i * 7919) % 2001 - 1000) for i in range(3000)], dtype=torch.float32).cuda()
+    d6 = torch.empty(6000, device="cuda")
+    _lib.check(lib.syn_axis_angle_to_rot6d(aa.data_ptr(), 1000, d6.data_ptr(), _lib.current_stream()), "syn_axis_angle_to_rot6d")
+    n64 = noise.double().cpu()
+    assert abs(float(n64.sum()) - vals["randn_sum"]) < 1e-6 and abs(float((n64 * n64).sum()) - vals["randn_sq"]) < 1e-5
+    assert abs(float(d6.double().sum()) - vals["rot6d_sum"]) < 1e-5 and vals["roundtrip_max_err"] < 1e-4
+    assert abs(vals["randn_sq"] / 4096 - 1.0) < 0.1                                    # a standard normal sample
