@@ -42,9 +42,11 @@ class RefProcess:
             out = out * ~m + y["inpainted_motion"] * m
         return out.clamp(-1, 1) if clip_denoised else out
 
-    def p_sample(self, model_fn, x, t, y, noise, clip_denoised=False):
+    def p_sample(self, model_fn, x, t, y, noise, clip_denoised=False, const_noise=False):
         # gaussian_diffusion.py:279-397 (START_X, FIXED_SMALL) + :505-557
         x0 = self.predict(model_fn, x, t, y, clip_denoised)
+        if const_noise:                                   # :543-544: the first sample's draw for every sample
+            noise = noise[[0]].repeat(x.shape[0], 1, 1, 1)
         mean = _take(self.tab["posterior_mean_coef1"], t, x) * x0 + \
             _take(self.tab["posterior_mean_coef2"], t, x) * x
         logvar = _take(self.tab["posterior_log_variance_clipped"], t, x)
@@ -63,7 +65,7 @@ class RefProcess:
         nz = (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
         return mean + nz * sigma * noise, x0
 
-    def _loop(self, step, model_fn, shape, y, noise, step_noise, skip_timesteps, init_image, trace):
+    def _loop(self, step, model_fn, shape, y, noise, step_noise, skip_timesteps, init_image, trace, dump_steps=None):
         # gaussian_diffusion.py:672-739 / :937-1002
         img = noise if noise is not None else torch.randn(*shape)
         if skip_timesteps and init_image is None:
@@ -71,19 +73,22 @@ class RefProcess:
         idx = list(range(self.num_timesteps - skip_timesteps))[::-1]
         if init_image is not None:
             img = self.q_sample(init_image, torch.full((shape[0],), idx[0], dtype=torch.long), img)
+        dump = []
         for k, i in enumerate(idx):
             t = torch.full((shape[0],), i, dtype=torch.long)
             eps = step_noise[k] if step_noise is not None else torch.randn_like(img)
             img, x0 = step(model_fn, img, t, y, eps)
             if trace is not None:
                 trace.append((img.clone(), x0.clone()))
-        return img
+            if dump_steps is not None and k in dump_steps:         # :660-661: the enumeration index of the executed step, not its timestep
+                dump.append(img.clone())
+        return dump if dump_steps is not None else img
 
     @torch.no_grad()
     def p_sample_loop(self, model_fn, shape, y, noise=None, step_noise=None, skip_timesteps=0,
-                      init_image=None, clip_denoised=False, trace=None):
-        step = lambda m, x, t, yy, e: self.p_sample(m, x, t, yy, e, clip_denoised)
-        return self._loop(step, model_fn, shape, y, noise, step_noise, skip_timesteps, init_image, trace)
+                      init_image=None, clip_denoised=False, trace=None, const_noise=False, dump_steps=None):
+        step = lambda m, x, t, yy, e: self.p_sample(m, x, t, yy, e, clip_denoised, const_noise)
+        return self._loop(step, model_fn, shape, y, noise, step_noise, skip_timesteps, init_image, trace, dump_steps)
 
     @torch.no_grad()
     def ddim_sample_loop(self, model_fn, shape, y, noise=None, step_noise=None, skip_timesteps=0,

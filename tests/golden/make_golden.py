@@ -200,5 +200,50 @@ def main():
     print("checksum of synth weights:", float(sum(v.double().abs().sum() for v in model.state_dict().values())))
 
 
+def main_loop_kwargs():
+    """The rarely-used arguments of `p_sample_loop` (gaussian_diffusion.py:607-739) run on the reference: dump_steps, const_noise,
+    init_image + skip_timesteps, clip_denoised, the in-painting blend of p_mean_variance (:316-320) -> loop_kwargs_outputs.npz."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    RefMDM, _, make_diff, _, data_path = import_reference()
+    model = synth.synth_fill_(RefMDM(synth.default_args(data_path=data_path)).eval(), seed=0)
+    ddpm = make_diff(use_ddim=False)
+    y2, x2 = synth.synth_clip_inputs(2, seed=31), synth.synth_latent(2, seed=31)
+    out = {}
+    with torch.no_grad():
+        sn = synth.synth_step_noise(10, 2, seed=32)
+        with InjectNoise(list(sn)):
+            dump = ddpm.p_sample_loop(model, (2, 1536, 1, 32), noise=x2.clone(), clip_denoised=False, model_kwargs={"y": y2},
+                                      skip_timesteps=990, dump_steps=[0, 3, 9])
+        assert isinstance(dump, list) and len(dump) == 3
+        out["dump_steps_0_3_9"] = f32(torch.stack(dump))
+        sn = synth.synth_step_noise(5, 2, seed=33)
+        with InjectNoise(list(sn)):                                   # const_noise: row 0 of every draw for all samples (:543-544)
+            out["const_noise"] = f32(ddpm.p_sample_loop(model, (2, 1536, 1, 32), noise=x2.clone(), clip_denoised=False, model_kwargs={"y": y2},
+                                                        skip_timesteps=995, const_noise=True))
+        init = synth.synth_latent(2, seed=34, name="init_image")
+        sn = synth.synth_step_noise(8, 2, seed=35)
+        with InjectNoise(list(sn)):                                   # x_T = q_sample(init_image, t = 7, noise) (:705-712)
+            out["init_image_skip992"] = f32(ddpm.p_sample_loop(model, (2, 1536, 1, 32), noise=x2.clone(), clip_denoised=False, model_kwargs={"y": y2},
+                                                               skip_timesteps=992, init_image=init))
+        sn = synth.synth_step_noise(5, 2, seed=36)
+        with InjectNoise(list(sn)):
+            out["clip_denoised"] = f32(ddpm.p_sample_loop(model, (2, 1536, 1, 32), noise=x2.clone(), clip_denoised=True, model_kwargs={"y": y2},
+                                                          skip_timesteps=995))
+        g = synth._gen("inpainting", 37)
+        mask = torch.rand(2, 1536, 1, 32, generator=g) < 0.25
+        motion = torch.randn(2, 1536, 1, 32, generator=g)
+        sn = synth.synth_step_noise(5, 2, seed=38)
+        with InjectNoise(list(sn)):
+            out["inpainting"] = f32(ddpm.p_sample_loop(model, (2, 1536, 1, 32), noise=x2.clone(), clip_denoised=False,
+                                                       model_kwargs={"y": dict(y2, inpainting_mask=mask, inpainted_motion=motion)}, skip_timesteps=995))
+    np.savez_compressed(os.path.join(HERE, "loop_kwargs_outputs.npz"), **out)
+    for k, v in out.items():
+        print(f"{k:24s} {tuple(v.shape)} {float(np.abs(v).mean()):.4f}")
+
+
 if __name__ == "__main__":
-    main()
+    if "loop_kwargs" in sys.argv[1:]:
+        main_loop_kwargs()
+    else:
+        main()

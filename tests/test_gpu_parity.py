@@ -821,3 +821,31 @@ def test_full_1000_step_p_sample_loop_vs_oracle(beatx):
         e = rel_l2(g, want)
         print(f"1000-step p_sample_loop rel-L2 vs oracle {e:.3e}  ({name})")
         assert torch.isfinite(g).all() and e < LOOP_TOL, name
+
+
+@pytest.mark.parametrize("case", range(5), ids=["dump_steps", "const_noise", "init_image", "clip_denoised", "inpainting"])
+def test_rarely_used_loop_arguments_vs_reference(beatx, case):
+    """`p_sample_loop`'s full argument list (gaussian_diffusion.py:607-739) against the reference's own outputs (loop_kwargs_outputs.npz):
+    dump_steps and init_image + skip_timesteps on the fused device loop, const_noise / clip_denoised / the in-painting blend (:316-320) on
+    the per-step path they fall back to.  progress=True must not change a result."""
+    import os
+    from syntalker_amd.process import create_gaussian_diffusion
+    from tests.conftest import GOLDEN
+    from tests.test_oracle_golden import _loop_kwargs_cases
+    key, steps, seed, kw, extra = _loop_kwargs_cases()[case]
+    fx = np.load(os.path.join(GOLDEN, "loop_kwargs_outputs.npz"))
+    y = synth.to_device(dict(synth.synth_clip_inputs(2, seed=31), **extra), DEV)
+    sn = synth.synth_step_noise(steps, 2, seed=seed)
+    kw = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    kw.setdefault("clip_denoised", False)
+    d = create_gaussian_diffusion()
+    run = lambda **more: d.p_sample_loop(beatx, (2, 1536, 1, 32), noise=synth.synth_latent(2, seed=31).to(DEV), model_kwargs={"y": y},
+                                         step_noise=sn, **kw, **more)
+    got = run()
+    got = torch.stack(got) if isinstance(got, list) else got
+    e = rel_l2(got.cpu(), fx[key])
+    print(f"{key}: rel-L2 vs the reference {e:.3e}")
+    assert got.shape == fx[key].shape and e < LOOP_TOL, (key, e)
+    again = run(progress=True)
+    again = torch.stack(again) if isinstance(again, list) else again
+    assert rel_l2(again.cpu(), got.cpu()) < 5e-3                     # (another kernel grouping of the same steps: bf16 re-rounding at most)

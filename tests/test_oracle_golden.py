@@ -151,3 +151,29 @@ def test_h3d_ddim50_bodypart_loop(golden):
     s = RefProcess(True).ddim_sample_loop(guided, (1, 1536, 1, 32), dict(y, style_feature=parts), noise=x.clone(),
                                           step_noise=synth.synth_step_noise(50, 1, seed=9))
     assert rel_l2(s, golden["h3d.ddim50_bodypart.sample"]) < 5e-5
+
+
+def _loop_kwargs_cases():
+    """(key in loop_kwargs_outputs.npz, steps, noise seed, p_sample_loop keyword arguments, extra y entries)"""
+    g = synth._gen("inpainting", 37)
+    mask = torch.rand(2, 1536, 1, 32, generator=g) < 0.25
+    motion = torch.randn(2, 1536, 1, 32, generator=g)
+    return [("dump_steps_0_3_9", 10, 32, dict(skip_timesteps=990, dump_steps=[0, 3, 9]), {}),
+            ("const_noise", 5, 33, dict(skip_timesteps=995, const_noise=True), {}),
+            ("init_image_skip992", 8, 35, dict(skip_timesteps=992, init_image=synth.synth_latent(2, seed=34, name="init_image")), {}),
+            ("clip_denoised", 5, 36, dict(skip_timesteps=995, clip_denoised=True), {}),
+            ("inpainting", 5, 38, dict(skip_timesteps=995), {"inpainting_mask": mask, "inpainted_motion": motion})]
+
+
+@pytest.mark.parametrize("case", range(5), ids=["dump_steps", "const_noise", "init_image", "clip_denoised", "inpainting"])
+def test_rarely_used_loop_arguments_match_reference(case):
+    """gaussian_diffusion.py:607-739 / :316-320 / :543-544: the oracle's loop under the arguments the trainers never pass but the API has."""
+    key, steps, seed, kw, extra = _loop_kwargs_cases()[case]
+    fx = np.load(__import__("os").path.join(__import__("tests.conftest", fromlist=["GOLDEN"]).GOLDEN, "loop_kwargs_outputs.npz"))
+    sd = synth_state_dict("beatx")
+    y = dict(synth.synth_clip_inputs(2, seed=31), **extra)
+    sn = synth.synth_step_noise(steps, 2, seed=seed)
+    with torch.no_grad():
+        got = RefProcess(False).p_sample_loop(_model_fn(sd), (2, 1536, 1, 32), y, noise=synth.synth_latent(2, seed=31), step_noise=sn, **kw)
+    got = torch.stack(got) if isinstance(got, list) else got
+    assert rel_l2(got, fx[key]) < 1e-5, key
