@@ -300,3 +300,19 @@ def test_frechet_metric_equals_oracle_restatement():
     lat = rng.standard_normal((5, 32, 1536))
     want = embed_latents(np.transpose(lat, (0, 2, 1))[:, :, None, :], dim=12)        # the oracle takes (N, 1536, 1, 32)
     assert np.allclose(metrics.latent_embedding(lat, dim=12), want)
+
+
+def test_loop_arguments_the_reference_refuses_are_refused():
+    """gaussian_diffusion.py:912-915: the DDIM loop raises NotImplementedError for dump_steps / const_noise; cond_fn (classifier guidance),
+    randomize_class and cond_fn_with_grad are never passed by the reference's callers and raise here instead of being ignored."""
+    d = process.create_gaussian_diffusion(use_ddim=True)
+    toy = torch.nn.Linear(1, 1)
+    for kw in ({"dump_steps": [0]}, {"const_noise": True}):
+        with pytest.raises(NotImplementedError):
+            d.ddim_sample_loop(toy, (1, 4, 1, 2), **kw)
+    ddpm = process.create_gaussian_diffusion()
+    for kw in ({"randomize_class": True}, {"cond_fn_with_grad": True}):
+        with pytest.raises(NotImplementedError):
+            ddpm.p_sample_loop(toy, (1, 4, 1, 2), skip_timesteps=999, **kw)
+    with pytest.raises(NotImplementedError):
+        ddpm.p_sample_loop(lambda x, t, **k: x, (1, 4, 1, 2), skip_timesteps=999, cond_fn=lambda *a, **k: None, device="cpu")
