@@ -237,6 +237,25 @@ def main_loop_kwargs():
         with InjectNoise(list(sn)):
             out["inpainting"] = f32(ddpm.p_sample_loop(model, (2, 1536, 1, 32), noise=x2.clone(), clip_denoised=False,
                                                        model_kwargs={"y": dict(y2, inpainting_mask=mask, inpainted_motion=motion)}, skip_timesteps=995))
+        # DDIM with eta != 0 (gaussian_diffusion.py:741-791: sigma = eta sqrt((1 - a_prev) / (1 - a)) sqrt(1 - a / a_prev)), 50 steps, one clip
+        y1, x1 = synth.synth_clip_inputs(1, seed=39), synth.synth_latent(1, seed=39)
+        sn = synth.synth_step_noise(50, 1, seed=40)
+        with InjectNoise(list(sn)):
+            out["ddim50_eta05"] = f32(make_diff(use_ddim=True).ddim_sample_loop(model, (1, 1536, 1, 32), noise=x1.clone(), clip_denoised=False,
+                                                                              model_kwargs={"y": y1}, eta=0.5))
+    # the wrappers' `eval=True` branches (cfg_sampler.py:25-26, 76-80, 141-146: "accelerate the sample process for evaluating metrics")
+    _, RefMDMH3D, _, cfgmod, _ = import_reference()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    mh = synth.synth_fill_(RefMDMH3D(synth.default_args(data_path=data_path)).eval(), seed=0)
+    with torch.no_grad():
+        yh, xh, th = synth.synth_clip_inputs(2, seed=7, style_dim=256, style_zero=False), synth.synth_latent(2, seed=7), torch.tensor([10, 700])
+        out["h3d.cfg.eval"] = f32(cfgmod.ClassifierFreeSampleModel(mh, eval=True)(xh, th, dict(yh, scale=torch.ones(1) * 2.5)))
+        yb, xb, tb = synth.synth_clip_inputs(1, seed=8, style_dim=256, style_zero=False), synth.synth_latent(1, seed=8), torch.tensor([321])
+        g = synth._gen("part_prompts", 8)
+        parts = {"upper_mask": torch.randn(1, 256, generator=g), "hands_mask": None, "lower_mask": torch.randn(1, 256, generator=g)}
+        out["h3d.twocfg_bodypart.eval"] = f32(cfgmod.TwoClassifierFreeSampleModel_Bodypart(mh, eval=True)(xb, tb, dict(yb, style_feature=parts)))
+        out["h3d.cfg_bodypart.eval"] = f32(cfgmod.ClassifierFreeSampleModel_Bodypart(mh, eval=True)(
+            xb, tb, dict(yb, style_feature=parts, scale=torch.ones(1) * 2.5)))
     np.savez_compressed(os.path.join(HERE, "loop_kwargs_outputs.npz"), **out)
     for k, v in out.items():
         print(f"{k:24s} {tuple(v.shape)} {float(np.abs(v).mean()):.4f}")

@@ -849,3 +849,31 @@ def test_rarely_used_loop_arguments_vs_reference(beatx, case):
     again = run(progress=True)
     again = torch.stack(again) if isinstance(again, list) else again
     assert rel_l2(again.cpu(), got.cpu()) < 5e-3                     # (another kernel grouping of the same steps: bf16 re-rounding at most)
+
+
+def test_wrapper_eval_branches_and_ddim_eta_vs_reference(beatx, h3d):
+    """The guidance wrappers built with `eval=True` (cfg_sampler.py:25-26, 76-80, 141-146: the unconditional evaluation only) and the DDIM loop
+    with eta = 0.5 (noise drawn AND used, gaussian_diffusion.py:741-791) against the reference's outputs."""
+    import os
+    from syntalker_amd import guidance as G
+    from syntalker_amd.process import create_gaussian_diffusion
+    from tests.conftest import GOLDEN
+    fx = np.load(os.path.join(GOLDEN, "loop_kwargs_outputs.npz"))
+    with torch.no_grad():
+        y = synth.to_device(synth.synth_clip_inputs(2, seed=7, style_dim=256, style_zero=False), DEV)
+        x, t = synth.synth_latent(2, seed=7).to(DEV), torch.tensor([10, 700], device=DEV)
+        e = rel_l2(G.ClassifierFreeSampleModel(h3d, eval=True)(x, t, dict(y, scale=torch.ones(1, device=DEV) * 2.5)).cpu(), fx["h3d.cfg.eval"])
+        assert e < FWD_TOL, e
+        yb, xb, parts = _bodypart_case()
+        tb = torch.tensor([321], device=DEV)
+        e = rel_l2(G.TwoClassifierFreeSampleModel_Bodypart(h3d, eval=True)(xb, tb, dict(yb, style_feature=parts)).cpu(), fx["h3d.twocfg_bodypart.eval"])
+        assert e < FWD_TOL, e
+        e = rel_l2(G.ClassifierFreeSampleModel_Bodypart(h3d, eval=True)(xb, tb, dict(yb, style_feature=parts, scale=torch.ones(1, device=DEV) * 2.5)).cpu(),
+                   fx["h3d.cfg_bodypart.eval"])
+        assert e < FWD_TOL, e
+    y1 = synth.to_device(synth.synth_clip_inputs(1, seed=39), DEV)
+    got = create_gaussian_diffusion(use_ddim=True).ddim_sample_loop(beatx, (1, 1536, 1, 32), noise=synth.synth_latent(1, seed=39).to(DEV), clip_denoised=False,
+                                                                   model_kwargs={"y": y1}, eta=0.5, step_noise=synth.synth_step_noise(50, 1, seed=40))
+    e = rel_l2(got.cpu(), fx["ddim50_eta05"])
+    print(f"DDIM-50 eta 0.5 vs the reference: {e:.3e}")
+    assert e < LOOP_TOL

@@ -177,3 +177,29 @@ def test_rarely_used_loop_arguments_match_reference(case):
         got = RefProcess(False).p_sample_loop(_model_fn(sd), (2, 1536, 1, 32), y, noise=synth.synth_latent(2, seed=31), step_noise=sn, **kw)
     got = torch.stack(got) if isinstance(got, list) else got
     assert rel_l2(got, fx[key]) < 1e-5, key
+
+
+def _loop_fixture():
+    import os
+    from tests.conftest import GOLDEN
+    return np.load(os.path.join(GOLDEN, "loop_kwargs_outputs.npz"))
+
+
+def test_wrapper_eval_branches_and_ddim_eta_match_reference():
+    """The `eval=True` branches of the guidance wrappers (cfg_sampler.py:25-26, 76-80, 141-146) and DDIM with eta = 0.5
+    (gaussian_diffusion.py:741-791) on the oracle, against the reference's outputs."""
+    fx = _loop_fixture()
+    sd = synth_state_dict("h3d")
+    fn = _model_fn(sd, "h3d")
+    with torch.no_grad():
+        y, x, t = synth.synth_clip_inputs(2, seed=7, style_dim=256, style_zero=False), synth.synth_latent(2, seed=7), torch.tensor([10, 700])
+        assert rel_l2(gr.cfg(fn, x, t, dict(y, scale=torch.ones(1) * 2.5), eval_metric=True), fx["h3d.cfg.eval"]) < 5e-6
+        yb, xb, parts = _bodypart_case()
+        tb = torch.tensor([321])
+        assert rel_l2(gr.two_cfg_bodypart(fn, xb, tb, dict(yb, style_feature=parts), eval_metric=True), fx["h3d.twocfg_bodypart.eval"]) < 5e-6
+        assert rel_l2(gr.cfg_bodypart(fn, xb, tb, dict(yb, style_feature=parts, scale=torch.ones(1) * 2.5), eval_metric=True),
+                      fx["h3d.cfg_bodypart.eval"]) < 5e-6
+        sdb = synth_state_dict("beatx")
+        y1, x1 = synth.synth_clip_inputs(1, seed=39), synth.synth_latent(1, seed=39)
+        got = RefProcess(True).ddim_sample_loop(_model_fn(sdb), (1, 1536, 1, 32), y1, noise=x1, step_noise=synth.synth_step_noise(50, 1, seed=40), eta=0.5)
+        assert rel_l2(got, fx["ddim50_eta05"]) < 1e-5
