@@ -256,6 +256,12 @@ def main_loop_kwargs():
         out["h3d.twocfg_bodypart.eval"] = f32(cfgmod.TwoClassifierFreeSampleModel_Bodypart(mh, eval=True)(xb, tb, dict(yb, style_feature=parts)))
         out["h3d.cfg_bodypart.eval"] = f32(cfgmod.ClassifierFreeSampleModel_Bodypart(mh, eval=True)(
             xb, tb, dict(yb, style_feature=parts, scale=torch.ones(1) * 2.5)))
+    # models/denoiser.py with use_motionclip (:103-104, 172-174): a 512-d style vector enters through input_process3; `uncond` zeroes it (:110-113)
+    mm = synth.synth_fill_(RefMDM(synth.default_args(data_path=data_path, use_motionclip=True)).eval(), seed=0)
+    with torch.no_grad():
+        ym, xm, tm = synth.synth_clip_inputs(2, seed=41, style_dim=512, style_zero=False), synth.synth_latent(2, seed=41), torch.tensor([5, 900])
+        out["motionclip.fwd.cond"] = f32(mm(xm, tm, ym))
+        out["motionclip.fwd.uncond"] = f32(mm(xm, tm, dict(ym, uncond=True)))
     np.savez_compressed(os.path.join(HERE, "loop_kwargs_outputs.npz"), **out)
     for k, v in out.items():
         print(f"{k:24s} {tuple(v.shape)} {float(np.abs(v).mean()):.4f}")

@@ -877,3 +877,19 @@ def test_wrapper_eval_branches_and_ddim_eta_vs_reference(beatx, h3d):
     e = rel_l2(got.cpu(), fx["ddim50_eta05"])
     print(f"DDIM-50 eta 0.5 vs the reference: {e:.3e}")
     assert e < LOOP_TOL
+
+
+def test_motionclip_variant_vs_reference(kernel):
+    """`MDM(args)` with use_motionclip=True (models/denoiser.py:103-104, 172-174) on each step kernel against the reference's forward."""
+    import os
+    from tests.conftest import GOLDEN
+    from tests.test_oracle_golden import _motionclip_sd
+    fx = np.load(os.path.join(GOLDEN, "loop_kwargs_outputs.npz"))
+    m, _ = _motionclip_sd()
+    m = m.to(DEV)
+    m.layer_mode = kernel
+    y = synth.to_device(synth.synth_clip_inputs(2, seed=41, style_dim=512, style_zero=False), DEV)
+    x, t = synth.synth_latent(2, seed=41).to(DEV), torch.tensor([5, 900], device=DEV)
+    with torch.no_grad():
+        assert rel_l2(m(x, t, y).cpu(), fx["motionclip.fwd.cond"]) < FWD_TOL
+        assert rel_l2(m(x, t, dict(y, uncond=True)).cpu(), fx["motionclip.fwd.uncond"]) < FWD_TOL

@@ -203,3 +203,21 @@ def test_wrapper_eval_branches_and_ddim_eta_match_reference():
         y1, x1 = synth.synth_clip_inputs(1, seed=39), synth.synth_latent(1, seed=39)
         got = RefProcess(True).ddim_sample_loop(_model_fn(sdb), (1, 1536, 1, 32), y1, noise=x1, step_noise=synth.synth_step_noise(50, 1, seed=40), eta=0.5)
         assert rel_l2(got, fx["ddim50_eta05"]) < 1e-5
+
+
+def _motionclip_sd():
+    from syntalker_amd.denoiser import MDM
+    m = MDM(synth.default_args(use_motionclip=True)).eval()
+    synth.synth_fill_(m, seed=0)
+    return m, {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def test_motionclip_variant_matches_reference():
+    """models/denoiser.py with use_motionclip=True (:103-104, 172-174): the 512-d style input through input_process3, zeroed by `uncond`."""
+    fx = _loop_fixture()
+    _, sd = _motionclip_sd()
+    y, x, t = synth.synth_clip_inputs(2, seed=41, style_dim=512, style_zero=False), synth.synth_latent(2, seed=41), torch.tensor([5, 900])
+    with torch.no_grad():
+        assert rel_l2(dr.mdm_forward(sd, x, t, y, use_motionclip=True), fx["motionclip.fwd.cond"]) < FP32_TOL
+        assert rel_l2(dr.mdm_forward(sd, x, t, dict(y, uncond=True), use_motionclip=True), fx["motionclip.fwd.uncond"]) < FP32_TOL
+    assert rel_l2(fx["motionclip.fwd.cond"], fx["motionclip.fwd.uncond"]) > 1e-2          # the style input matters
