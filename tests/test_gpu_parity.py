@@ -893,3 +893,31 @@ def test_motionclip_variant_vs_reference(kernel):
     with torch.no_grad():
         assert rel_l2(m(x, t, y).cpu(), fx["motionclip.fwd.cond"]) < FWD_TOL
         assert rel_l2(m(x, t, dict(y, uncond=True)).cpu(), fx["motionclip.fwd.uncond"]) < FWD_TOL
+
+
+def test_data_parallel_wrapper_and_caller_owned_kwargs(beatx):
+    """The reference's DEFAULT model wrap is `nn.DataParallel(model, args.gpus).cuda()` (train.py:94), and its drivers hand that object to
+    `p_sample_loop` / `training_losses`: the wrapper is looked through (same fused loop, same bits), `training_losses` works on it, and a
+    forward never mutates the caller's `y` (models/denoiser.py:139 copies it)."""
+    from syntalker_amd.process import create_gaussian_diffusion
+    d = create_gaussian_diffusion()
+    wrapped = torch.nn.DataParallel(beatx, [0])
+    y = synth.to_device(synth.synth_clip_inputs(2, seed=44), DEV)
+    keys, ptrs = sorted(y), {k: v.data_ptr() for k, v in y.items() if torch.is_tensor(v)}
+    x = synth.synth_latent(2, seed=44).to(DEV)
+    sn = synth.synth_step_noise(12, 2, seed=45)
+    a = d.p_sample_loop(beatx, (2, 1536, 1, 32), noise=x.clone(), clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=988, step_noise=sn)
+    b = d.p_sample_loop(wrapped, (2, 1536, 1, 32), noise=x.clone(), clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=988, step_noise=sn)
+    assert torch.equal(a, b)
+    with torch.no_grad():
+        o1 = beatx(x, torch.tensor([3, 700], device=DEV), y)
+        o2 = wrapped(x, torch.tensor([3, 700], device=DEV), y=y)
+    assert torch.equal(o1, o2)
+    assert sorted(y) == keys and all(y[k].data_ptr() == p for k, p in ptrs.items())          # nothing added, removed or replaced
+    m = _model("beatx")
+    m.differentiable_eval = True
+    terms = d.training_losses(torch.nn.DataParallel(m, [0]), synth.synth_latent(2, seed=46, name="x0").to(DEV), torch.tensor([10, 500], device=DEV),
+                              model_kwargs={"y": y})
+    assert terms["loss"].shape == (2,) and torch.isfinite(terms["loss"]).all() and torch.equal(terms["loss"], terms["rot_mse"])
+    terms["loss"].mean().backward()
+    assert m.mytimmblocks[0].attn.qkv.weight.grad is not None
