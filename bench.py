@@ -386,7 +386,7 @@ def run_guided(args, rank, local, world, dev, dist):
             plan = plan_fn(y)
             V = len(plan.variants)
             if sb is None:
-                sb = mdm.buffers(B, V)
+                sb = mdm.step_buffers(B, V)
                 sb.cfg_w.copy_(plan.tensor(dev))
             sb.cond.view(V, B, 32, 512)[:, b0:b0 + n].copy_(mdm.variant_conds(y, plan.variants).reshape(V, n, 32, 512))
         V = len(plan.variants)
@@ -656,7 +656,7 @@ def run_sample(args, rank, local, world, dev, dist):
     # per-clip conditioning, once, in chunks (the audio encoder's activations are the only large temporaries).
     # Timed with hipEvents around the encoder calls only (synthetic-input generation and H2D copies excluded),
     # first chunk discarded as warm-up (MIOpen solver selection).
-    sb = model.buffers(B, 1)
+    sb = model.step_buffers(B, 1)
     chunk, cond_ms, cond_clips = 256, 0.0, 0
     for b0 in range(0, B, chunk):
         n = min(chunk, B - b0)

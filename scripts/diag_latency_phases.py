@@ -7,7 +7,7 @@ from syntalker_amd.process import create_gaussian_diffusion
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 V = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 m = synth.synth_fill_(MDM(synth.default_args()).eval(), 0).cuda(); m.layer_mode = 3
-pm = m.packed(); sb = m.buffers(B, V)
+pm = m.packed(); sb = m.step_buffers(B, V)
 sb.cond.normal_(); sb.load_x(torch.randn(B, 1536, 1, 32, device='cuda'))
 if V > 1: sb.cfg_w.fill_(1.0 / V)
 coef = engine.posterior_coefs(create_gaussian_diffusion().tables(), 'cuda')

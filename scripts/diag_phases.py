@@ -7,7 +7,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 mt = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 NOISE = (sys.argv[3] if len(sys.argv) > 3 else 'rng')      # rng | buf | none
 m = synth.synth_fill_(MDM(synth.default_args()).eval(), 0).cuda(); m.m_tile = mt
-pm = m.packed(); sb = m.buffers(B, 1)
+pm = m.packed(); sb = m.step_buffers(B, 1)
 sb.cond.normal_(); sb.load_x(torch.randn(B, 1536, 1, 32, device='cuda'))
 coef = engine.posterior_coefs(create_gaussian_diffusion().tables(), 'cuda')
 lib = _lib.load()

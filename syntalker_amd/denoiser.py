@@ -174,7 +174,9 @@ class MDM(nn.Module):
             self._cond_entry = None
         return self._packed
 
-    def buffers(self, B, V=1, want_x0=False) -> engine.StepBuffers:
+    def step_buffers(self, B, V=1, want_x0=False) -> engine.StepBuffers:
+        """The device buffers of a loop over B clips x V variants (cached).  (Named so that `nn.Module.buffers()` stays what PyTorch's wrappers -
+        nn.DataParallel.forward, the reference's default wrap, train.py:94 - expect it to be.)"""
         k = (B, V, want_x0, self.m_tile, self.layer_mode)
         if k not in self._bufs:
             if len(self._bufs) > 4:
@@ -228,7 +230,7 @@ class MDM(nn.Module):
             raise SynHipError(f"step kernels are specialised for (B,1536,1,32) latents, got {tuple(x.shape)}")
         V = len(variants)
         pm = self.packed()
-        sb = self.buffers(B, V)
+        sb = self.step_buffers(B, V)
         with torch.no_grad():
             sb.cond.copy_(self.variant_conds(y, variants).reshape(-1, engine.D))
             sb.load_x(x)

@@ -298,7 +298,7 @@ class GaussianDiffusion:
         with torch.no_grad():
             plan = plan_fn(y)
             V = len(plan.variants)
-            pm, sb = mdm.packed(), mdm.buffers(B, V, want_x0=each is not None)
+            pm, sb = mdm.packed(), mdm.step_buffers(B, V, want_x0=each is not None)
             sb.cond.copy_((mdm.variant_conds(y, plan.variants) if conds is None else conds).reshape(-1, engine.D))
             if V > 1:
                 sb.cfg_w.copy_(plan.tensor(dev))

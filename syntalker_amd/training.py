@@ -1414,7 +1414,7 @@ class GraphedTrainStep:
             torch.cuda.current_stream(x0.device).wait_stream(side)
 
     def _snapshot(self):
-        tensors = [p for p in self.model.parameters()] + [b for _, b in self.model.named_buffers()]     # (MDM.buffers is the step-buffer factory)
+        tensors = [p for p in self.model.parameters()] + list(self.model.buffers())
         state = {}
         for group in self.opt.param_groups:
             for p in group["params"]:

@@ -2,7 +2,7 @@
 
 The product has no CPU path: `MDM` raises on CPU tensors and the three classes above are thin owners of device memory around the
 C ABI.  The multi-process tests (gloo, no GPU in the build container) still have to drive the PRODUCT's host logic - `MDM.packed()`
-/ `buffers()` / `variant_conds()` caching, `guidance.resolve`, `process._fused` (schedule hand-over between the 10-step and the
+/ `step_buffers()` / `variant_conds()` caching, `guidance.resolve`, `process._fused` (schedule hand-over between the 10-step and the
 single-step graph, `first_clip` bookkeeping, x_T handling), `sharding.sample_sharded` - so these doubles implement the same
 interfaces with the oracle's folded forward (`oracle/denoiser_ref.mdm_forward_folded`) as the step and a counter-based noise keyed
 exactly like the kernels' (seed, step = t_coef, GLOBAL clip index).  `install(monkeypatch)` swaps them in.

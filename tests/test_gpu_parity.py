@@ -64,7 +64,7 @@ def test_forward_residual_stream_vs_golden(beatx, golden):
     try:
         with torch.no_grad():
             beatx(x, torch.tensor([500, 999], device=DEV), y)
-        h8 = beatx.buffers(2, 1).xn.float().view(2, 32, 512).cpu()
+        h8 = beatx.step_buffers(2, 1).xn.float().view(2, 32, 512).cpu()
     finally:
         beatx.layer_mode = 0
     assert rel_l2(h8, golden["beatx.tap.h8"]) < FWD_TOL
@@ -366,7 +366,7 @@ def test_full_size_properties(beatx, B):
     from syntalker_amd import engine
     from syntalker_amd.process import create_gaussian_diffusion
     d = create_gaussian_diffusion()
-    assert beatx.buffers(B, 1).fragment == (B == 1024)
+    assert beatx.step_buffers(B, 1).fragment == (B == 1024)
     y1 = synth.synth_clip_inputs(4, seed=31)
     y = {k: (v.repeat(B // 4, *([1] * (v.dim() - 1))) if torch.is_tensor(v) else v) for k, v in y1.items()}
     y = synth.to_device(y, DEV)
@@ -385,7 +385,7 @@ def test_full_size_properties(beatx, B):
     assert torch.equal(s1, s2) and not torch.equal(s1, s3)          # (3)
     assert torch.isfinite(s1).all()
     # (2): one explicit step at t=500 with captured x0_hat
-    pm, sb = beatx.packed(), beatx.buffers(B, 1, want_x0=True)
+    pm, sb = beatx.packed(), beatx.step_buffers(B, 1, want_x0=True)
     sb.cond.copy_(beatx.variant_conds(y, [(False, False, None)]).reshape(-1, 512))
     sb.load_x(xT)
     x_before = sb.x.clone()
@@ -417,7 +417,7 @@ def test_ddim_loop_after_a_ddpm_loop_on_the_same_buffers(beatx):
     want = ddim.ddim_sample_loop(fresh, (3, 1536, 1, 32), noise=xT, clip_denoised=False, model_kwargs={"y": y})
     create_gaussian_diffusion().p_sample_loop(beatx, (3, 1536, 1, 32), noise=xT, clip_denoised=False, model_kwargs={"y": y},
                                               skip_timesteps=0, seed=5)          # leaves t_coef = 0 after the last step ...
-    sb = beatx.buffers(3, 1)
+    sb = beatx.step_buffers(3, 1)
     sb.t_coef.fill_(999); sb.t_model.fill_(999)                                # ... so put the worst case there explicitly
     got = ddim.ddim_sample_loop(beatx, (3, 1536, 1, 32), noise=xT, clip_denoised=False, model_kwargs={"y": y})
     assert torch.isfinite(got).all() and torch.equal(got, want)
@@ -809,7 +809,7 @@ def test_full_1000_step_p_sample_loop_vs_oracle(beatx):
                                                                   model_kwargs={"y": synth.to_device(y, DEV)}, seed=seed).cpu()
         finally:
             beatx.layer_mode = 0
-    assert beatx.buffers(B, 1).fragment is False
+    assert beatx.step_buffers(B, 1).fragment is False
     sd = synth_state_dict("beatx")
     fw = dr.fold_weights(sd)
     with torch.no_grad():

@@ -1,6 +1,6 @@
 """world_size-2 gloo tests (CPU) of the multi-GPU paths: clip-sharded sampling (slices, first_clip bookkeeping, ragged gather)
 and data-parallel training (DDP wiring of `training.make_ddp`).  First with toy modules (the sharding / DDP code alone), then
-with the PRODUCT's `MDM` - 29.6 M parameters, its packed() / buffers() / variant_conds() plumbing, `process._fused` - over the CPU
+with the PRODUCT's `MDM` - 29.6 M parameters, its packed() / step_buffers() / variant_conds() plumbing, `process._fused` - over the CPU
 stand-ins of the device engine in tests/cpu_engine.py (the HIP kernels need a GPU; the stand-ins run the oracle's arithmetic)."""
 import os
 import socket
