@@ -26,5 +26,11 @@ def load_checkpoints(model, save_path, load_name="model"):
 
 
 def save_checkpoints(save_path, model, opt=None, epoch=None, lrs=None):
-    """Writes only the model state, like the reference (no optimizer / epoch)."""
-    torch.save({"model_state": model.state_dict()}, save_path)
+    """utils/other_tools.py:757-769: the model state, plus `epoch + 1` and the optimizer's (and the scheduler's) state when they are given -
+    the reference's trainer passes none of them (train.py:283-286)."""
+    states = {"model_state": model.state_dict()}
+    if lrs is not None:
+        states.update(epoch=epoch + 1, opt_state=opt.state_dict(), lrs=lrs.state_dict())
+    elif opt is not None:
+        states.update(epoch=epoch + 1, opt_state=opt.state_dict())
+    torch.save(states, save_path)

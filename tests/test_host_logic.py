@@ -335,3 +335,19 @@ def test_word_table_comes_from_the_dataset_vocabulary(tmp_path):
     with pytest.warns(UserWarning):
         z = MDM(synth.default_args(data_path=str(tmp_path) + "/"))
     assert float(z.text_pre_encoder_body.weight.detach().abs().max()) == 0.0 and z.text_pre_encoder_body.weight.shape == (11195, 300)
+
+
+def test_save_checkpoints_keeps_the_reference_file_layout(tmp_path):
+    """utils/other_tools.py:757-769: {'model_state'} alone, + 'epoch' (epoch + 1) and 'opt_state' with an optimizer, + 'lrs' with a scheduler."""
+    from syntalker_amd import checkpoint
+    net = torch.nn.Linear(3, 2)
+    opt = torch.optim.Adam(net.parameters())
+    sch = torch.optim.lr_scheduler.StepLR(opt, 10)
+    p = str(tmp_path / "c.bin")
+    checkpoint.save_checkpoints(p, net)
+    assert sorted(torch.load(p)) == ["model_state"]
+    checkpoint.save_checkpoints(p, net, opt=opt, epoch=4)
+    st = torch.load(p)
+    assert sorted(st) == ["epoch", "model_state", "opt_state"] and st["epoch"] == 5
+    checkpoint.save_checkpoints(p, net, opt=opt, epoch=4, lrs=sch)
+    assert sorted(torch.load(p)) == ["epoch", "lrs", "model_state", "opt_state"]
