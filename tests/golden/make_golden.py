@@ -262,9 +262,12 @@ def main_loop_kwargs():
         ym, xm, tm = synth.synth_clip_inputs(2, seed=41, style_dim=512, style_zero=False), synth.synth_latent(2, seed=41), torch.tensor([5, 900])
         out["motionclip.fwd.cond"] = f32(mm(xm, tm, ym))
         out["motionclip.fwd.uncond"] = f32(mm(xm, tm, dict(ym, uncond=True)))
+    # the checkpoint surface: every state_dict entry of the three model configurations, name:shape:dtype in the reference's order
+    keys = lambda m: np.array([f"{k}:{'x'.join(map(str, v.shape))}:{str(v.dtype).replace('torch.', '')}" for k, v in m.state_dict().items()])
+    out["state_keys.beatx"], out["state_keys.h3d"], out["state_keys.motionclip"] = keys(model), keys(mh), keys(mm)
     np.savez_compressed(os.path.join(HERE, "loop_kwargs_outputs.npz"), **out)
     for k, v in out.items():
-        print(f"{k:24s} {tuple(v.shape)} {float(np.abs(v).mean()):.4f}")
+        print(f"{k:24s} {tuple(v.shape)}" + (f" {float(np.abs(v).mean()):.4f}" if v.dtype.kind == "f" else ""))
 
 
 if __name__ == "__main__":

@@ -351,3 +351,17 @@ def test_save_checkpoints_keeps_the_reference_file_layout(tmp_path):
     assert sorted(st) == ["epoch", "model_state", "opt_state"] and st["epoch"] == 5
     checkpoint.save_checkpoints(p, net, opt=opt, epoch=4, lrs=sch)
     assert sorted(torch.load(p)) == ["epoch", "lrs", "model_state", "opt_state"]
+
+
+@pytest.mark.parametrize("which", ["beatx", "h3d", "motionclip"])
+def test_state_dict_is_the_reference_state_dict_entry_for_entry(which):
+    """Every `state_dict()` entry - parameters AND buffers (positional table, rotary frequencies, BatchNorm counters) - with the reference
+    module's name, shape, dtype and order (tests/golden/make_golden.py loop_kwargs: taken from `models.denoiser[_h3d].MDM(args).state_dict()`)."""
+    from syntalker_amd.denoiser import MDM
+    from syntalker_amd.denoiser_h3d import MDM as MDMH
+    fx = np.load(os.path.join(REPO, "tests", "golden", "loop_kwargs_outputs.npz"))
+    m = MDMH(synth.default_args()) if which == "h3d" else MDM(synth.default_args(use_motionclip=which == "motionclip"))
+    got = [f"{k}:{'x'.join(map(str, v.shape))}:{str(v.dtype).replace('torch.', '')}" for k, v in m.state_dict().items()]
+    want = [str(s) for s in fx[f"state_keys.{which}"]]
+    assert set(got) == set(want), (sorted(set(got) - set(want))[:5], sorted(set(want) - set(got))[:5])
+    assert got == want                                             # and in the same order
