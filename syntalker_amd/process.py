@@ -208,7 +208,7 @@ class GaussianDiffusion:
         return (t != 0).float().view(-1, *([1] * (x.dim() - 1)))
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
-                 const_noise=False, noise=None):
+                 const_noise=False, *, noise=None):
         if cond_fn is not None:
             raise NotImplementedError("cond_fn (classifier guidance) is never used by the reference's callers")
         out = self.p_mean_variance(model, x, t, clip_denoised, denoised_fn, model_kwargs)
@@ -220,7 +220,7 @@ class GaussianDiffusion:
         return {"sample": sample, "pred_xstart": out["pred_xstart"]}
 
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
-                    eta=0.0, noise=None):
+                    eta=0.0, *, noise=None):
         if cond_fn is not None:
             raise NotImplementedError("cond_fn (classifier guidance) is never used by the reference's callers")
         out = self.p_mean_variance(model, x, t, clip_denoised, denoised_fn, model_kwargs)

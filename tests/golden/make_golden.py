@@ -265,6 +265,24 @@ def main_loop_kwargs():
     # the checkpoint surface: every state_dict entry of the three model configurations, name:shape:dtype in the reference's order
     keys = lambda m: np.array([f"{k}:{'x'.join(map(str, v.shape))}:{str(v.dtype).replace('torch.', '')}" for k, v in m.state_dict().items()])
     out["state_keys.beatx"], out["state_keys.h3d"], out["state_keys.motionclip"] = keys(model), keys(mh), keys(mm)
+    # the call surface the drivers use: positional-or-keyword parameters (name=default) of the reference's public entry points
+    import inspect
+    from diffusion import resample as ref_resample
+    from diffusion import model_util as ref_model_util
+    d0 = make_diff()
+
+    def sig(fn):
+        ps = [p for p in inspect.signature(fn).parameters.values() if p.kind in (p.POSITIONAL_OR_KEYWORD, p.POSITIONAL_ONLY) and p.name != "self"]
+        return ",".join(p.name + ("" if p.default is p.empty else "=" + repr(p.default)) for p in ps)
+    base = type(d0).__mro__[1]                      # GaussianDiffusion: respace.py forwards training_losses / p_mean_variance as (model, *args, **kwargs)
+    surf = {"SpacedDiffusion." + n: getattr(base if n in ("training_losses", "p_mean_variance") else type(d0), n) for n in ("p_sample_loop", "ddim_sample_loop", "training_losses", "q_sample", "p_sample", "ddim_sample",
+                                                                     "p_mean_variance", "p_sample_loop_progressive", "ddim_sample_loop_progressive")}
+    surf.update({"MDM.forward": RefMDM.forward, "MDM_h3d.forward": RefMDMH3D.forward, "create_gaussian_diffusion": ref_model_util.create_gaussian_diffusion,
+                 "create_named_schedule_sampler": ref_resample.create_named_schedule_sampler, "UniformSampler.sample": ref_resample.UniformSampler.sample})
+    for cls in ("ClassifierFreeSampleModel", "TwoClassifierFreeSampleModel", "TwoClassifierFreeSampleModel_Bodypart", "ClassifierFreeSampleModel_Bodypart"):
+        surf[cls + ".__init__"] = getattr(cfgmod, cls).__init__
+        surf[cls + ".forward"] = getattr(cfgmod, cls).forward
+    out["signatures"] = np.array([f"{k}({sig(f)})" for k, f in surf.items()])
     np.savez_compressed(os.path.join(HERE, "loop_kwargs_outputs.npz"), **out)
     for k, v in out.items():
         print(f"{k:24s} {tuple(v.shape)}" + (f" {float(np.abs(v).mean()):.4f}" if v.dtype.kind == "f" else ""))

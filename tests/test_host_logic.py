@@ -365,3 +365,33 @@ def test_state_dict_is_the_reference_state_dict_entry_for_entry(which):
     want = [str(s) for s in fx[f"state_keys.{which}"]]
     assert set(got) == set(want), (sorted(set(got) - set(want))[:5], sorted(set(want) - set(got))[:5])
     assert got == want                                             # and in the same order
+
+
+def test_call_signatures_are_the_reference_signatures():
+    """Parameter names, order and defaults of the entry points the reference's drivers call (tests/golden/make_golden.py loop_kwargs took them
+    from the reference with `inspect`): the build's versions start with exactly those parameters; what they add is keyword-only."""
+    import inspect
+    from syntalker_amd import guidance, resample
+    from syntalker_amd.denoiser import MDM
+    from syntalker_amd.denoiser_h3d import MDM as MDMH
+    fx = np.load(os.path.join(REPO, "tests", "golden", "loop_kwargs_outputs.npz"))
+    d = process.create_gaussian_diffusion()
+    here = {"MDM.forward": MDM.forward, "MDM_h3d.forward": MDMH.forward, "create_gaussian_diffusion": process.create_gaussian_diffusion,
+            "create_named_schedule_sampler": resample.create_named_schedule_sampler, "UniformSampler.sample": resample.UniformSampler.sample}
+    for entry in (str(s) for s in fx["signatures"]):
+        name, want = entry.split("(", 1)
+        want = want[:-1]
+        if name.startswith("SpacedDiffusion."):
+            fn = getattr(type(d), name.split(".", 1)[1])
+        elif name in here:
+            fn = here[name]
+        else:
+            cls, meth = name.split(".")
+            fn = getattr(getattr(guidance, cls), meth)
+        ps = [p for p in inspect.signature(fn).parameters.values() if p.name != "self"]
+        pos = [p for p in ps if p.kind in (p.POSITIONAL_OR_KEYWORD, p.POSITIONAL_ONLY)]
+        got = ",".join(p.name + ("" if p.default is p.empty else "=" + repr(p.default)) for p in pos)
+        if name == "create_gaussian_diffusion":                  # (the default class lives under another module path)
+            got, want = ",".join(x.split("=")[0] for x in got.split(",")), ",".join(x.split("=")[0] for x in want.split(","))
+        assert got == want, (name, got, want)
+        assert all(p.kind is p.KEYWORD_ONLY and p.default is not p.empty for p in ps if p not in pos), name
