@@ -262,6 +262,18 @@ def main_loop_kwargs():
         ym, xm, tm = synth.synth_clip_inputs(2, seed=41, style_dim=512, style_zero=False), synth.synth_latent(2, seed=41), torch.tensor([5, 900])
         out["motionclip.fwd.cond"] = f32(mm(xm, tm, ym))
         out["motionclip.fwd.uncond"] = f32(mm(xm, tm, dict(ym, uncond=True)))
+    # training_losses through the text-prompt denoiser (h3d_diffusion_new_trainer.py:446-463 `_g_training`), eval-mode modules (deterministic)
+    mh.zero_grad()
+    y4 = synth.synth_clip_inputs(4, seed=42, style_dim=256, style_zero=False)
+    x0h, epsh, t4 = synth.synth_latent(4, seed=42, name="x0"), synth.synth_latent(4, seed=43, name="eps"), torch.tensor([1, 250, 640, 998])
+    terms = ddpm.training_losses(mh, x0h, t4, model_kwargs={"y": y4}, noise=epsh)
+    out["h3d.train.loss"] = f32(terms["loss"])
+    terms["loss"].mean().backward()
+    names = ["input_process3.weight", "input_process3.bias", "mytimmblocks.3.mlp.fc1.weight", "embed_text.weight", "WavEncoder.feat_extractor.2.conv2.weight",
+             "text_pre_encoder_body.weight"]
+    out["h3d.train.gradnorm"] = np.array([dict(mh.named_parameters())[n].grad.norm().item() for n in names], np.float64)
+    out["h3d.train.gradnorm_names"] = np.array(names)
+    assert mh.uncon_text_embeddings.grad is None                   # eval(): no dropout towards the null prompt, the parameter is not reached
     # the checkpoint surface: every state_dict entry of the three model configurations, name:shape:dtype in the reference's order
     keys = lambda m: np.array([f"{k}:{'x'.join(map(str, v.shape))}:{str(v.dtype).replace('torch.', '')}" for k, v in m.state_dict().items()])
     out["state_keys.beatx"], out["state_keys.h3d"], out["state_keys.motionclip"] = keys(model), keys(mh), keys(mm)

@@ -921,3 +921,24 @@ def test_data_parallel_wrapper_and_caller_owned_kwargs(beatx):
     assert terms["loss"].shape == (2,) and torch.isfinite(terms["loss"]).all() and torch.equal(terms["loss"], terms["rot_mse"])
     terms["loss"].mean().backward()
     assert m.mytimmblocks[0].attn.qkv.weight.grad is not None
+
+
+def test_h3d_training_loss_and_gradient_norms_vs_reference():
+    """The text-prompt denoiser's training step (h3d_diffusion_new_trainer.py:446-463: style_feature through input_process3) on the differentiable
+    HIP path against the reference's loss and gradient norms (eval-mode modules, fixed t and noise)."""
+    import os
+    from syntalker_amd.process import create_gaussian_diffusion
+    from tests.conftest import GOLDEN
+    fx = np.load(os.path.join(GOLDEN, "loop_kwargs_outputs.npz"))
+    m = _model("h3d")
+    m.differentiable_eval = True
+    y = synth.to_device(synth.synth_clip_inputs(4, seed=42, style_dim=256, style_zero=False), DEV)
+    x0, eps = synth.synth_latent(4, seed=42, name="x0").to(DEV), synth.synth_latent(4, seed=43, name="eps").to(DEV)
+    terms = create_gaussian_diffusion().training_losses(m, x0, torch.tensor([1, 250, 640, 998], device=DEV), model_kwargs={"y": y}, noise=eps)
+    assert np.allclose(terms["loss"].detach().cpu().numpy(), fx["h3d.train.loss"], rtol=2e-2)
+    terms["loss"].mean().backward()
+    params = dict(m.named_parameters())
+    got = np.array([params[str(n)].grad.norm().item() for n in fx["h3d.train.gradnorm_names"]])
+    print("h3d grad norms got / want:", got / fx["h3d.train.gradnorm"])
+    assert np.allclose(got, fx["h3d.train.gradnorm"], rtol=3e-2)
+    assert m.uncon_text_embeddings.grad is None and m.uncon_audio_embeddings.grad is None      # eval(): the null prompt is not reached, as in the reference

@@ -221,3 +221,18 @@ def test_motionclip_variant_matches_reference():
         assert rel_l2(dr.mdm_forward(sd, x, t, y, use_motionclip=True), fx["motionclip.fwd.cond"]) < FP32_TOL
         assert rel_l2(dr.mdm_forward(sd, x, t, dict(y, uncond=True), use_motionclip=True), fx["motionclip.fwd.uncond"]) < FP32_TOL
     assert rel_l2(fx["motionclip.fwd.cond"], fx["motionclip.fwd.uncond"]) > 1e-2          # the style input matters
+
+
+def test_h3d_training_loss_and_gradient_norms_match_reference():
+    """training_losses through the text-prompt denoiser (h3d_diffusion_new_trainer.py:446-463), eval-mode modules: loss per sample and the gradient
+    norms of six tensors (input_process3, a block, embed_text, an encoder convolution, the word table) on the oracle vs the reference."""
+    fx = _loop_fixture()
+    buffers = ("running_mean", "running_var", "num_batches_tracked", ".pe", "inv_freq")
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(buffers)) for k, v in synth_state_dict("h3d").items()}
+    y = synth.synth_clip_inputs(4, seed=42, style_dim=256, style_zero=False)
+    x0, eps = synth.synth_latent(4, seed=42, name="x0"), synth.synth_latent(4, seed=43, name="eps")
+    terms = RefProcess(False).training_losses(lambda a, b, c: dr.mdm_forward(sd, a, b, c, variant="h3d"), x0, torch.tensor([1, 250, 640, 998]), y, eps)
+    assert np.allclose(terms["loss"].detach().numpy(), fx["h3d.train.loss"], rtol=5e-6, atol=0)
+    terms["loss"].mean().backward()
+    got = np.array([sd[str(n)].grad.norm().item() for n in fx["h3d.train.gradnorm_names"]])
+    assert np.allclose(got, fx["h3d.train.gradnorm"], rtol=2e-4), got / fx["h3d.train.gradnorm"]
