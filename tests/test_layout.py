@@ -40,6 +40,11 @@ def test_gpu_paths_never_read_the_reference_tree():
     for path in _py_files(os.path.join(REPO, "tests")):
         if path.endswith(("make_golden.py", "make_vq_golden.py", "make_longform_golden.py", "test_layout.py")):   # golden generators run in the build container only
             continue
+        if path.endswith("test_dropin_reference_driver.py"):
+            # CPU-only, skipped where the tree does not exist (the GPU box): the reference's own driver code run against this build
+            src = open(path).read()
+            assert src.count("/root/reference") == 1 and "skipif(not os.path.isdir(REF_TREE)" in src and "pytest.mark.gpu" not in src
+            continue
         if path.endswith("test_config.py"):
             # one CPU-only test there reads the reference's own YAML files where the tree exists (the build container) and is skipped
             # elsewhere; its -m gpu tests carry their configurations inline
