@@ -277,6 +277,11 @@ def main_loop_kwargs():
     # the checkpoint surface: every state_dict entry of the three model configurations, name:shape:dtype in the reference's order
     keys = lambda m: np.array([f"{k}:{'x'.join(map(str, v.shape))}:{str(v.dtype).replace('torch.', '')}" for k, v in m.state_dict().items()])
     out["state_keys.beatx"], out["state_keys.h3d"], out["state_keys.motionclip"] = keys(model), keys(mh), keys(mm)
+    # respace.py:8-61 `space_timesteps` over specifications the factory does not use but the function accepts
+    from diffusion.respace import space_timesteps as ref_space
+    for tag, (n, spec) in {"ddim25": (1000, "ddim25"), "100": (1000, "100"), "10_10_10": (300, "10,10,10"), "list_250": (1000, [250]),
+                           "7_3": (37, "7,3"), "ddim10_of_100": (100, "ddim10")}.items():
+        out["space_timesteps." + tag] = np.array(sorted(ref_space(n, spec)), np.int64)
     # the call surface the drivers use: positional-or-keyword parameters (name=default) of the reference's public entry points
     import inspect
     from diffusion import resample as ref_resample

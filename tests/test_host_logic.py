@@ -395,3 +395,16 @@ def test_call_signatures_are_the_reference_signatures():
             got, want = ",".join(x.split("=")[0] for x in got.split(",")), ",".join(x.split("=")[0] for x in want.split(","))
         assert got == want, (name, got, want)
         assert all(p.kind is p.KEYWORD_ONLY and p.default is not p.empty for p in ps if p not in pos), name
+
+
+def test_space_timesteps_over_other_specifications_matches_reference():
+    """respace.py:8-61 beyond the two specifications the factory uses ("ddimN" strides, comma-separated section counts, a list, uneven sections)."""
+    fx = np.load(os.path.join(REPO, "tests", "golden", "loop_kwargs_outputs.npz"))
+    cases = {"ddim25": (1000, "ddim25"), "100": (1000, "100"), "10_10_10": (300, "10,10,10"), "list_250": (1000, [250]), "7_3": (37, "7,3"),
+             "ddim10_of_100": (100, "ddim10")}
+    for tag, (n, spec) in cases.items():
+        assert sorted(process.space_timesteps(n, spec)) == list(fx["space_timesteps." + tag]), tag
+    with pytest.raises(ValueError):
+        process.space_timesteps(10, "7,7")
+    with pytest.raises(ValueError):
+        process.space_timesteps(1000, "ddim999")
