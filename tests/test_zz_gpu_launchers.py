@@ -94,3 +94,11 @@ def test_native_host_calls_the_c_abi_without_python(tmp_path):
     assert abs(float(n64.sum()) - vals["randn_sum"]) < 1e-6 and abs(float((n64 * n64).sum()) - vals["randn_sq"]) < 1e-5
     assert abs(float(d6.double().sum()) - vals["rot6d_sum"]) < 1e-4 and vals["roundtrip_max_err"] < 1e-4
     assert abs(vals["randn_sq"] / 4096 - 1.0) < 0.1                                    # a standard normal sample
+
+
+def test_two_data_parallel_ranks_on_one_gpu_equal_the_full_batch():
+    """scripts/check_ddp_two_ranks_one_gpu.py: two processes on this box's one GPU over gloo - SyncBatchNorm statistics reduced over the ranks,
+    DDP-averaged gradients of two 4-clip half-batches - against the 8-clip batch in one process, every parameter gradient.  (SURVEY 8e on
+    hardware as far as a 1-GPU box allows: the RCCL collectives themselves only ever see one rank here.)"""
+    r = _launch("ddp_two_ranks_one_gpu", [os.path.join(REPO, "scripts", "check_ddp_two_ranks_one_gpu.py")], nproc=2)
+    assert r.returncode == 0 and "TWO_RANK_CHECK_OK" in r.stdout, r.stdout + r.stderr
