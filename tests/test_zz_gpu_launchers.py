@@ -102,3 +102,10 @@ def test_two_data_parallel_ranks_on_one_gpu_equal_the_full_batch():
     hardware as far as a 1-GPU box allows: the RCCL collectives themselves only ever see one rank here.)"""
     r = _launch("ddp_two_ranks_one_gpu", [os.path.join(REPO, "scripts", "check_ddp_two_ranks_one_gpu.py")], nproc=2)
     assert r.returncode == 0 and "TWO_RANK_CHECK_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_clip_sharded_sampling_over_two_ranks_on_one_gpu_is_bitwise_the_unsharded_run():
+    """scripts/check_sharded_sampling_one_gpu.py: `sharding.sample_sharded` with two processes on this box's GPU (gloo), 11 clips split 6 + 5, noise
+    drawn in the kernels from the global clip index - gathered result = the one-process result bit for bit, plain DDPM and CFG-guided DDIM-50."""
+    r = _launch("sharded_sampling_one_gpu", [os.path.join(REPO, "scripts", "check_sharded_sampling_one_gpu.py")], nproc=2)
+    assert r.returncode == 0 and "SHARDED_SAMPLING_OK" in r.stdout, r.stdout + r.stderr
