@@ -105,7 +105,8 @@ def test_two_data_parallel_ranks_on_one_gpu_equal_the_full_batch():
 
 
 def test_clip_sharded_sampling_over_two_ranks_on_one_gpu_is_bitwise_the_unsharded_run():
-    """scripts/check_sharded_sampling_one_gpu.py: `sharding.sample_sharded` with two processes on this box's GPU (gloo), 11 clips split 6 + 5, noise
-    drawn in the kernels from the global clip index - gathered result = the one-process result bit for bit, plain DDPM and CFG-guided DDIM-50."""
+    """scripts/check_sharded_sampling_one_gpu.py: `sharding.sample_sharded` with two processes on this box's GPU (gloo), ragged splits, noise drawn in
+    the kernels from the global clip index - gathered result = the one-process result bit for bit (plain DDPM, CFG-guided DDIM-50) whenever shards and
+    batch run on the same step kernel, within the bf16 floor when the library picks another kernel for the smaller shards."""
     r = _launch("sharded_sampling_one_gpu", [os.path.join(REPO, "scripts", "check_sharded_sampling_one_gpu.py")], nproc=2)
     assert r.returncode == 0 and "SHARDED_SAMPLING_OK" in r.stdout, r.stdout + r.stderr
