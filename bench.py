@@ -509,6 +509,10 @@ def main():
                          "(the step is ~1000 launches: issued from Python it is host-bound, 10-12 ms against 6.4 ms replayed); --no-train-graph = the eager step")
     ap.add_argument("--force-ddp", action="store_true",
                     help="train mode with one GPU: still wrap the model in DDP over a 1-rank RCCL process group, i.e. time the wrapper the multi-GPU run uses")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="process-group backend of a multi-rank run (nccl = RCCL; gloo: functional checks)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="map the ranks onto the GPUs that exist (rank % count) - with --backend gloo a functional check of the N > 1 path on a 1-GPU box; "
+                         "its throughput is NOT a scaling measurement")
     ap.add_argument("--no-extras", action="store_true",
                     help="sample mode: skip the train_step / guided sub-objects (BASELINE configs[2]-[4]) the default 1-GPU line carries")
     ap.add_argument("--torch-adam", action="store_true", help="train mode: torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(fused) instead of training.ClipAdam (A/B)")
@@ -531,6 +535,8 @@ def main():
     else:
         if not torch.cuda.is_available():
             sys.exit("bench.py: no GPU visible (the hot path has no CPU fallback; --dry-run exercises the launch path only)")
+        if args.share_gpu:                                      # functional check on a box with fewer GPUs than ranks: ranks share devices
+            local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     if world > 1 or (args.force_ddp and args.mode == "train"):
@@ -541,7 +547,10 @@ def main():
         else:
             if args.mode == "train" and args.train_graph is not False:
                 os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")   # whole-step capture: no watchdog thread on the stream
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)          # backend "nccl" = RCCL on ROCm
+            if args.backend == "gloo":                          # (--share-gpu runs: RCCL refuses two ranks on one device)
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)      # backend "nccl" = RCCL on ROCm
     ranks_seen = dist.get_world_size() if dist is not None else 1
     if args.dry_run:
         out = dry_run(args, rank, world, dist)
@@ -554,7 +563,9 @@ def main():
     if rank == 0 and world == 1 and args.mode == "sample" and not args.dry_run and not args.no_extras:
         out.update(extras(args, local, dev))
     if rank == 0:
-        out["rccl_ranks" if not args.dry_run else "gloo_ranks"] = ranks_seen
+        out["rccl_ranks" if not (args.dry_run or args.backend == "gloo") else "gloo_ranks"] = ranks_seen
+        if args.share_gpu and not args.dry_run:
+            out["shared_gpu"] = f"{world} ranks on {torch.cuda.device_count()} device(s): a functional run of the multi-rank path, not a scaling number"
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()                 # ranks leave together (rank 0 may still have been timing the CPU baseline)

@@ -110,3 +110,19 @@ def test_clip_sharded_sampling_over_two_ranks_on_one_gpu_is_bitwise_the_unsharde
     batch run on the same step kernel, within the bf16 floor when the library picks another kernel for the smaller shards."""
     r = _launch("sharded_sampling_one_gpu", [os.path.join(REPO, "scripts", "check_sharded_sampling_one_gpu.py")], nproc=2)
     assert r.returncode == 0 and "SHARDED_SAMPLING_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_multi_rank_path_runs_on_this_box():
+    """The line the driver's scaling run would get: `torchrun --nproc-per-node 2 bench.py --gpus 2 ...` - here with `--backend gloo --share-gpu` (both
+    ranks on this box's one GPU) so that the N > 1 path of the sampling bench - rank start-up, per-rank clip shards and noise keys, the barrier-bracketed
+    timed region, max over ranks, ONE JSON line from rank 0 - runs on the real kernels before an 8-GPU node ever sees it.  Not a scaling measurement."""
+    import json
+    r = _launch("bench_two_ranks_one_gpu", [os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "20", "--warmup", "5",
+                                             "--batch", "512"], nproc=2)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["gloo_ranks"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak" and "shared_gpu" in d
+    assert d["config"]["clips_per_gpu"] == 512 and d["config"]["global_clips"] == 1024 and d["value"] > 1e5 and d["roofline"]["kernel"]
+    assert "cpu_baseline" not in d and "train_step" not in d             # 1-GPU-run items
