@@ -19,7 +19,6 @@ scale-by-keep (timm_transformer/transformer.py:21-38), h3d Bernoulli(0.3) style 
 """
 from __future__ import annotations
 
-import contextlib
 import ctypes as C
 import math
 
@@ -760,43 +759,6 @@ def _conv_terms(role: int):
     _lib.load().syn_debug_conv_terms(CONV_TERMS[role])
 
 
-# Weight gradients of the audio encoder's convolutions on a SIDE stream: a weight gradient is a leaf of the backward - nothing of the chain waits for it -
-# and its kernels are bound by the LDS / matrix pipes, while what the main stream runs next (the previous layer's BatchNorm backward passes) is bound by HBM.
-# Only inside `train_step` / `GraphedTrainStep` (they join the side stream before the optimizer reads the gradients; DDP's communication hook joins it before
-# a bucket's all-reduce); a bare `.backward()` keeps everything on one stream.  In a captured step the side stream is a branch of the graph.
-WGRAD_OVERLAP = bool(int(_os.environ.get("SYN_TRAIN_WGRAD_OVERLAP", "0")))
-_side_streams: dict = {}
-_overlap_on = False
-
-
-def _wgrad_side(device):
-    if not (WGRAD_OVERLAP and _overlap_on):
-        return None
-    s = _side_streams.get(device)
-    if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device=device)
-    s.wait_stream(torch.cuda.current_stream(device))          # dy and x are complete
-    return s
-
-
-def join_side_streams(device=None):
-    """The current stream waits for everything issued on the weight-gradient side stream(s)."""
-    for dev, s in _side_streams.items():
-        if device is None or dev == device:
-            torch.cuda.current_stream(dev).wait_stream(s)
-
-
-class _backward_with_side_streams:
-    def __enter__(self):
-        global _overlap_on
-        self.prev, _overlap_on = _overlap_on, True
-
-    def __exit__(self, *a):
-        global _overlap_on
-        _overlap_on = self.prev
-        join_side_streams()
-
-
 class ConvSplitFn(torch.autograd.Function):
     """(N, C, 1, L) channels_last convolution of the audio encoder, forward on the hand-written implicit-GEMM kernel with
     operands split into bf16 hi + lo halves (`syn_conv1d_train_fwd`: three MFMAs per product, fp32-grade - the plain bf16
@@ -888,15 +850,11 @@ class ConvSplitFn(torch.autograd.Function):
                 lib = _lib.load()
                 n, _, _, l = x.shape
                 l_out, kts = gy.shape[-1], -(-15 // stride) * stride
-                side = _wgrad_side(x.device)
-                if side is not None:
-                    x.record_stream(side); gy.record_stream(side)
-                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                    ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l_out, stride * cin) * cout * kts * cin, device=x.device, dtype=torch.float32)
-                    gw = _grad_out(ctx.owner, (cout, cin, 1, 15)) if ctx.owner is not None else torch.empty(cout, cin, 1, 15, device=x.device, dtype=torch.float32)
-                    _conv_terms(2)
-                    _lib.check(lib.syn_conv1d_train_wgrad(x.data_ptr(), gy.data_ptr(), n, l, cin, stride, pad, cout, ws.data_ptr(), gw.data_ptr(),
-                                                          _lib.current_stream(x.device)), "syn_conv1d_train_wgrad")
+                ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l_out, stride * cin) * cout * kts * cin, device=x.device, dtype=torch.float32)
+                gw = _grad_out(ctx.owner, (cout, cin, 1, 15)) if ctx.owner is not None else torch.empty(cout, cin, 1, 15, device=x.device, dtype=torch.float32)
+                _conv_terms(2)
+                _lib.check(lib.syn_conv1d_train_wgrad(x.data_ptr(), gy.data_ptr(), n, l, cin, stride, pad, cout, ws.data_ptr(), gw.data_ptr(),
+                                                      _lib.current_stream(x.device)), "syn_conv1d_train_wgrad")
                 gw = gw.to(w.dtype)
             else:
                 raise _unsupported_conv("weight gradient", cin, stride, pad, cout)
@@ -931,14 +889,10 @@ class ConvFirstFn(torch.autograd.Function):
         lib = _lib.load()
         n, l_in, cin = wavc.shape
         gy = gy.contiguous(memory_format=torch.channels_last)
-        side = _wgrad_side(gy.device)
-        if side is not None:
-            wavc.record_stream(side); gy.record_stream(side)
-        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            ws = torch.empty(lib.syn_conv1d_first_parts(n, gy.shape[-1]) * 64 * cin * 15, device=gy.device, dtype=torch.float32)
-            gw = _grad_out(ctx.owner, (64, cin, 15))
-            _lib.check(lib.syn_conv1d_first_wgrad(wavc.data_ptr(), gy.data_ptr(), n, l_in, cin, stride, pad, ws.data_ptr(), gw.data_ptr(),
-                                                  _lib.current_stream(gy.device)), "syn_conv1d_first_wgrad")
+        ws = torch.empty(lib.syn_conv1d_first_parts(n, gy.shape[-1]) * 64 * cin * 15, device=gy.device, dtype=torch.float32)
+        gw = _grad_out(ctx.owner, (64, cin, 15))
+        _lib.check(lib.syn_conv1d_first_wgrad(wavc.data_ptr(), gy.data_ptr(), n, l_in, cin, stride, pad, ws.data_ptr(), gw.data_ptr(),
+                                              _lib.current_stream(gy.device)), "syn_conv1d_first_wgrad")
         return None, gw.reshape(wshape).to(wdtype), None, None
 
 
@@ -1258,7 +1212,6 @@ def _avg_comm_hook(state, bucket):
     bucket, all-reduce)."""
     import torch.distributed as dist
     buf = bucket.buffer()
-    join_side_streams(buf.device)                  # weight gradients written on the side stream (`_wgrad_side`) are part of this bucket
     if dist.get_backend() == "nccl":
         op = dist.ReduceOp.AVG if dist.get_world_size() > 1 else dist.ReduceOp.SUM      # (one rank: RCCL's in-place SUM launches nothing, AVG a pre-multiply kernel)
         fut = dist.all_reduce(buf, op=op, async_op=True).get_future()
@@ -1391,8 +1344,7 @@ def train_step(model, diffusion, sampler, optimizer, x0, model_kwargs, grad_norm
     t, _ = sampler.sample(x0.shape[0], x0.device)
     optimizer.zero_grad(set_to_none=True)
     loss = diffusion.training_losses(model, x0, t, model_kwargs=model_kwargs)["loss"].mean()
-    with _backward_with_side_streams():
-        loss.backward()
+    loss.backward()
     if grad_norm and not isinstance(optimizer, ClipAdam):           # (ClipAdam carries its max_norm: the clip is part of its step)
         torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm)
     optimizer.step()
@@ -1484,8 +1436,7 @@ class GraphedTrainStep:
     def _body(self):
         self.opt.zero_grad(set_to_none=True)
         loss = self.diffusion.training_losses(self.wrapped, self.x0, self.t, model_kwargs={"y": self.y})["loss"].mean()
-        with _backward_with_side_streams():
-            loss.backward()
+        loss.backward()
         if self.grad_norm and not isinstance(self.opt, ClipAdam):
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
         self.opt.step()
