@@ -11,6 +11,11 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
+# The CPU oracle is a chain of small torch ops: on a GPU box's 128 hardware threads torch's intra-op pool makes them 10x SLOWER than on 8
+# (bench.py's cpu_baseline probe: 6 forwards/s at 128 threads, 68-79 at 8-16), and four pods share those cores.
+torch.set_num_threads(min(8, os.cpu_count() or 8))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU test")
