@@ -794,13 +794,12 @@ def test_batch_between_two_pass_sizes_runs_as_two_slices_vs_oracle(beatx, monkey
 def test_full_1000_step_p_sample_loop_vs_oracle(beatx):
     """One whole p_sample_loop as the reference's sampler runs it (1000 DDPM steps, noise drawn in the step kernel, 10-step
     graph replays) against the oracle over the same 1000 regenerated noise tensors - once with the library's own kernel choice at
-    B = 3 (the small-batch kernel) and once pinned to the wave-per-sequence kernel `k_seq`, the one `bench.py` times (100 persistent
-    10-step launches).  The oracle's loop runs once (1000 CPU forwards: 3 clips keep it under a minute on a busy box's host cores;
-    rounds 1-3 ran 8)."""
+    B = 8 (the small-batch kernel) and once pinned to the wave-per-sequence kernel `k_seq`, the one `bench.py` times (100 persistent
+    10-step launches).  The oracle's loop runs once (1000 CPU forwards on 8 threads, tests/conftest.py)."""
     from oracle import denoiser_ref as dr
     from oracle.process_ref import RefProcess
     from syntalker_amd.process import create_gaussian_diffusion
-    B, seed = 3, 2024
+    B, seed = 8, 2024
     y, xT = synth.synth_clip_inputs(B, seed=61), synth.synth_latent(B, seed=61)
     got = {}
     for mode, name in ((0, "library's choice"), (5, "k_seq")):
