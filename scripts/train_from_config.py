@@ -15,7 +15,8 @@ the RVQ-VAE latents / vqvae_latent_scale, audio (B, 68266, 2), word ids (B, 128)
             [, style_feature (N,256) for the h3d configuration]; an epoch walks it in batches of batch_size.
 --resume    a checkpoint of the reference's format; keys with nn.DataParallel's `module.` prefix are accepted.
 --graph     replay the whole step from one hipGraph (training.GraphedTrainStep; static batch shape).
-With more than one rank (torchrun) the model is wrapped by training.make_ddp and every rank trains on its own batches.
+With more than one rank (torchrun) the model is wrapped by training.make_ddp and every rank trains on its own batches: with --data the
+epoch's permutation is dealt over the ranks as the reference's DistributedSampler does (train.py:60, set_epoch at :277; `sharding.epoch_indices`).
 """
 import argparse
 import json
@@ -37,14 +38,19 @@ def synthetic_batch(args, B, seed, dev):
     return synth.synth_latent(B, seed=seed, name="x0").to(dev), synth.to_device(y, dev)
 
 
-def batches_from(npz, args, B, dev):
-    z = np.load(npz)
+def batches_from(npz, args, B, dev, rank=0, world=1, epoch=0, seed=0):
+    """One epoch of THIS rank's batches (train.py:54-61: DataLoader(batch_size, drop_last=True) over DistributedSampler(train_data) under DDP,
+    shuffle=True otherwise; the sampler is re-seeded per epoch, train.py:277): `sharding.epoch_batches` deals the epoch's permutation
+    round-robin over the ranks, so an N-rank run trains on N disjoint batches per step - a global batch of N x B."""
+    from syntalker_amd.sharding import epoch_batches
+    z = dict(np.load(npz))                           # every array read once (an NpzFile re-reads the member on every access)
     n = z["latent"].shape[0]
-    for lo in range(0, n - B + 1, B):
-        y = {"audio": torch.from_numpy(z["audio"][lo:lo + B]).float(), "word": torch.from_numpy(z["word"][lo:lo + B]).long(),
-             "seed": torch.from_numpy(z["seed"][lo:lo + B]).float(), "mask": torch.ones(B, 1, 1, 32, dtype=torch.bool),
-             "style_feature": torch.from_numpy(z["style_feature"][lo:lo + B]).float() if "style_feature" in z.files else torch.zeros(B, 512)}
-        yield torch.from_numpy(z["latent"][lo:lo + B]).float().to(dev), synth.to_device(y, dev)
+    for idx in epoch_batches(n, B, rank, world, epoch, seed):
+        ix = idx.numpy()
+        y = {"audio": torch.from_numpy(z["audio"][ix]).float(), "word": torch.from_numpy(z["word"][ix]).long(),
+             "seed": torch.from_numpy(z["seed"][ix]).float(), "mask": torch.ones(B, 1, 1, 32, dtype=torch.bool),
+             "style_feature": torch.from_numpy(z["style_feature"][ix]).float() if "style_feature" in z else torch.zeros(B, 512)}
+        yield torch.from_numpy(z["latent"][ix]).float().to(dev), synth.to_device(y, dev)
 
 
 def main(argv=None) -> dict:
@@ -102,7 +108,7 @@ def main(argv=None) -> dict:
     for epoch in range(epochs + 1):                                           # train.py:270: range(args.epochs + 1), the last one only saves
         if epoch != epochs:
             net.train()
-            it = batches_from(a.data, args, B, dev) if a.data else (synthetic_batch(args, B, 1000 * epoch + s + 100000 * rank, dev)
+            it = batches_from(a.data, args, B, dev, rank, world, epoch, a.seed) if a.data else (synthetic_batch(args, B, 1000 * epoch + s + 100000 * rank, dev)
                                                                      for s in range(a.steps_per_epoch))
             t0, losses = time.time(), []
             for x0, y in it:

@@ -22,6 +22,39 @@ def shard_range(n_clips: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + per + (1 if rank < extra else 0)
 
 
+def epoch_indices(n_items: int, rank: int, world: int, epoch: int, seed: int = 0, shuffle: bool = True, drop_last: bool = False) -> torch.Tensor:
+    """The indices rank `rank` of `world` walks in epoch `epoch` - torch.utils.data.distributed.DistributedSampler's rule, which is what the
+    reference's DDP branch hands its DataLoader (train.py:60, `sampler.set_epoch(epoch)` at train.py:277): one permutation of the whole
+    set per epoch from a generator seeded with seed + epoch (identical on every rank), padded by wrapping around to a multiple of `world`
+    (or cut to one with drop_last), then dealt round-robin: rank r takes positions r, r + world, ...  The ranks' index sets are therefore
+    disjoint (up to the wrap-around padding) and together cover the set; every rank gets the same count, so DDP's collectives line up."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside [0, {world})")
+    if shuffle:
+        order = torch.randperm(n_items, generator=torch.Generator().manual_seed(seed + epoch))
+    else:
+        order = torch.arange(n_items)
+    if drop_last and n_items % world:
+        total = n_items // world * world
+        order = order[:total]
+    else:
+        total = -(-n_items // world) * world
+        pad = total - n_items
+        if pad:
+            reps = -(-pad // max(n_items, 1))
+            order = torch.cat([order, order.repeat(reps)[:pad]])
+    return order[rank:total:world]
+
+
+def epoch_batches(n_items: int, batch_size: int, rank: int, world: int, epoch: int, seed: int = 0, shuffle: bool = True):
+    """This rank's batches of item indices for one epoch: `epoch_indices` cut into batches of `batch_size`, last partial batch dropped
+    (the reference's DataLoader(..., batch_size, drop_last=True, sampler=DistributedSampler), train.py:54-61).  With one rank this is the
+    reference's non-DDP loader: a fresh shuffle of the whole set per epoch."""
+    idx = epoch_indices(n_items, rank, world, epoch, seed, shuffle)
+    for lo in range(0, idx.numel() - batch_size + 1, batch_size):
+        yield idx[lo:lo + batch_size]
+
+
 def shard_kwargs(y: dict, lo: int, hi: int, n_clips: int) -> dict:
     """Slice every per-clip tensor of model_kwargs['y'] (leading dim == n_clips); leave the rest alone."""
     out = {}

@@ -412,3 +412,63 @@ def test_two_rank_ddp_over_the_real_parameter_set(tmp_path):
     for n, g in got["grads"].items():
         err = float((g - params[n].grad).norm() / params[n].grad.norm())
         assert err < 1e-4, (n, err)
+
+
+# ---- per-rank data sharding of the training driver (reference train.py:54-61, :277: DistributedSampler + set_epoch) --------------------
+def test_epoch_indices_equal_torch_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+    from syntalker_amd.sharding import epoch_indices
+    for n in (1, 7, 40, 101):
+        for world in (1, 2, 3, 8):
+            for epoch in (0, 1, 5):
+                for drop_last in (False, True):
+                    for r in range(world):
+                        ref = DistributedSampler(range(n), num_replicas=world, rank=r, shuffle=True, seed=3, drop_last=drop_last)
+                        ref.set_epoch(epoch)
+                        assert epoch_indices(n, r, world, epoch, seed=3, drop_last=drop_last).tolist() == list(ref), (n, world, epoch, r, drop_last)
+    assert epoch_indices(10, 1, 4, 0, shuffle=False).tolist() == [1, 5, 9]      # padded by wrapping: 0..9, 0, 1 dealt round-robin
+
+
+def _sampler_worker(rank, world, port, out, npz):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("train_from_config", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                         "scripts", "train_from_config.py"))
+        drv = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(drv)
+        seen = []
+        for epoch in (0, 1):
+            # the driver's own batch iterator: the latent's first value carries the item's index
+            ids = [x0[:, 0, 0, 0].long() for x0, _ in drv.batches_from(npz, None, 3, "cpu", rank, world, epoch, seed=0)]
+            seen.append(torch.cat(ids) if ids else torch.zeros(0, dtype=torch.long))
+        mine = torch.stack(seen)                                              # (epochs, items of this rank)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        if rank == 0:
+            torch.save(torch.stack(parts), out)                              # (rank, epoch, item)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_training_driver_batches_are_disjoint_and_cover_the_epoch(tmp_path):
+    import numpy as np
+    n, B = 14, 3
+    npz = str(tmp_path / "data.npz")
+    lat = np.zeros((n, 1536, 1, 32), np.float32)
+    lat[:, 0, 0, 0] = np.arange(n)
+    np.savez(npz, latent=lat, audio=np.zeros((n, 8, 2), np.float32), word=np.zeros((n, 128), np.int64), seed=np.zeros((n, 4, 1536), np.float32))
+    out = str(tmp_path / "seen.pt")
+    mp.spawn(_sampler_worker, args=(2, _free_port(), out, npz), nprocs=2, join=True)
+    seen = torch.load(out)                                                    # (2 ranks, 2 epochs, 6 items): 7 per rank, batches of 3, last dropped
+    assert seen.shape == (2, 2, 6)
+    for e in range(2):
+        a, b = set(seen[0, e].tolist()), set(seen[1, e].tolist())
+        assert len(a) == 6 and len(b) == 6 and not (a & b), (a, b)          # disjoint index sets: a global batch of 2 x B per step
+        assert (a | b) <= set(range(n)) and len(a | b) == 12                 # 12 of the 14 items (each rank's 7th item falls to drop_last)
+    assert seen[:, 0].tolist() != seen[:, 1].tolist()                        # set_epoch: a new permutation per epoch
+    # over the ranks' full index lists (before batching) the epoch is covered exactly
+    from syntalker_amd.sharding import epoch_indices
+    both = torch.cat([epoch_indices(n, r, 2, 0) for r in range(2)])
+    assert sorted(both.tolist()) == list(range(n))
