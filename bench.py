@@ -240,7 +240,7 @@ def dry_run(args, rank, world, dist):
     if args.mode == "train":
         from syntalker_amd import synth, training
         from syntalker_amd.denoiser import MDM
-        graph = args.train_graph if args.train_graph is not None else True
+        graph = args.train_graph if args.train_graph is not None else (args.backend != "gloo" or world == 1 and not args.force_ddp)
         model = synth.synth_fill_(MDM(synth.default_args()).train(), 0)
         n_params = sum(p.numel() for p in model.parameters())
         if world > 1 or args.force_ddp:
@@ -284,7 +284,8 @@ def run_train(args, rank, local, world, dev, dist):
     y["audio"] = torch.randn(B, 68266, 2, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + rank))   # training clip length
     x0 = synth.synth_latent(B, seed=1 + rank, name="x0").to(dev)
     model = synth.synth_fill_(MDM(synth.default_args()).train(), 0).to(dev)
-    graph = args.train_graph if args.train_graph is not None else True
+    # the captured step is the default; gloo collectives cannot be captured in a hipGraph, so a gloo run (functional checks) steps eagerly
+    graph = args.train_graph if args.train_graph is not None else (args.backend != "gloo" or world == 1 and not args.force_ddp)
     ddp = world > 1 or args.force_ddp          # --force-ddp: the wrapper (and RCCL, one rank) on a 1-GPU box - what the N-GPU run will use
     net = model
     side = torch.cuda.Stream(device=dev) if graph else torch.cuda.current_stream(dev)
@@ -298,8 +299,26 @@ def run_train(args, rank, local, world, dev, dist):
         opt = torch.optim.Adam(net.parameters(), lr=5e-5, betas=(0.5, 0.999), capturable=graph, fused=True)
     else:
         opt = training.ClipAdam(net.parameters(), lr=5e-5, betas=(0.5, 0.999), max_norm=0.99)
+    fallback = None
     if graph:
-        g = training.GraphedTrainStep(net, diff, opt, x0, {"y": y}, warmup=11 if ddp else 3, stream=side)
+        # The capture of a step with RCCL collectives inside has run on hardware with ONE rank only (this pool has no multi-GPU node): if it
+        # raises on some rank of a larger job, every rank drops to the eager step (same arithmetic, host-bound) and the line says so,
+        # instead of the whole bench aborting.
+        try:
+            g = training.GraphedTrainStep(net, diff, opt, x0, {"y": y}, warmup=11 if ddp else 3, stream=side)
+        except Exception as e:                                   # noqa: BLE001 - anything the capture throws is reported, not swallowed
+            if world == 1:
+                raise
+            g, fallback = None, f"{type(e).__name__}: {e}"[:300]
+        if world > 1:
+            torch.cuda.synchronize(dev)
+            ok = torch.tensor([0 if fallback else 1], device=dev, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok) == 0:
+                if g is not None:
+                    g.close()
+                g, graph, fallback = None, False, fallback or "the capture failed on another rank"
+    if graph:
         last = {}
         def step():
             last["loss"] = g(x0, sampler.sample(B, x0.device)[0], {"y": y})
@@ -346,7 +365,7 @@ def run_train(args, rank, local, world, dev, dist):
                                    "clip 0.99, Adam 5e-5 (0.5, 0.999), MDM denoiser 8x512 + trained WavEncoder, random-init",
                        "clips_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"dp{world}: one process per GPU, DDP bucketed all-reduce of 29.6 M gradients over RCCL" if ddp else "single GPU",
-                       "graph_replayed": graph, "ddp_wrapper": ddp},
+                       "graph_replayed": graph, "ddp_wrapper": ddp, **({"graph_fallback": fallback} if fallback else {})},
             "loss": round(loss, 5), "step_split": split,
             "roofline": {"bound": "mfma", "achieved": round(value / world * F_TRAIN / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(value / world * F_TRAIN / PEAK_BF16, 4), "traffic": None,

@@ -485,7 +485,8 @@ int syn_test_handoff(uint32_t* sync_320_zeroed, uint32_t* buf_8x4096, const floa
 /* attention over ws_q/ws_k/ws_vt -> ws_o for n_seq sequences of 32 tokens, 4 heads x 128. */
 int syn_test_attention(const void* q, const void* k, const void* vt, int32_t n_seq, void* o, void* stream);
 
-/* ---- diagnostics (scripts/diag_*.py, scripts/ubench_*.py; never called by the product path) ------------------------------
+/* ---- diagnostics (scripts/diag_*.py, scripts/ubench_*.py, A/B environment switches; never called by the product path in its default configuration:
+ * syn_debug_conv_terms is reached from syntalker_amd/training.py only when SYN_CONV_TERMS asks for something other than 3,3,3) ------
  * Process-wide switches of the library, not thread-safe, no status to return.  They replace nothing in the reference. */
 /* per-phase cycle counters of the step kernels: the attention / MLP phases write s_memtime stamps into these device buffers (NULL: off) */
 void syn_debug_timing(long long* attn_buf, long long* mlp_buf);

@@ -22,6 +22,9 @@ EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_ste
            "syn_step_advance", "syn_steps_advance", "syn_prefers_fragment_order", "syn_x_to_fragment", "syn_x_from_fragment", "syn_ln_fwd", "syn_ln_bwd", "syn_gelu_fwd", "syn_gelu_bwd", "syn_attn_fwd", "syn_attn_bwd",
            "syn_axis_angle_to_rot6d", "syn_rot6d_to_axis_angle", "syn_rotary", "syn_linear_wgrad_rows", "syn_masked_smooth_l1")
 
+# the `void syn_debug_*` switches of the header's diagnostics section (process-wide, A/B runs and scripts/ only)
+DIAGNOSTICS = ("syn_debug_timing", "syn_debug_gemm_resident", "syn_debug_linear_tile", "syn_debug_conv_terms", "syn_debug_seq_skew", "syn_debug_seq_step")
+
 vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
 
 

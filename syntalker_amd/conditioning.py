@@ -215,7 +215,7 @@ class ClipConditioner:
         self.sd, self.fw, self.variant, self.use_style, self.pool = sd, folded, variant, use_style, pool
         self.wav_blocks = fold_wav_encoder(sd)
         self._hip_wav = None
-        self._word_checked, self._word_ref = None, None
+        self._word_checked = {}            # uncond_audio state -> (key of the word tensor last validated in that state, the tensor)
         if pool != 4:
             raise NotImplementedError("the conditioning kernel pools 4 audio frames per latent frame (vqvae_squeeze_scale = 4)")
         self.weights = CondWeights(sd, folded, use_style, sd["mix_audio_text.weight"].device)
@@ -283,12 +283,17 @@ class ClipConditioner:
         if feat.shape[0] != bs or word.device != dev or seed.device != dev or (style is not None and style.device != dev):
             raise _lib.SynHipError("conditioning inputs disagree on batch size or device")
         src = y["word"]
-        wkey = (id(src), src._version, bool(uncond_audio))
-        if self._word_checked != wkey:          # one device reduction + one host read per word tensor, not two per call
+        # The range check exists for the reference's error behaviour (nn.Embedding raises); memory safety does not depend on it: k_cond_frames
+        # clamps every id into [0, vocab) before it indexes the table.  One device reduction + one host read per word tensor and
+        # uncond_audio state (the h3d wrappers alternate the two states on the same tensor), keyed by object identity and in-place version -
+        # a write that bypasses the version counter (`.data`, a raw-pointer kernel, a graph replay into a static buffer) is not re-validated.
+        wkey = (id(src), src._version)
+        state = bool(uncond_audio)
+        if self._word_checked.get(state, (None, None))[0] != wkey:
             lo, hi = torch.stack(torch.aminmax(word)).tolist()
             if lo < 0 or hi >= w.vocab:
                 raise IndexError(f"word id out of range: [{lo}, {hi}] for a vocabulary of {w.vocab} (nn.Embedding would raise too)")
-            self._word_checked, self._word_ref = wkey, src          # (the reference keeps the id unique while the key is alive)
+            self._word_checked[state] = (wkey, src)                  # (the reference keeps the id unique while the key is alive)
         out = torch.empty(bs, 32, D, dtype=torch.float32, device=dev)
         d = torch.empty(8, bs, D, dtype=torch.float32, device=dev)        # SYN_COND_SCRATCH_ROWS partial sums per clip (include/syn_hip.h)
         _lib.check(_lib.load().syn_cond_encode(C.byref(w.c_struct()), feat.data_ptr(), word.data_ptr(), seed.data_ptr(), _lib.ptr(style),

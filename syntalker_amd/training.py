@@ -183,7 +183,7 @@ class HipLinearFn(torch.autograd.Function):
         M = xb.shape[0]
         dy2 = dy.reshape(-1, N)
         dx = dw = db = dybt = None
-        if SMALL_M_WGRAD and M <= 64 and N % 16 == 0 and dy2.is_cuda and ctx.needs_input_grad[1] and w.dtype is torch.float32:
+        if SMALL_M_WGRAD and 0 < M <= 64 and N % 16 == 0 and dy2.is_cuda and ctx.needs_input_grad[1] and w.dtype is torch.float32:
             # a Linear that saw one row per clip (timestep MLP, embed_text): weight + bias gradient in ONE fp32 launch instead of the GEMM path's
             # pads / transposes / packs around a nearly empty MFMA tile
             dyc, xc = _f32c(dy2), xb.contiguous()
@@ -322,7 +322,10 @@ def _grad_out(param, shape=None):
     shape = tuple(shape if shape is not None else param.shape)
     buf = getattr(param, "_syn_grad_buf", None) if param is not None else None
     if (buf is not None and param.grad is None and buf.dtype is torch.float32 and buf.is_contiguous() and buf.numel() == math.prod(shape)
-            and torch.is_grad_enabled() is False):
+            and torch.is_grad_enabled() is False and not getattr(param, "_syn_grad_handed", False)):
+        # handed out ONCE per backward: a parameter used by two nodes of one backward (tied weights, a module applied twice) gets a fresh
+        # tensor the second time, which autograd accumulates as usual (cleared by `_reset_handed` at the top of the next step)
+        param._syn_grad_handed = True
         return buf.view(shape)
     dev = param.device if param is not None else None
     return torch.empty(shape, dtype=torch.float32, device=dev)
@@ -346,6 +349,15 @@ def unbind_grad_buffers(model):
     for p in model.parameters():
         if hasattr(p, "_syn_grad_buf"):
             del p._syn_grad_buf
+        if hasattr(p, "_syn_grad_handed"):
+            del p._syn_grad_handed
+
+
+def _reset_handed(model):
+    """Start of a step: every bound gradient buffer may be handed out again (`_grad_out`)."""
+    for p in model.parameters():
+        if getattr(p, "_syn_grad_handed", False):
+            p._syn_grad_handed = False
 
 
 def _f32c(t):
@@ -642,7 +654,8 @@ LOSS_FUSED = bool(int(_os.environ.get("SYN_TRAIN_LOSS_FUSED", "1")))
 def masked_smooth_l1(target, out, mask):
     """The fused loss when it applies (device fp32 tensors, one mask row per sample, no gradient asked for the target), else None."""
     if not (LOSS_FUSED and out.is_cuda and out.dim() == 4 and out.dtype is torch.float32 and target.shape == out.shape and not target.requires_grad
-            and torch.is_tensor(mask) and mask.is_cuda and mask.dtype is torch.bool and tuple(mask.shape) == (out.shape[0], 1, 1, out.shape[-1])
+            and target.is_cuda and target.device == out.device
+            and torch.is_tensor(mask) and mask.is_cuda and mask.device == out.device and mask.dtype is torch.bool and tuple(mask.shape) == (out.shape[0], 1, 1, out.shape[-1])
             and out.shape[-1] <= 64 and (out.numel() // out.shape[0]) % 4 == 0):
         return None
     return MaskedSmoothL1Fn.apply(target, out, mask)
@@ -752,11 +765,21 @@ def _unsupported_conv(what, cin, stride, pad, cout):
 
 # Which cross products of the hi / lo operand split each convolution role issues (`syn_debug_conv_terms`; bit 0: A_lo . B_hi, bit 1: A_hi . B_lo,
 # 3 = both = fp32-grade).  "forward,data-gradient,weight-gradient"; A / B = (W, x), (W^T, dy), (dy, x).  An A/B switch.
-CONV_TERMS = tuple(int(v) for v in _os.environ.get("SYN_CONV_TERMS", "3,3,3").split(","))
+def _parse_conv_terms(text: str) -> tuple:
+    parts = text.split(",")
+    if len(parts) != 3 or not all(p.strip() in ("0", "1", "2", "3") for p in parts):
+        raise ValueError(f"SYN_CONV_TERMS must be three masks 0..3 'forward,data-gradient,weight-gradient' (default 3,3,3), got {text!r}")
+    return tuple(int(p) for p in parts)
+
+
+CONV_TERMS = _parse_conv_terms(_os.environ.get("SYN_CONV_TERMS", "3,3,3"))
 
 
 def _conv_terms(role: int):
-    _lib.load().syn_debug_conv_terms(CONV_TERMS[role])
+    """Diagnostics only: with the default (3, 3, 3) the library's switch is never touched - the product path makes no `syn_debug_*` call.
+    An A/B run (SYN_CONV_TERMS set to something else) selects the role's mask in front of every convolution launch."""
+    if CONV_TERMS != (3, 3, 3):
+        _lib.load().syn_debug_conv_terms(CONV_TERMS[role])
 
 
 class ConvSplitFn(torch.autograd.Function):
@@ -1372,7 +1395,7 @@ class GraphedTrainStep:
     Call `close()` (or let the object die) before interpreter shutdown."""
 
     def __init__(self, model, diffusion, optimizer, x0, model_kwargs, grad_norm: float = 0.99, warmup: int = 3, stream=None,
-                 keep_warmup_updates: bool = False):
+                 keep_warmup_updates: bool = False, noise=None):
         engine._require_cuda(x0, "x0")
         _check_clip(optimizer, grad_norm)
         self.model, self.opt, self.grad_norm, self.diffusion = model, optimizer, grad_norm, diffusion
@@ -1380,6 +1403,9 @@ class GraphedTrainStep:
         self.wrapped = diffusion._wrap_model(model)          # its timestep map is uploaded once, outside the capture
         self.x0 = x0.detach().clone()
         self.t = torch.zeros(x0.shape[0], dtype=torch.long, device=x0.device)
+        # `noise` (a tensor like x0): the step takes its q_sample noise from a static buffer the caller fills per call (`__call__(..., noise=)`,
+        # the `noise=` argument of training_losses - parity tests with injected noise) instead of drawing it inside the graph
+        self.noise = None if noise is None else noise.detach().clone()
         self.y = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in model_kwargs["y"].items()}
         side = stream if stream is not None else torch.cuda.Stream(device=x0.device)   # DDP: the stream the wrapper was built on
         side.wait_stream(torch.cuda.current_stream(x0.device))
@@ -1402,8 +1428,15 @@ class GraphedTrainStep:
             # retire them before the capture starts - the device is drained, the thread sweeps every ~100 ms - and keep other threads'
             # runtime calls out of this capture's error domain (thread-local mode: launches on the capturing stream are captured whichever
             # thread issues them - the autograd engine's do - but a foreign thread's query cannot invalidate the capture).
+            # Deterministic part of the drain: every rank has issued its warm-up collectives (barrier) and the device has finished them
+            # (synchronize).  What is left is the watchdog thread's sweep, which PyTorch does not expose: it polls every ~100 ms, so the wait
+            # is three periods by default (SYN_GRAPH_WATCHDOG_DRAIN_S to change it, 0 to skip).
+            if torch.distributed.get_world_size() > 1:
+                torch.distributed.barrier()
             torch.cuda.synchronize(x0.device)
-            __import__("time").sleep(0.3)
+            drain = float(_os.environ.get("SYN_GRAPH_WATCHDOG_DRAIN_S", "0.3"))
+            if drain > 0:
+                __import__("time").sleep(drain)
             mode = "thread_local"
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=side, capture_error_mode=mode):
@@ -1435,16 +1468,22 @@ class GraphedTrainStep:
 
     def _body(self):
         self.opt.zero_grad(set_to_none=True)
-        loss = self.diffusion.training_losses(self.wrapped, self.x0, self.t, model_kwargs={"y": self.y})["loss"].mean()
+        if self.bound:
+            _reset_handed(self.model)
+        loss = self.diffusion.training_losses(self.wrapped, self.x0, self.t, model_kwargs={"y": self.y}, noise=self.noise)["loss"].mean()
         loss.backward()
         if self.grad_norm and not isinstance(self.opt, ClipAdam):
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
         self.opt.step()
         return loss.detach()
 
-    def __call__(self, x0, t, model_kwargs):
+    def __call__(self, x0, t, model_kwargs, noise=None):
         self.x0.copy_(x0)
         self.t.copy_(t)
+        if (noise is None) != (self.noise is None):
+            raise ValueError("GraphedTrainStep: pass `noise` to every call if and only if the step was constructed with a noise buffer")
+        if noise is not None:
+            self.noise.copy_(noise)
         for k, v in model_kwargs["y"].items():
             if torch.is_tensor(v):
                 self.y[k].copy_(v)

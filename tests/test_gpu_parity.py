@@ -680,6 +680,51 @@ def test_graph_replayed_train_step(beatx):
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
 
 
+def test_five_step_training_trajectory_vs_the_reference_loop():
+    """The reference's own training loop - `_g_training` lifted from diffusion_rvqvae_trainer.py:339-356, its Adam (optimizers/optim_factory.py:
+    122-123), clip_grad_norm_(0.99), five updates on one 4-clip batch with fixed timesteps / noise (tests/golden/make_train_golden.py ->
+    train_trajectory.npz) - against this build's `GraphedTrainStep` + `ClipAdam` (the captured step bench.py times): the loss of every step
+    (2.28 -> 1.49: each one carries the four updates before it), the gradient norm the clip saw, ten tensors' parameter changes, BatchNorm
+    buffers.  Tolerances: loss 2e-2 (bf16 operands); parameter changes are compared by cosine: Adam's first updates are sign-like
+    (|m / sqrt(v)| ~ 1 whatever the gradient's size), so an element whose gradient is below the bf16 error of its tensor moves by +-lr on
+    either side - rel-L2 of the change measures the share of such elements, not an arithmetic error."""
+    import os
+    from syntalker_amd import training
+    from syntalker_amd.process import create_gaussian_diffusion
+    from tests.test_oracle_golden import trajectory_case
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_trajectory.npz"))
+    y, x0, eps = trajectory_case()
+    m = _model("beatx").train()
+    m.drop_path = 0.0
+    d = create_gaussian_diffusion()
+    opt = training.ClipAdam(m.parameters(), lr=5e-5, betas=(0.5, 0.999), max_norm=0.99)
+    params = dict(m.named_parameters())
+    init = {str(n): params[str(n)].detach().clone() for n in g["watch"]}
+    yd = synth.to_device(y, DEV)
+    step = training.GraphedTrainStep(m, d, opt, x0.to(DEV), {"y": yd}, grad_norm=0.99, noise=eps[0].to(DEV))
+    losses, norms = [], []
+    for k in range(5):
+        losses.append(float(step(x0.to(DEV), torch.from_numpy(g["t"][k]).to(DEV), {"y": yd}, noise=eps[k].to(DEV))))
+        norms.append(float(opt.last_norm()))
+    step.close()
+    print("trajectory loss got / want:", np.array(losses) / g["loss"], " grad norm got / want:", np.array(norms) / g["grad_norm"])
+    assert np.allclose(losses, g["loss"], rtol=2e-2), (losses, g["loss"])
+    assert np.allclose(norms, g["grad_norm"], rtol=3e-2), (norms, g["grad_norm"])
+    worst_cos, worst_norm = 1.0, 0.0
+    for n in init:
+        dlt = (params[n].detach() - init[n]).reshape(-1).cpu()
+        want = torch.from_numpy(g[f"delta_head.{n}"])
+        cos = float(torch.nn.functional.cosine_similarity(dlt[:4096], want, dim=0))
+        nr = float(dlt.double().norm()) / float(g[f"delta_norm.{n}"])
+        print(f"  {n}: delta norm got / want {nr:.4f}, cosine {cos:.4f}, rel-L2 {rel_l2(dlt[:4096], want):.3e}")
+        worst_cos, worst_norm = min(worst_cos, cos), max(worst_norm, abs(nr - 1))
+        assert cos > 0.97 and abs(nr - 1) < 5e-2, (n, cos, nr)
+    print(f"trajectory: worst delta cosine {worst_cos:.4f}, worst |norm ratio - 1| {worst_norm:.3e}")
+    sd = m.state_dict()
+    for n in ("WavEncoder.feat_extractor.0.bn1.running_mean", "WavEncoder.feat_extractor.5.bn2.running_var", "WavEncoder.feat_extractor.0.bn1.num_batches_tracked"):
+        assert np.allclose(sd[n].double().cpu().numpy(), g[f"buffer.{n}"], rtol=5e-3, atol=5e-4), n
+
+
 def test_captured_train_step_at_the_bench_size_replays_back_to_back(beatx):
     """The whole training step of BASELINE config 3 (32 clips, 68 266 audio samples x 2 channels) captured in one hipGraph and
     replayed 40 times with NOTHING waiting between the replays.  Round 1 had to synchronise after every replay (HSA

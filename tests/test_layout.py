@@ -38,7 +38,7 @@ def test_gpu_paths_never_read_the_reference_tree():
     for rel in ("bench.py", "__graft_entry__.py"):
         assert "/root/reference" not in open(os.path.join(REPO, rel)).read()
     for path in _py_files(os.path.join(REPO, "tests")):
-        if path.endswith(("make_golden.py", "make_vq_golden.py", "make_longform_golden.py", "test_layout.py")):   # golden generators run in the build container only
+        if path.endswith(("make_golden.py", "make_vq_golden.py", "make_longform_golden.py", "make_train_golden.py", "make_frechet_golden.py", "test_layout.py")):   # golden generators run in the build container only
             continue
         if path.endswith("test_dropin_reference_driver.py"):
             # CPU-only, skipped where the tree does not exist (the GPU box): the reference's own driver code run against this build

@@ -1,5 +1,7 @@
 """Pin the oracle (oracle/*.py) against outputs of the reference itself (tests/golden/*.npz,
 produced by tests/golden/make_golden.py in the build container).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -12,6 +14,7 @@ from syntalker_amd import synth
 from tests.conftest import rel_l2
 from tests.refmodel import synth_state_dict
 
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FP32_TOL = 2e-6      # fp32 reference vs fp32 restatement: op order differs slightly, nothing else
 
 
@@ -236,3 +239,47 @@ def test_h3d_training_loss_and_gradient_norms_match_reference():
     terms["loss"].mean().backward()
     got = np.array([sd[str(n)].grad.norm().item() for n in fx["h3d.train.gradnorm_names"]])
     assert np.allclose(got, fx["h3d.train.gradnorm"], rtol=2e-4), got / fx["h3d.train.gradnorm"]
+
+
+def trajectory_case():
+    """Inputs of tests/golden/make_train_golden.py, from seeds alone: one 4-clip batch (the seed rows written into x0 as
+    `_g_training` reads them back, diffusion_rvqvae_trainer.py:346-349) and the per-step noise."""
+    y = synth.synth_clip_inputs(4, seed=41)
+    x0 = synth.synth_latent(4, seed=41, name="x0")
+    lat = x0.squeeze(2).permute(0, 2, 1).contiguous()
+    lat[:, :4] = y["seed"]
+    x0 = lat.permute(0, 2, 1).unsqueeze(2).contiguous()
+    y = dict(y, seed=lat[:, :4].clone())
+    eps = [synth.synth_latent(4, seed=60 + k, name="eps") for k in range(5)]
+    return y, x0, eps
+
+
+def test_five_step_training_trajectory_matches_the_reference_loop():
+    """K = 5 steps of the reference's OWN training code - `_g_training` lifted from diffusion_rvqvae_trainer.py:339-356, its Adam from
+    optimizers/optim_factory.py:122-123, clip_grad_norm_(0.99), its UniformSampler - against oracle/train_ref.py: the loss of every step
+    (each depends on all the updates before it: 2.28 -> 1.49), the gradient norm clip_grad_norm_ saw, the parameter changes of ten named
+    tensors after the five updates, and the BatchNorm buffers after five training forwards."""
+    from oracle import train_ref
+    g = np.load(os.path.join(GOLD, "train_trajectory.npz"))
+    y, x0, eps = trajectory_case()
+    sd = {k: v.clone() for k, v in synth_state_dict("beatx").items()}
+    init = {str(n): sd[str(n)].clone() for n in g["watch"]}
+    t_steps = [torch.from_numpy(row) for row in g["t"]]
+    np.random.seed(100)                                    # the timesteps are what the reference's sampler drew from numpy's global RNG
+    from syntalker_amd.resample import UniformSampler
+    from syntalker_amd.process import create_gaussian_diffusion
+    assert UniformSampler(create_gaussian_diffusion()).sample(4, "cpu")[0].tolist() == g["t"][0].tolist()
+    losses, norms = train_ref.train_trajectory(sd, y, x0, t_steps, eps)
+    print("loss got / want:", np.array(losses) / g["loss"], "norm got / want:", np.array(norms) / g["grad_norm"])
+    assert np.allclose(losses, g["loss"], rtol=1e-5), (losses, g["loss"])
+    assert np.allclose(norms, g["grad_norm"], rtol=2e-4), (norms, g["grad_norm"])
+    worst = 0.0
+    for n in init:
+        d = (sd[n].detach() - init[n]).reshape(-1)
+        assert abs(float(d.double().norm()) / float(g[f"delta_norm.{n}"]) - 1) < 1e-3, n
+        e = float((d[:4096] - torch.from_numpy(g[f"delta_head.{n}"])).norm() / torch.from_numpy(g[f"delta_head.{n}"]).norm())
+        worst = max(worst, e)
+        assert e < 1e-5, (n, e)        # (measured 0: gradient differences of 1e-7 relative move an update of ~5e-5 by less than the parameter's fp32 spacing)
+    print(f"worst parameter-delta rel-L2 vs the reference loop: {worst:.2e}")
+    for n in ("WavEncoder.feat_extractor.0.bn1.running_mean", "WavEncoder.feat_extractor.5.bn2.running_var", "WavEncoder.feat_extractor.0.bn1.num_batches_tracked"):
+        assert np.allclose(sd[n].double().numpy(), g[f"buffer.{n}"], rtol=1e-5, atol=1e-6), n
