@@ -25,6 +25,8 @@ def frechet_from_stats(mu1, c1, mu2, c2, eps: float = 1e-6) -> float:
         off = np.eye(c1.shape[0]) * eps
         covmean = linalg.sqrtm((c1 + off).dot(c2 + off))
     if np.iscomplexobj(covmean):
+        if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):       # :1675-1678 raises ValueError, which `frechet_distance` (:1615-1626) turns into 1e10
+            return 1e10
         covmean = covmean.real
     d = mu1 - mu2
     return float(d.dot(d) + np.trace(c1) + np.trace(c2) - 2.0 * np.trace(covmean))
