@@ -180,6 +180,34 @@ class GaussianDiffusion:
         return (mean, self._tab("posterior_variance", t, x_t).expand(x_t.shape),
                 self._tab("posterior_log_variance_clipped", t, x_t).expand(x_t.shape))
 
+    def q_mean_variance(self, x_start, t):
+        """gaussian_diffusion.py:218-233: mean, variance, log-variance of q(x_t | x_0)."""
+        return (self._tab("sqrt_alphas_cumprod", t, x_start) * x_start,
+                self._tab_expr("one_minus_ac", lambda: 1.0 - self.alphas_cumprod, t, x_start).expand(x_start.shape),
+                self._tab("log_one_minus_alphas_cumprod", t, x_start).expand(x_start.shape))
+
+    def _tab_expr(self, key, make, t, like):
+        """`_tab` for a table the reference derives in fp64 at the call site (e.g. 1 / posterior_mean_coef1) before the fp32 gather."""
+        k = ("expr", key, t.device)
+        if k not in self._dev:
+            self._dev[k] = torch.from_numpy(np.asarray(make(), dtype=np.float64)).float().to(t.device)
+        return self._dev[k][t].view(-1, *([1] * (like.dim() - 1)))
+
+    def _predict_xstart_from_eps(self, x_t, t, eps):
+        """gaussian_diffusion.py:399-404."""
+        assert x_t.shape == eps.shape
+        return self._tab("sqrt_recip_alphas_cumprod", t, x_t) * x_t - self._tab("sqrt_recipm1_alphas_cumprod", t, x_t) * eps
+
+    def _predict_xstart_from_xprev(self, x_t, t, xprev):
+        """gaussian_diffusion.py:406-414: (xprev - coef2 x_t) / coef1."""
+        assert x_t.shape == xprev.shape
+        return (self._tab_expr("inv_c1", lambda: 1.0 / self.posterior_mean_coef1, t, x_t) * xprev
+                - self._tab_expr("c2_over_c1", lambda: self.posterior_mean_coef2 / self.posterior_mean_coef1, t, x_t) * x_t)
+
+    def _predict_eps_from_xstart(self, x_t, t, pred_xstart):
+        """gaussian_diffusion.py:416-420."""
+        return (self._tab("sqrt_recip_alphas_cumprod", t, x_t) * x_t - pred_xstart) / self._tab("sqrt_recipm1_alphas_cumprod", t, x_t)
+
     # ---- generic (any model) reverse step ---------------------------------------------------------
     def _scale_timesteps(self, t):
         return t
@@ -232,6 +260,29 @@ class GaussianDiffusion:
             noise = torch.randn_like(x)
         mean = x0 * torch.sqrt(abp) + torch.sqrt(1 - abp - sigma ** 2) * eps
         return {"sample": mean + self._nonzero(t, x) * sigma * noise, "pred_xstart": x0}
+
+    def ddim_reverse_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, eta=0.0):
+        """gaussian_diffusion.py:850-886: x_{t+1} by the deterministic DDIM ODE run backwards (generic path: one model call)."""
+        assert eta == 0.0, "Reverse ODE only for deterministic path"
+        out = self.p_mean_variance(model, x, t, clip_denoised, denoised_fn, model_kwargs)
+        eps = self._predict_eps_from_xstart(x, t, out["pred_xstart"])
+        abn = self._tab("alphas_cumprod_next", t, x)
+        return {"sample": out["pred_xstart"] * torch.sqrt(abn) + torch.sqrt(1 - abn) * eps, "pred_xstart": out["pred_xstart"]}
+
+    # What the reference's GaussianDiffusion also defines and none of its trainers, tests or demos reaches (SURVEY.md §2 #1): explicit errors
+    # naming the reference lines instead of AttributeError.
+    def _unsupported(name, where):
+        def method(self, *a, **k):
+            raise NotImplementedError(f"GaussianDiffusion.{name} (reference diffusion/gaussian_diffusion.py:{where}) is not on the path any of the "
+                                      "reference's callers takes (train.py / test.py / demo.py use p_sample_loop, ddim_sample_loop, training_losses); "
+                                      "not built")
+        method.__name__ = name
+        return method
+    for _n, _w in (("plms_sample", "1004"), ("plms_sample_loop", "1088"), ("plms_sample_loop_progressive", "1130"), ("_vb_terms_bpd", "1201"),
+                   ("_prior_bpd", "1530"), ("calc_bpd_loop", "1548"), ("p_sample_with_grad", "559"), ("ddim_sample_with_grad", "793"),
+                   ("condition_mean", "427"), ("condition_mean_with_grad", "442"), ("condition_score", "457"), ("condition_score_with_grad", "481")):
+        locals()[_n] = _unsupported(_n, _w)
+    del _n, _w, _unsupported
 
     # ---- loops ---------------------------------------------------------------------------------------
     def _start(self, shape, noise, device, skip_timesteps, init_image):

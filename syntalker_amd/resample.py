@@ -23,7 +23,19 @@ class UniformSampler:
                 torch.from_numpy(1 / (len(p) * p[idx])).float().to(device))
 
 
+class LossSecondMomentResampler:
+    """resample.py:124-154 (importance sampling from a history of per-timestep losses, fed by `update_with_local_losses`, resample.py:70-121, with
+    an all_gather per step).  The reference's trainers hard-code 'uniform' (diffusion_rvqvae_trainer.py:186): not built."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("LossSecondMomentResampler (reference diffusion/resample.py:124) is never selected by the reference's trainers "
+                                  "(schedule_sampler_type = 'uniform', diffusion_rvqvae_trainer.py:186); not built")
+
+
 def create_named_schedule_sampler(name, diffusion):
+    """resample.py:8-22."""
     if name == "uniform":
         return UniformSampler(diffusion)
-    raise NotImplementedError(f"unknown or unsupported schedule sampler: {name}")
+    if name == "loss-second-moment":
+        return LossSecondMomentResampler(diffusion)
+    raise NotImplementedError(f"unknown schedule sampler: {name}")

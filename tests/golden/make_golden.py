@@ -305,8 +305,48 @@ def main_loop_kwargs():
         print(f"{k:24s} {tuple(v.shape)}" + (f" {float(np.abs(v).mean()):.4f}" if v.dtype.kind == "f" else ""))
 
 
+class ToyDenoiser(torch.nn.Module):
+    """A denoiser-shaped function for the parts of the API that only need *a* model (the diffusion classes call model(x, t, **model_kwargs))."""
+
+    def forward(self, x, t, y=None):
+        return 0.8 * torch.tanh(x) + 0.0005 * t.view(-1, 1, 1, 1).float() + y["seed"].mean(dim=(1, 2)).view(-1, 1, 1, 1)
+
+
+def surface_inputs():
+    x = synth.synth_latent(3, seed=71, name="surface.x")[:, :48]
+    other = synth.synth_latent(3, seed=72, name="surface.other")[:, :48]
+    y = {"seed": synth.synth_clip_inputs(3, seed=73)["seed"], "mask": torch.ones(3, 1, 1, 32, dtype=torch.bool)}
+    return x, other, y
+
+
+def main_surface():
+    """The rest of GaussianDiffusion's public surface: q_mean_variance (gaussian_diffusion.py:218), _predict_xstart_from_eps /
+    _from_xprev / _predict_eps_from_xstart (:399-420), ddim_reverse_sample (:850) on the full and the ddim50-spaced process -> surface_outputs.npz."""
+    torch.manual_seed(0)
+    _, _, make_diff, _, _ = import_reference()
+    x, other, y = surface_inputs()
+    out = {}
+    with torch.no_grad():
+        for tag, ddim, t in (("ddpm", False, torch.tensor([0, 412, 999])), ("ddim", True, torch.tensor([0, 23, 49]))):
+            d = make_diff(use_ddim=ddim)
+            for i, v in enumerate(d.q_mean_variance(x, t)):
+                out[f"{tag}.q_mean_variance.{i}"] = f32(v)
+            out[f"{tag}.xstart_from_eps"] = f32(d._predict_xstart_from_eps(x, t, other))
+            out[f"{tag}.xstart_from_xprev"] = f32(d._predict_xstart_from_xprev(x, t, other))
+            out[f"{tag}.eps_from_xstart"] = f32(d._predict_eps_from_xstart(x, t, other))
+            r = d.ddim_reverse_sample(ToyDenoiser(), x, t, clip_denoised=False, model_kwargs={"y": y})
+            out[f"{tag}.ddim_reverse.sample"], out[f"{tag}.ddim_reverse.pred_xstart"] = f32(r["sample"]), f32(r["pred_xstart"])
+            r = d.ddim_reverse_sample(ToyDenoiser(), x, t, clip_denoised=True, model_kwargs={"y": y})
+            out[f"{tag}.ddim_reverse_clipped.sample"] = f32(r["sample"])
+    np.savez_compressed(os.path.join(HERE, "surface_outputs.npz"), **out)
+    for k, v in out.items():
+        print(f"{k:36s} {tuple(v.shape)} {float(np.abs(v).mean()):.5f}")
+
+
 if __name__ == "__main__":
     if "loop_kwargs" in sys.argv[1:]:
         main_loop_kwargs()
+    elif "surface" in sys.argv[1:]:
+        main_surface()
     else:
         main()

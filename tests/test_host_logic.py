@@ -425,3 +425,46 @@ def test_space_timesteps_over_other_specifications_matches_reference():
         process.space_timesteps(10, "7,7")
     with pytest.raises(ValueError):
         process.space_timesteps(1000, "ddim999")
+
+
+def test_rest_of_the_gaussian_diffusion_surface_matches_reference():
+    """q_mean_variance, _predict_xstart_from_eps / _from_xprev, _predict_eps_from_xstart, ddim_reverse_sample (gaussian_diffusion.py:218, 399-420,
+    850) on the generic torch path against the reference's outputs (tests/golden/make_golden.py surface), full and ddim50-spaced process; the
+    methods nobody reaches (plms_*, calc_bpd_loop, *_with_grad, condition_*) and the loss-second-moment resampler raise NotImplementedError
+    naming the reference line instead of AttributeError."""
+    import importlib.util
+    from syntalker_amd import process, resample
+    spec = importlib.util.spec_from_file_location("make_golden_surface", os.path.join(REPO, "tests", "golden", "make_golden.py"))
+    src = open(spec.origin).read()
+    ns = {"torch": torch, "synth": __import__("syntalker_amd.synth", fromlist=["synth"])}
+    # the generator's input recipe and toy model, without importing the module (its import pulls the reference tree onto sys.path)
+    import ast
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in ("ToyDenoiser", "surface_inputs")]
+    exec(compile(ast.Module(body=keep, type_ignores=[]), spec.origin, "exec"), ns)
+    x, other, y = ns["surface_inputs"]()
+    toy = ns["ToyDenoiser"]()
+    g = np.load(os.path.join(REPO, "tests", "golden", "surface_outputs.npz"))
+    def close(a, name):
+        return (np.allclose(a.numpy(), g[name], rtol=2e-6, atol=1e-6 * float(np.abs(g[name]).max())), name)
+    with torch.no_grad():
+        for tag, ddim, t in (("ddpm", False, torch.tensor([0, 412, 999])), ("ddim", True, torch.tensor([0, 23, 49]))):
+            d = process.create_gaussian_diffusion(use_ddim=ddim)
+            for i, v in enumerate(d.q_mean_variance(x, t)):
+                assert close(v, f"{tag}.q_mean_variance.{i}")[0], (tag, i)
+            assert close(d._predict_xstart_from_eps(x, t, other), f"{tag}.xstart_from_eps")[0]
+            assert close(d._predict_xstart_from_xprev(x, t, other), f"{tag}.xstart_from_xprev")[0]
+            assert close(d._predict_eps_from_xstart(x, t, other), f"{tag}.eps_from_xstart")[0]
+            r = d.ddim_reverse_sample(toy, x, t, clip_denoised=False, model_kwargs={"y": y})
+            assert close(r["sample"], f"{tag}.ddim_reverse.sample")[0] and close(r["pred_xstart"], f"{tag}.ddim_reverse.pred_xstart")[0]
+            r = d.ddim_reverse_sample(toy, x, t, clip_denoised=True, model_kwargs={"y": y})
+            assert close(r["sample"], f"{tag}.ddim_reverse_clipped.sample")[0]
+    d = process.create_gaussian_diffusion()
+    for name in ("plms_sample", "plms_sample_loop", "plms_sample_loop_progressive", "calc_bpd_loop", "_vb_terms_bpd", "_prior_bpd", "p_sample_with_grad",
+                 "ddim_sample_with_grad", "condition_mean", "condition_score"):
+        with pytest.raises(NotImplementedError, match="gaussian_diffusion.py"):
+            getattr(d, name)(None)
+    with pytest.raises(NotImplementedError, match="resample.py:124"):
+        resample.create_named_schedule_sampler("loss-second-moment", d)
+    with pytest.raises(AssertionError):
+        d.ddim_reverse_sample(toy, x, torch.tensor([0, 1, 2]), model_kwargs={"y": y}, eta=0.5)
