@@ -81,65 +81,77 @@ STAGE_INFO_FUSED = {
 
 
 def cpu_baseline(budget_s: float):
-    """Reference forward as written (no hoisting / folding), fp32, torch CPU, B=1 — SURVEY.md §8d protocol.
-    torch's intra-op threading does not scale to every core on a 32-token problem, so a short probe picks the
-    fastest of {all cores, 32, 16, 8} threads and the bounded sample is timed with that setting."""
+    """Reference forward as written (no hoisting / folding), fp32, torch CPU, B=1 - SURVEY.md §8d protocol.
+    torch's intra-op threading does not scale to every core on a 32-token problem, so a probe (>= 10 forwards per setting) ranks
+    {all cores, 32, 16, 8} threads; the reported value is the MEDIAN of three equal windows at the probe's winner, with their spread.
+    A box whose sustained rate falls more than 25 % short of its own probe (round 4's driver box: probe 77, sustained 39.5 - the thread pool
+    was re-sized four times in front of the sample) also times the runner-up and keeps the better one, and the line says so."""
     from oracle import denoiser_ref as dr
     from syntalker_amd import synth
     from tests.refmodel import synth_state_dict
     sd = synth_state_dict("beatx")
     y, x = synth.synth_clip_inputs(1, seed=1), synth.synth_latent(1, seed=1)
     all_cores = torch.get_num_threads()
-    best, probe = None, {}
+
+    def window(seconds, min_n, fn):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fn(n)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt > seconds and n >= min_n:
+                return n, dt
+
+    as_written = lambda i: dr.mdm_forward(sd, x, torch.tensor([996 - i % 900]), y)
+
+    def sustained(nt):
+        """three windows at nt threads -> (median rate, spread = (max - min) / median, forwards, seconds)"""
+        torch.set_num_threads(nt)
+        for i in range(3):
+            as_written(i)                                   # the pool at its new size, warm
+        wins = [window(budget_s / 3, 7, as_written) for _ in range(3)]
+        rates = sorted(n / dt for n, dt in wins)
+        return rates[1], (rates[2] - rates[0]) / rates[1], sum(n for n, _ in wins), sum(dt for _, dt in wins)
+
+    probe, note = {}, ""
     with torch.no_grad():
         for nt in sorted({all_cores, 32, 16, 8}, reverse=True):
             if nt > all_cores:
                 continue
             torch.set_num_threads(nt)
-            dr.mdm_forward(sd, x, torch.tensor([999]), y)
-            t0 = time.perf_counter()
-            for i in range(3):
-                dr.mdm_forward(sd, x, torch.tensor([998 - i]), y)
-            probe[nt] = 3 / (time.perf_counter() - t0)
-            if best is None or probe[nt] > probe[best]:
-                best = nt
+            as_written(0); as_written(1)
+            n, dt = window(0.25, 10, as_written)
+            probe[nt] = n / dt
+        ranked = sorted(probe, key=probe.get, reverse=True)
+        best = ranked[0]
+        value, spread, n, dt = sustained(best)
+        if value < 0.75 * probe[best]:
+            note = f"; sustained rate at {best} threads ({value:.1f}) was more than 25 % below its probe ({probe[best]:.1f})"
+            if len(ranked) > 1:
+                v2, s2, n2, dt2 = sustained(ranked[1])
+                note += f", runner-up {ranked[1]} threads sustained {v2:.1f}"
+                if v2 > value:
+                    best, value, spread, n, dt = ranked[1], v2, s2, n2, dt2
+            note += f": reported = the better one ({best} threads)"
         torch.set_num_threads(best)
-        n, t0 = 0, time.perf_counter()
-        while True:
-            dr.mdm_forward(sd, x, torch.tensor([996 - n % 900]), y)
-            n += 1
-            dt = time.perf_counter() - t0
-            if dt > budget_s and n >= 20:
-                break
         # the same CPU path with the build's algebra (conditioning hoisted, input stage folded), so that the GPU
         # speed-up can be split into its algorithmic and its hardware part (BASELINE.md 3)
         fw = dr.fold_weights(sd)
         cond, te = dr.clip_conditioning(sd, y, fw), dr.time_table(sd, fw)
-        nh, t1 = 0, time.perf_counter()
-        while True:
-            dr.mdm_forward_folded(sd, fw, cond, te, x, torch.tensor([996 - nh % 900]))
-            nh += 1
-            dth = time.perf_counter() - t1
-            if dth > budget_s / 4 and nh >= 20:
-                break
+        nh, dth = window(budget_s / 4, 20, lambda i: dr.mdm_forward_folded(sd, fw, cond, te, x, torch.tensor([996 - i % 900])))
         # SURVEY 8d also asks for B = 40 (the reference's own test batch): a bounded sample of whole-batch forwards
         y40, x40 = synth.synth_clip_inputs(40, seed=2), synth.synth_latent(40, seed=2)
         dr.mdm_forward(sd, x40, torch.full((40,), 999), y40)
-        n40, t2 = 0, time.perf_counter()
-        while True:
-            dr.mdm_forward(sd, x40, torch.full((40,), 996 - n40), y40)
-            n40 += 1
-            dt40 = time.perf_counter() - t2
-            if dt40 > budget_s / 3 and n40 >= 2:
-                break
+        n40, dt40 = window(budget_s / 3, 2, lambda i: dr.mdm_forward(sd, x40, torch.full((40,), 996 - i), y40))
     torch.set_num_threads(all_cores)
-    return {"value": round(n / dt, 2), "unit": "clip-steps/s", "cores": best, "kind": "port",
+    return {"value": round(value, 2), "unit": "clip-steps/s", "cores": best, "kind": "port", "spread": round(spread, 3),
+            "probe": {str(k): round(v, 1) for k, v in probe.items()}, "sustained_over_probe": round(value / probe[best], 3),
             "hoisted_value": round(nh / dth, 2), "value_b40": round(40 * n40 / dt40, 2),
-            "sample": f"{n} as-written MDM forwards at B=1 (fp32, torch {torch.__version__} CPU, {best} of {all_cores} "
-                      f"threads = fastest of a probe {({k: round(v, 1) for k, v in probe.items()})}, conditioning "
-                      f"recomputed every step like the reference), {dt:.1f} s; hoisted_value = the same with the conditioning "
-                      f"computed once and the input stage folded ({nh} forwards, {dth:.1f} s); value_b40 = as-written forwards at B=40 "
-                      f"({n40} forwards, {dt40:.1f} s, same thread count)"}
+            "sample": f"median of three {budget_s / 3:.1f}-s windows ({n} as-written MDM forwards at B=1 in all, {dt:.1f} s; spread (max - min) / median = "
+                      f"{spread:.1%}); fp32, torch {torch.__version__} CPU, {best} of {all_cores} threads = the winner of a probe of >= 10 forwards per "
+                      f"setting {({k: round(v, 1) for k, v in probe.items()})}{note}; conditioning recomputed every step like the reference; "
+                      f"hoisted_value = the same with the conditioning computed once and the input stage folded ({nh} forwards, {dth:.1f} s); "
+                      f"value_b40 = as-written forwards at B=40 ({n40} forwards, {dt40:.1f} s, same thread count)"}
 
 
 def small_batch_probe(pm, coef, dev, sizes=(1, 8, 16, 32, 64, 256), reps=300):
@@ -398,6 +410,7 @@ def run_guided(args, rank, local, world, dev, dist):
             print(f"[guided] {tag[:40]} B={B}", file=sys.stderr, flush=True)
         chunk = 128
         plan = sb = None
+        cond_ms = 0.0
         for b0 in range(0, B, chunk):                               # conditioning of all variants, once per clip, in chunks
             n = min(chunk, B - b0)
             y = synth.to_device(synth.synth_clip_inputs(n, seed=1000 * rank + b0 + 7, style_dim=256, style_zero=False), dev)
@@ -407,7 +420,14 @@ def run_guided(args, rank, local, world, dev, dist):
             if sb is None:
                 sb = mdm.step_buffers(B, V)
                 sb.cfg_w.copy_(plan.tensor(dev))
-            sb.cond.view(V, B, 32, 512)[:, b0:b0 + n].copy_(mdm.variant_conds(y, plan.variants).reshape(V, n, 32, 512))
+                mdm.variant_conds(y, plan.variants)                 # (first call of the process: lazy initialisation, not timed)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            cv = mdm.variant_conds(y, plan.variants)
+            e1.record()
+            sb.cond.view(V, B, 32, 512)[:, b0:b0 + n].copy_(cv.reshape(V, n, 32, 512))
+            torch.cuda.synchronize()
+            cond_ms += e0.elapsed_time(e1)
         V = len(plan.variants)
         sb.load_x(torch.randn(B, 1536, 1, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(rank)))
         sb.set_rng(4321, first_clip=rank * B)
@@ -430,6 +450,13 @@ def run_guided(args, rank, local, world, dev, dist):
                                     f"{evals}); duration = hipEvents around the replays of the timed region"}}
         if steady_ms is not None:
             out["steady_state_ms_per_step"] = round(steady_ms, 4)
+        # what the per-clip conditioning (outside the timed region: once per clip, all V variants) adds to a whole loop of this sampler
+        L = 1000 if noisy else 50
+        loop_ms = L * dt / K * 1e3
+        out["per_clip_conditioning"] = {"ms_per_clip": round(cond_ms / B, 5), "loop_steps": L, "share_of_a_whole_loop": round(cond_ms / (cond_ms + loop_ms), 4),
+                                        "clip_steps_per_s_including_it": round(world * B * L / ((cond_ms + loop_ms) * 1e-3), 1),
+                                        "note": f"audio encoder + word / seed / style paths for the {V} variants of {B} clips, hipEvent-timed, NOT in guided_clip_steps_per_s: "
+                                                f"it is paid once per clip, i.e. spread over the {L} steps of this sampler's loop"}
         del sb
         return out
 
@@ -449,7 +476,7 @@ def run_guided(args, rank, local, world, dev, dist):
             "config": {"workload": main["workload"], "clips_per_gpu": B3, "variants": main["variants"], "global_clips": world * B3,
                        "parallelism": f"clip-sharded x{world}, no collective", "primed_steps": args.prime * LOOP_CH},
             "reference_evaluation_equivalents_per_s": main["reference_evaluation_equivalents_per_s"],
-            "roofline": main["roofline"], "steady_state_ms_per_step": main.get("steady_state_ms_per_step"),
+            "roofline": main["roofline"], "steady_state_ms_per_step": main.get("steady_state_ms_per_step"), "per_clip_conditioning": main.get("per_clip_conditioning"),
             "ddim50": d50, "bodypart_twocfg": body}
 
 
@@ -492,7 +519,7 @@ def extras(args, local, dev) -> dict:
     try:
         gd = run_guided(sub, 0, local, 1, dev, None)
         keep = ("workload", "clips_per_gpu", "variants", "reference_evaluations_per_step", "guided_clip_steps_per_s", "ms_per_step",
-                "reference_evaluation_equivalents_per_s", "steady_state_ms_per_step")
+                "reference_evaluation_equivalents_per_s", "steady_state_ms_per_step", "per_clip_conditioning")
         def brief(d):
             b = {k: d[k] for k in keep if k in d}
             rf = d.get("roofline") or {}
@@ -501,7 +528,7 @@ def extras(args, local, dev) -> dict:
         main_ = {"workload": gd["config"]["workload"], "clips_per_gpu": gd["config"]["clips_per_gpu"], "variants": gd["config"]["variants"],
                  "reference_evaluations_per_step": 2, "guided_clip_steps_per_s": gd["value"], "ms_per_step": gd["ms_per_step"],
                  "reference_evaluation_equivalents_per_s": gd["reference_evaluation_equivalents_per_s"],
-                 "steady_state_ms_per_step": gd.get("steady_state_ms_per_step"), "roofline": gd["roofline"]}
+                 "steady_state_ms_per_step": gd.get("steady_state_ms_per_step"), "roofline": gd["roofline"], "per_clip_conditioning": gd.get("per_clip_conditioning")}
         out["guided"] = {"steps": gd["steps"], "warmup": gd["warmup"], "cfg_ddpm": brief(main_), "cfg_ddim50": brief(gd["ddim50"]),
                          "bodypart_twocfg_ddim50": brief(gd["bodypart_twocfg"])}
     except Exception as e:

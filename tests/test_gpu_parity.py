@@ -272,7 +272,7 @@ def test_cpu_tensors_fail_loudly():
 
 
 def test_bench_size_batch_is_copies_of_its_clips(beatx):
-    """The bench batch (1024 clips = 512 workgroups of the whole-step kernel, two rounds on the chip) built as 128 copies
+    """The bench batch (1024 clips = 256 workgroups x 4 waves of the wave-per-sequence kernel k_seq, one sequence per wave) built as 128 copies
     of 8 distinct clips: every copy must carry the bits of the original wherever it sits in the batch, and the 8
     originals must match the CPU oracle.  Conditioning is computed once for the 8 clips and tiled (see
     test_batch_rows_are_independent for why)."""
