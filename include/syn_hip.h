@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define SYN_ABI_VERSION 6     /* 6: pose formats either side of the RVQ-VAEs - syn_axis_angle_to_rot6d, syn_rot6d_to_axis_angle;
+#define SYN_ABI_VERSION 7     /* 7: fused tail of the audio encoder's BasicBlock in training (syn_bn_finalize / syn_bn_apply2 / syn_bn_block_bwd,
+                                * syn_conv1d_train_fwd_norm / _wgrad_norm, syn_conv1d_first_fwd_stats / _tiles), syn_test_mfma_rate;
+                                * 6: pose formats either side of the RVQ-VAEs - syn_axis_angle_to_rot6d, syn_rot6d_to_axis_angle;
                                 * 5: training block entry points - bf16 outputs of syn_ln_fwd / syn_gelu_fwd / syn_attn_fwd, syn_linear_res (residual + DropPath factor
                                 * in the GEMM's epilogue), syn_linear_bwd_prep row_scale, syn_linear_pair bias_grad;
                                 * 4: syn_model.tape carries its first 4 chunks again behind the last (no wrap test in k_seq's weight stream);
@@ -188,6 +190,11 @@ int syn_conv1d_first_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
                          void* stream);
 int syn_conv1d_first_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws,
                            float* dw, void* stream);
+/* (ABI 7) the forward with the BatchNorm statistics of its output from the same launch: bn_part (NULL, or syn_conv1d_first_tiles(n_clips, l_out) x 2 x 64
+ * floats) = per-workgroup sum and sum of squares of every output channel, what syn_bn_finalize takes (chunks = that tile count). */
+int32_t syn_conv1d_first_tiles(int32_t n_clips, int32_t l_out);
+int syn_conv1d_first_fwd_stats(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, const float* w, float* y,
+                               float* bn_part, void* stream);
 
 /* The two fragment sets syn_conv1d_train_fwd takes, from the module's weight w [cout][cin][15] (fp32) in one launch; each
  * output holds syn_conv1d_pack_bytes(...) bytes.  transposed = 1: the matrix of the DATA GRADIENT (stride 1; for a strided
@@ -214,6 +221,14 @@ int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
  * of every output channel, straight from the accumulators - the BatchNorm that follows takes them as syn_bn_act_fwd's ws with
  * ws_chunks = that tile count and skips its own pass over y. */
 int32_t syn_conv1d_train_fwd_tiles(int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, int32_t cout);
+/* (ABI 7) the stride-1 layers with the BatchNorm (+ LeakyReLU) of the convolution in front applied to the input as it is staged - x is that
+ * convolution's raw output, the kernel reads act(x * in_affine[0][c] + in_affine[1][c]) (in_affine [2][cin] from syn_bn_finalize; in_act != 0:
+ * LeakyReLU(0.01)), zero outside the clip; no bias.  The weight gradient with the same view of x. */
+int syn_conv1d_train_fwd_norm(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
+                              const void* w_hi, const void* w_lo, int32_t cout, const float* in_affine, int32_t in_act, float* y, float* bn_part,
+                              void* stream);
+int syn_conv1d_train_wgrad_norm(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
+                                int32_t cout, const float* in_affine, int32_t in_act, float* ws, float* dw, void* stream);
 
 /* Every bf16 fragment set the training step's Linear layers need, from the fp32 master weights in ONE launch (the weights change
  * once per step, in optimizer.step()): job j packs src (n x k row-major, transposed = 0: as syn_pack_weight; k x n row-major,
@@ -276,6 +291,26 @@ int syn_bn_bwd_sums(const float* dz, const float* z, const float* y, const float
 int syn_bn_act_bwd_apply(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, const float* beta,
                          const double* sums_local, const double* sums_total, int64_t rows, int64_t rows_total, int32_t channels, int32_t act,
                          float* dgamma_dbeta, float* scratch, float* dy, float* dshortcut, void* stream);
+
+/* (ABI 7) The same block tail with fewer passes over its tensors (models/utils/layer.py:171-184: conv1 -> bn1 -> act -> conv2 -> bn2 (+ shortcut | + bn(conv(x)))
+ * -> act).  A batch-statistics BatchNorm is a per-channel affine map a(v) = v * scale + shift once its statistics exist:
+ *   syn_bn_finalize   part [chunks][2][channels] (sum, sum of squares: a convolution's bn_part) -> stats [2][channels] = mean, rstd; affine [2][channels] =
+ *                     scale = rstd gamma, shift = beta - mean rstd gamma; running statistics as nn.BatchNorm1d updates them (conv_bias as in syn_bn_act_fwd)
+ *   syn_bn_apply2     z = act(a(y) + s), s = a_s(shortcut) when short_affine is given (the down-sampling branch's BatchNorm, applied here instead of in a
+ *                     pass of its own), the raw shortcut otherwise, nothing when shortcut is NULL
+ *   syn_bn_block_bwd  from dz = d loss / d z: dp = dz act'(p) with the pre-activation p RECOMPUTED from y and the shortcut (the block's output is neither
+ *                     read nor needed by the backward); dgb [3][channels] = dgamma, dbeta, 0 of a; dy; with a normalised shortcut also short_dgb and
+ *                     dshortcut = the data gradient of ITS BatchNorm, with a raw one dshortcut = dp.  One statistics pass and one apply pass over
+ *                     (dz, y, shortcut) for both BatchNorms.  ws: 3 * syn_bn_chunks(rows) * channels floats.
+ * bn1 + LeakyReLU in front of conv2 is applied by conv2 itself while it stages its input (syn_conv1d_train_fwd_norm; the weight gradient recomputes it the
+ * same way, syn_conv1d_train_wgrad_norm): in_affine [2][cin] = bn1's affine, in_act != 0: LeakyReLU(0.01); positions outside the clip stay zero. */
+int syn_bn_finalize(const float* part, int32_t chunks, int64_t rows, int32_t channels, const float* gamma, const float* beta, float eps, float momentum,
+                    float* run_mean, float* run_var, const float* conv_bias, float* stats, float* affine, void* stream);
+int syn_bn_apply2(const float* y, const float* affine, const float* shortcut, const float* short_affine, int64_t rows, int32_t channels, int32_t act,
+                  float* z, void* stream);
+int syn_bn_block_bwd(const float* dz, const float* y, const float* shortcut, const float* stats, const float* affine, const float* short_stats,
+                     const float* short_affine, int64_t rows, int32_t channels, int32_t act, float* ws, float* dgb, float* short_dgb, float* dy,
+                     float* dshortcut, void* stream);
 
 /* (ABI 5) The optimizer step of the reference's training loop (diffusion_rvqvae_trainer.py:351-356: clip_grad_norm_(grad_norm), then Adam)
  * over lists of <= SYN_OPT_MAX fp32 tensors, pointers as kernel arguments (a captured step holds them by value):
@@ -482,6 +517,10 @@ int syn_test_gemm(const void* x_bf16, const void* w_packed, const float* bias, i
  * old value.  sync [320] and stale [9] zeroed by the caller; buf [8][4096]. */
 int syn_test_handoff(uint32_t* sync_320_zeroed, uint32_t* buf_8x4096, const float* stream, int64_t stream_n, uint32_t* stale_9_zeroed,
                      int32_t words, int32_t rounds, int32_t mode, void* stream_h);
+/* (ABI 7) the matrix pipe alone in k_seq's occupancy (one wave per SIMD, 12 independent v_mfma_f32_32x32x16_bf16 accumulators, register operands): iters x 192
+ * MFMAs per wave on every CU; out: 256 floats per CU (keeps the loop alive); *flops (host, may be NULL) = the floating-point operations of the launch.
+ * Timed by bench.py as roofline.practical_peak: what the chip delivers on this instruction at the clock it holds under that load. */
+int syn_test_mfma_rate(int32_t iters, float* out, int64_t* flops, void* stream);
 /* attention over ws_q/ws_k/ws_vt -> ws_o for n_seq sequences of 32 tokens, 4 heads x 128. */
 int syn_test_attention(const void* q, const void* k, const void* vt, int32_t n_seq, void* o, void* stream);
 

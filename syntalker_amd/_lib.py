@@ -13,14 +13,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SYN_HIP_LIB") or os.path.join(_HERE, "csrc", "libsyn_hip.so")   # env override: kernel A/B builds
 
 SYN_LAYERS = 8
-ABI_VERSION = 6             # include/syn_hip.h SYN_ABI_VERSION: a library built from other sources is refused at load time
+ABI_VERSION = 7             # include/syn_hip.h SYN_ABI_VERSION: a library built from other sources is refused at load time
 EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_steps", "syn_denoise_step_profile", "syn_pack_weight", "syn_pack_weight_t", "syn_to_token_major",
            "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_linear_pair", "syn_linear_and_pack", "syn_linear_res", "syn_linear_gelu", "syn_opt_blocks", "syn_opt_sqnorm", "syn_opt_scalars", "syn_opt_adam", "syn_test_gemm", "syn_test_attention", "syn_test_handoff",
            "syn_wav_encode", "syn_wav_workspace_bytes", "syn_wav_out_frames", "syn_linear_bwd_prep", "syn_embedding_wgrad", "syn_pack_weights", "syn_bn_chunks", "syn_bn_act_fwd", "syn_bn_act_bwd", "syn_bn_sums", "syn_bn_act_apply", "syn_bn_bwd_sums", "syn_bn_act_bwd_apply", "syn_conv1d_train_fwd", "syn_conv1d_train_fwd_tiles", "syn_conv1d_pack_split", "syn_conv1d_pack_split_many", "syn_conv1d_pack_bytes", "syn_conv1d_train_dgrad_strided", "syn_conv1d_train_wgrad", "syn_conv1d_wgrad_shares", "syn_conv1d_first_parts", "syn_conv1d_first_fwd", "syn_conv1d_first_wgrad", "syn_cond_encode",
            "syn_vq_conv1d", "syn_vq_quantize", "syn_vq_quantize_groups", "syn_vq_codes",
            "syn_vq_workspace_bytes", "syn_vq_map2latent", "syn_vq_latent2origin", "syn_vq_forward_decoder",
            "syn_step_advance", "syn_steps_advance", "syn_prefers_fragment_order", "syn_x_to_fragment", "syn_x_from_fragment", "syn_ln_fwd", "syn_ln_bwd", "syn_gelu_fwd", "syn_gelu_bwd", "syn_attn_fwd", "syn_attn_bwd",
-           "syn_axis_angle_to_rot6d", "syn_rot6d_to_axis_angle", "syn_rotary", "syn_linear_wgrad_rows", "syn_masked_smooth_l1")
+           "syn_axis_angle_to_rot6d", "syn_rot6d_to_axis_angle", "syn_rotary", "syn_linear_wgrad_rows", "syn_masked_smooth_l1",
+           "syn_bn_finalize", "syn_bn_apply2", "syn_bn_block_bwd", "syn_conv1d_train_fwd_norm", "syn_conv1d_train_wgrad_norm", "syn_conv1d_first_tiles",
+           "syn_conv1d_first_fwd_stats", "syn_test_mfma_rate")
 
 # the `void syn_debug_*` switches of the header's diagnostics section (process-wide, A/B runs and scripts/ only)
 DIAGNOSTICS = ("syn_debug_timing", "syn_debug_gemm_resident", "syn_debug_linear_tile", "syn_debug_conv_terms", "syn_debug_seq_skew", "syn_debug_seq_step")
@@ -157,6 +159,14 @@ def load():
     lib.syn_bn_act_apply.argtypes = [vp, vp, C.c_int64, C.c_int64, i32, vp, vp, C.c_float, C.c_float, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.syn_bn_bwd_sums.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, i32, i32, vp, vp, vp]
     lib.syn_bn_act_bwd_apply.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, C.c_int64, i32, i32, vp, vp, vp, vp, vp]
+    lib.syn_bn_finalize.argtypes = [vp, i32, C.c_int64, i32, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp]
+    lib.syn_bn_apply2.argtypes = [vp, vp, vp, vp, C.c_int64, i32, i32, vp, vp]
+    lib.syn_bn_block_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_int64, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.syn_conv1d_train_fwd_norm.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, vp, vp]
+    lib.syn_conv1d_train_wgrad_norm.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
+    lib.syn_conv1d_first_tiles.argtypes = [i32, i32]
+    lib.syn_conv1d_first_fwd_stats.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.syn_test_mfma_rate.argtypes = [i32, vp, vp, vp]
     lib.syn_linear_bwd_prep.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.syn_pack_weights.argtypes = [vp, i32, C.c_int64, vp]
     lib.syn_embedding_wgrad.argtypes = [vp, vp, i32, i32, i32, vp, vp]

@@ -2536,6 +2536,17 @@ int syn_test_handoff(uint32_t* sync_320_zeroed, uint32_t* buf_8x4096, const floa
     return e == hipSuccess ? 0 : fail("k_handoff_stress launch", e);
 }
 
+int syn_test_mfma_rate(int32_t iters, float* out, int64_t* flops, void* stream) {
+    if (iters <= 0 || !out) return fail_msg("syn_test_mfma_rate: bad arguments (out: 256 floats per CU)");
+    static OncePerDevice once;
+    if (once.first()) { allow_lds(seq::k_mfma_rate, seq::kLds); }
+    const int cus = device_cus();
+    hipLaunchKernelGGL(seq::k_mfma_rate, dim3(cus), dim3(seq::kThreads), seq::kLds, (hipStream_t)stream, out, iters);
+    if (flops) *flops = (int64_t)cus * 4 * (int64_t)iters * 16 * 12 * (2LL * 32 * 32 * 16);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_mfma_rate launch", e);
+}
+
 int syn_test_attention(const void* q, const void* k, const void* vt, int32_t n_seq, void* o, void* stream) {
     if (!q || !k || !vt || !o || n_seq <= 0) return fail_msg("syn_test_attention: bad arguments");
     hipLaunchKernelGGL(k_attn, dim3(n_seq), dim3(256), 0, (hipStream_t)stream, (const __bf16*)q, (const __bf16*)k,
@@ -2630,6 +2641,45 @@ int syn_bn_act_bwd(const float* dz, const float* z, const float* y, const float*
                        channels, n4, (long)rows, act, dy, dshortcut);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("syn_bn_act_bwd", e);
+}
+
+/* ---- the fused tail of a BasicBlock (syn_train.inc): statistics -> per-channel affine; one elementwise pass per block and direction ---- */
+static bool bn_shape_ok(int64_t rows, int32_t channels) { return rows > 0 && channels > 0 && channels % 4 == 0 && 256 % (channels / 4) == 0 && channels <= 1024; }
+
+int syn_bn_finalize(const float* part, int32_t chunks, int64_t rows, int32_t channels, const float* gamma, const float* beta, float eps, float momentum,
+                    float* run_mean, float* run_var, const float* conv_bias, float* stats, float* affine, void* stream) {
+    if (!part || chunks <= 0 || !gamma || !beta || !stats || !affine || !bn_shape_ok(rows, channels)) return fail_msg("syn_bn_finalize: bad arguments");
+    hipLaunchKernelGGL(trn::k_bn_finalize_aff, dim3(channels), dim3(256), 0, (hipStream_t)stream, part, chunks, channels, (long)rows, eps, momentum, gamma, beta,
+                       stats, affine, run_mean, run_var, conv_bias);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_bn_finalize", e);
+}
+
+int syn_bn_apply2(const float* y, const float* affine, const float* shortcut, const float* short_affine, int64_t rows, int32_t channels, int32_t act,
+                  float* z, void* stream) {
+    if (!y || !affine || !z || !bn_shape_ok(rows, channels) || (short_affine && !shortcut)) return fail_msg("syn_bn_apply2: bad arguments");
+    const long n4 = rows * channels / 4;
+    hipLaunchKernelGGL(trn::k_bn_apply2, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, affine, shortcut, short_affine, channels, n4, act, z);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_bn_apply2", e);
+}
+
+int syn_bn_block_bwd(const float* dz, const float* y, const float* shortcut, const float* stats, const float* affine, const float* short_stats,
+                     const float* short_affine, int64_t rows, int32_t channels, int32_t act, float* ws, float* dgb, float* short_dgb, float* dy,
+                     float* dshortcut, void* stream) {
+    if (!dz || !y || !stats || !affine || !ws || !dgb || !dy || !bn_shape_ok(rows, channels)) return fail_msg("syn_bn_block_bwd: bad arguments");
+    if ((short_affine != nullptr) != (short_stats != nullptr) || (short_affine && (!shortcut || !short_dgb || !dshortcut)))
+        return fail_msg("syn_bn_block_bwd: a normalised shortcut needs its tensor, statistics, affine, gradient buffer and dshortcut");
+    if (dshortcut && !shortcut) return fail_msg("syn_bn_block_bwd: dshortcut without a shortcut");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = syn_bn_chunks(rows);
+    hipLaunchKernelGGL(trn::k_bn_bwd_stats2, dim3(chunks), dim3(256), 0, s, dz, y, shortcut, stats, affine, short_stats, short_affine, (long)rows, channels, act, ws);
+    hipLaunchKernelGGL(trn::k_bn_bwd_finalize2, dim3(channels), dim3(256), 0, s, (const float*)ws, chunks, channels, dgb, short_affine ? short_dgb : nullptr);
+    const long n4 = rows * channels / 4;
+    hipLaunchKernelGGL(trn::k_bn_bwd_apply2, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dz, y, shortcut, stats, affine, short_stats, short_affine,
+                       (const float*)dgb, (const float*)short_dgb, channels, n4, (long)rows, act, dy, dshortcut);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_bn_block_bwd", e);
 }
 
 /* ---- nn.SyncBatchNorm on the same kernels: sums -> (the caller's all-reduce) -> apply ---- */
@@ -2875,9 +2925,10 @@ int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows
     return shares < 1 ? 1 : shares;
 }
 
-int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
-                           int32_t cout, float* ws, float* dw, void* stream) {
+static int conv_train_wgrad_impl(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
+                                 int32_t cout, const float* in_affine, int32_t in_act, float* ws, float* dw, void* stream) {
     if (!x || !dy || !ws || !dw || n_clips <= 0 || l_in <= 0 || cin % 16 || stride < 1) return fail_msg("syn_conv1d_train_wgrad: bad arguments");
+    if (in_affine && stride != 1) return fail_msg("syn_conv1d_train_wgrad_norm: the input affine is for the stride-1 layers (conv2 of a block)");
     if (!((stride == 1 && pad == 7) || (pad == 0 && stride * cin == 384 && (stride == 3 || stride == 6))))
         return fail_msg("syn_conv1d_train_wgrad: stride 1 with padding 7, or the encoder's unpadded strided layers (stride x cin = 384)");
     const int l_out = (l_in + 2 * pad - 15) / stride + 1, taps = (15 + stride - 1) / stride, cinp = stride * cin;
@@ -2886,6 +2937,7 @@ int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int
     a.GY = dy; a.gy_clip_stride = (long)l_out * cout; a.L_out = l_out; a.X = x; a.x_clip_stride = (long)l_in * cin; a.x_elems = (long)l_in * cin;
     a.cin = cinp; a.co_n = cout; a.n_clips = n_clips; a.chunks_per_clip = (l_out + wav::kWgP - 1) / wav::kWgP; a.row0 = stride == 1 ? -7 : 0;
     a.shares = syn_conv1d_wgrad_shares(n_clips, l_out, cinp); a.part = ws;
+    a.in_aff = in_affine; a.in_act = in_act;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (cout == 64 && taps == 15) rc = launch_wgrad<64, 15>(a, s);
@@ -2903,7 +2955,19 @@ int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int
     return e == hipSuccess ? 0 : fail("k_conv_wgrad_sum launch", e);
 }
 
+int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
+                           int32_t cout, float* ws, float* dw, void* stream) {
+    return conv_train_wgrad_impl(x, dy, n_clips, l_in, cin, stride, pad, cout, nullptr, 0, ws, dw, stream);
+}
+
+int syn_conv1d_train_wgrad_norm(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
+                                int32_t cout, const float* in_affine, int32_t in_act, float* ws, float* dw, void* stream) {
+    if (!in_affine) return fail_msg("syn_conv1d_train_wgrad_norm: in_affine is NULL (use syn_conv1d_train_wgrad)");
+    return conv_train_wgrad_impl(x, dy, n_clips, l_in, cin, stride, pad, cout, in_affine, in_act, ws, dw, stream);
+}
+
 int32_t syn_conv1d_first_parts(int32_t n_clips, int32_t l_out) { return n_clips * ((l_out + wav::kF1Chunk - 1) / wav::kF1Chunk); }
+int32_t syn_conv1d_first_tiles(int32_t n_clips, int32_t l_out) { return n_clips > 0 && l_out > 0 ? n_clips * ((l_out + wav::kF1Tile - 1) / wav::kF1Tile) : 0; }
 
 static int first_layer_args(wav::FArgs& a, const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, const char* who) {
     if (!x || n_clips <= 0 || l_in <= 0 || (cin != 1 && cin != 2) || stride < 1 || stride > 8 || pad < 0) return fail_msg(who);
@@ -2914,18 +2978,24 @@ static int first_layer_args(wav::FArgs& a, const float* x, int32_t n_clips, int3
     return 0;
 }
 
-int syn_conv1d_first_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, const float* w, float* y,
-                         void* stream) {
+int syn_conv1d_first_fwd_stats(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, const float* w, float* y,
+                               float* bn_part, void* stream) {
     wav::FArgs a;
     if (!w || !y) return fail_msg("syn_conv1d_first_fwd: bad arguments");
     if (int rc = first_layer_args(a, x, n_clips, l_in, cin, stride, pad, "syn_conv1d_first_fwd: bad arguments (cin 1 | 2, 64 output channels)")) return rc;
-    a.W = w; a.Y = y;
+    a.W = w; a.Y = y; a.part = bn_part;
     const dim3 grid((a.L_out + wav::kF1Tile - 1) / wav::kF1Tile, n_clips);
-    const size_t lds = (size_t)((wav::kF1Tile - 1) * stride + 15) * cin * sizeof(float);
+    size_t lds = (size_t)((wav::kF1Tile - 1) * stride + 15) * cin * sizeof(float);
+    if (lds < 4 * 2 * 64 * sizeof(float)) lds = 4 * 2 * 64 * sizeof(float);       // (the statistics of the four position groups meet in the window's place)
     if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_fwd<1>, grid, dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(wav::k_conv_first_fwd<2>, grid, dim3(256), lds, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_first_fwd launch", e);
+}
+
+int syn_conv1d_first_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, const float* w, float* y,
+                         void* stream) {
+    return syn_conv1d_first_fwd_stats(x, n_clips, l_in, cin, stride, pad, w, y, nullptr, stream);
 }
 
 int syn_conv1d_first_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws,
@@ -3017,6 +3087,7 @@ int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_i
         const size_t frag0 = (size_t)(c0 / 16) * (kt * cout / 32) * 64;
         a.Whi = (const uint4*)w_hi + frag0; a.Wlo = (const uint4*)w_lo + frag0; a.bias = nullptr;
         a.Y = dx; a.y_clip_stride = (long)l_in * cin; a.y_pitch = np; a.y_col0 = c0; a.y_elems = (long)l_in * cin; a.bn_part = nullptr;
+        a.in_aff = nullptr; a.in_act = 0;
         int rc;
         if (cout == 64 && kt == 3) rc = launch_conv_train<64, 3, 2, 2, 4>(a, n_clips, s);
         // (a launch covers 128 of the stride x cin columns: tiles halved while it would not fill the chip twice - 32 clips: 45 -> 30 us and
@@ -3056,9 +3127,11 @@ int32_t syn_conv1d_train_fwd_tiles(int32_t n_clips, int32_t l_in, int32_t cin, i
     return mw ? n_clips * ((l_out + mw - 1) / mw) : 0;
 }
 
-int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
-                         const void* w_hi, const void* w_lo, const float* bias, int32_t cout, float* y, float* bn_part, void* stream) {
+static int conv_train_fwd_impl(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
+                               const void* w_hi, const void* w_lo, const float* bias, int32_t cout, const float* in_affine, int32_t in_act,
+                               float* y, float* bn_part, void* stream) {
     if (!x || !w_hi || !w_lo || !y || n_clips <= 0 || l_in <= 0) return fail_msg("syn_conv1d_train_fwd: null pointer / empty batch");
+    if (in_affine && stride != 1) return fail_msg("syn_conv1d_train_fwd_norm: the input affine is for the stride-1 layers (conv2 of a block)");
     if (stride < 1 || pad < 0 || pad % stride) return fail_msg("syn_conv1d_train_fwd: padding must be a multiple of the stride");
     const int l_out = (l_in + 2 * pad - 15) / stride + 1;
     if (l_out <= 0) return fail_msg("syn_conv1d_train_fwd: input shorter than the kernel");
@@ -3066,6 +3139,7 @@ int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
     a.X = x; a.x_clip_stride = (long)l_in * cin; a.x_elems = (long)l_in * cin; a.row0 = -pad / stride; a.L_out = l_out;
     a.Whi = (const uint4*)w_hi; a.Wlo = (const uint4*)w_lo; a.bias = bias; a.Y = y; a.y_clip_stride = (long)l_out * cout;
     a.y_pitch = 0; a.y_col0 = 0; a.y_elems = 0; a.bn_part = bn_part;
+    a.in_aff = in_affine; a.in_act = in_act;
     if (bn_part && bias) return fail_msg("syn_conv1d_train_fwd: the statistics are those of the convolution without its bias (pass bias = NULL)");
     hipStream_t s = (hipStream_t)stream;
     const int cinp = stride * cin;
@@ -3091,6 +3165,18 @@ int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
         return conv_train_tile(cinp, stride, cout, n_clips, l_out) == 32 ? launch_conv_train<384, 5, 4, 1, 2>(a, n_clips, s)
                                                                          : launch_conv_train<384, 5, 4, 1, 1>(a, n_clips, s);
     return fail_msg("syn_conv1d_train_fwd: not one of the WavEncoder's convolutions (cin x stride -> cout: 64x1->64, 128x1->128, 256x1->256, 64x6->64, 64x6->128, 128x3->256)");
+}
+
+int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
+                         const void* w_hi, const void* w_lo, const float* bias, int32_t cout, float* y, float* bn_part, void* stream) {
+    return conv_train_fwd_impl(x, n_clips, l_in, cin, stride, pad, w_hi, w_lo, bias, cout, nullptr, 0, y, bn_part, stream);
+}
+
+int syn_conv1d_train_fwd_norm(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
+                              const void* w_hi, const void* w_lo, int32_t cout, const float* in_affine, int32_t in_act, float* y, float* bn_part,
+                              void* stream) {
+    if (!in_affine) return fail_msg("syn_conv1d_train_fwd_norm: in_affine is NULL (use syn_conv1d_train_fwd)");
+    return conv_train_fwd_impl(x, n_clips, l_in, cin, stride, pad, w_hi, w_lo, nullptr, cout, in_affine, in_act, y, bn_part, stream);
 }
 
 // Stage classes reported by syn_denoise_step_profile (index into ms[] / count[]).

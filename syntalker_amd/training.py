@@ -1090,11 +1090,249 @@ def _conv_bn_eval(conv, bn, x):
     return F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
 
 
+# ---- a BasicBlock of the audio encoder as ONE autograd node (round 5) -------------------------------------------------------------------
+# models/utils/layer.py:171-184 in train() mode.  Built from `_conv_bn_act` above a block is 3 convolutions + 3 BatchNorm tails of three
+# launches each way, and every tail is a pass of its own over tensors that are 117 MB each in block 0 at 32 clips: 13 tensor passes forward
+# and 24 backward in block 0 alone (BatchNorm kernels: 1.0 ms of a 6.4 ms step, profiles/r04_train_step_split.txt).  As one node:
+#   forward   conv1 (+ statistics from its epilogue) | finalize -> per-channel affine | [shortcut conv (+ statistics) | finalize] |
+#             conv2 reading act(bn1(y1)) AS IT STAGES ITS TILE (z1 is never written) | finalize | ONE elementwise pass:
+#             out = act(bn2(y2) + (bn_s(y_sc) | x))                                                  -> 7 tensor passes in block 0
+#   backward  ONE statistics + ONE apply pass for bn2 AND the shortcut's BatchNorm over (dout, y2, y_sc | x), the activation's sign from the
+#             recomputed pre-activation (`out` is neither saved nor read) | conv2 data gradient | conv2 weight gradient recomputing
+#             act(bn1(y1)) as it stages | bn1 backward | conv1 (and shortcut) gradients                 -> 19 tensor passes in block 0
+# Saved for the backward: x, y1, y2, y_sc and four small per-channel tables - not z1, not the normalised shortcut, not the output.
+WAV_BLOCK_FUSED = bool(int(_os.environ.get("SYN_TRAIN_WAV_BLOCK_FUSED", "1")))     # (A/B: 0 = the per-convolution nodes above)
+
+
+def _rows3(t):
+    """(N, C, 1, L) channels_last fp32 -> the same memory as (N, L, C) contiguous."""
+    t = t.detach()
+    if t.dtype is not torch.float32:
+        t = t.float()
+    return t.contiguous(memory_format=torch.channels_last).permute(0, 3, 1, 2).reshape(t.shape[0], t.shape[3], t.shape[1])
+
+
+def _as4(t3):
+    """(N, L, C) contiguous -> (N, C, 1, L) channels_last view of the same memory."""
+    n, l, c = t3.shape
+    return t3.view(n, 1, l, c).permute(0, 3, 1, 2)
+
+
+def _wb_conv_fwd(x3, conv, first, in_aff=None, in_act=0):
+    """The convolution alone (no bias) on (N, L, Cin) -> y (N, L_out, Cout), its BatchNorm partial sums, their chunk count."""
+    lib, dev = _lib.load(), x3.device
+    n, l_in, cin = x3.shape
+    stride, pad, cout = conv.stride[0], conv.padding[0], conv.out_channels
+    l_out = (l_in + 2 * pad - 15) // stride + 1
+    y = torch.empty(n, l_out, cout, device=dev, dtype=torch.float32)
+    st = _lib.current_stream(dev)
+    if first:
+        chunks = lib.syn_conv1d_first_tiles(n, l_out)
+        part = torch.empty(chunks, 2, 64, device=dev, dtype=torch.float32)
+        wc = conv.weight.detach()
+        _lib.check(lib.syn_conv1d_first_fwd_stats(x3.data_ptr(), n, l_in, cin, stride, pad, wc.data_ptr(), y.data_ptr(), part.data_ptr(), st),
+                   "syn_conv1d_first_fwd_stats")
+        return y, part, chunks
+    whi, wlo = _wb_pack(conv, False)
+    chunks = lib.syn_conv1d_train_fwd_tiles(n, l_in, cin, stride, pad, cout)
+    part = torch.empty(chunks, 2, cout, device=dev, dtype=torch.float32)
+    _conv_terms(0)
+    if in_aff is None:
+        _lib.check(lib.syn_conv1d_train_fwd(x3.data_ptr(), n, l_in, cin, stride, pad, whi.data_ptr(), wlo.data_ptr(), None, cout, y.data_ptr(),
+                                            part.data_ptr(), st), "syn_conv1d_train_fwd")
+    else:
+        _lib.check(lib.syn_conv1d_train_fwd_norm(x3.data_ptr(), n, l_in, cin, stride, pad, whi.data_ptr(), wlo.data_ptr(), cout, in_aff.data_ptr(),
+                                                 int(in_act), y.data_ptr(), part.data_ptr(), st), "syn_conv1d_train_fwd_norm")
+    return y, part, chunks
+
+
+def _wb_pack(conv, transposed):
+    """hi / lo fragment sets of a Conv1d(k 15) weight: the step's pack, or packed on the spot."""
+    pk = _lookup_conv_pack(conv.weight, transposed)
+    if pk is not None:
+        return pk
+    lib = _lib.load()
+    w = conv.weight.detach()
+    cout, cin, stride = conv.out_channels, conv.in_channels, conv.stride[0]
+    nb = lib.syn_conv1d_pack_bytes(cout, cin, stride, int(transposed))
+    whi = torch.empty(nb, dtype=torch.uint8, device=w.device)
+    wlo = torch.empty_like(whi)
+    _lib.check(lib.syn_conv1d_pack_split(w.data_ptr(), cout, cin, stride, int(transposed), whi.data_ptr(), wlo.data_ptr(), _lib.current_stream(w.device)),
+               "syn_conv1d_pack_split")
+    return whi, wlo
+
+
+def _wb_finalize(part, chunks, rows, bn, conv_bias):
+    c = bn.num_features
+    stats = torch.empty(2, c, device=part.device, dtype=torch.float32)
+    aff = torch.empty(2, c, device=part.device, dtype=torch.float32)
+    cb = None if conv_bias is None else conv_bias.detach()
+    _lib.check(_lib.load().syn_bn_finalize(part.data_ptr(), chunks, rows, c, bn.weight.detach().data_ptr(), bn.bias.detach().data_ptr(), float(bn.eps),
+                                           float(bn.momentum), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), _lib.ptr(cb), stats.data_ptr(),
+                                           aff.data_ptr(), _lib.current_stream(part.device)), "syn_bn_finalize")
+    if bn.num_batches_tracked is not None:
+        _tracked.append(bn.num_batches_tracked)
+    return stats, aff
+
+
+def _wb_dgrad(dy3, conv, l_in):
+    """Data gradient of `conv` (no bias): dy (N, L_out, Cout) -> dx (N, L_in, Cin)."""
+    lib, dev = _lib.load(), dy3.device
+    n, l_out, cout = dy3.shape
+    cin, stride, pad = conv.in_channels, conv.stride[0], conv.padding[0]
+    whi, wlo = _wb_pack(conv, True)
+    dx = torch.empty(n, l_in, cin, device=dev, dtype=torch.float32)
+    _conv_terms(1)
+    if stride == 1 and pad == 7 and (cout, 1, cin) in ConvSplitFn.SUPPORTED:
+        _lib.check(lib.syn_conv1d_train_fwd(dy3.data_ptr(), n, l_out, cout, 1, 7, whi.data_ptr(), wlo.data_ptr(), None, cin, dx.data_ptr(), None,
+                                            _lib.current_stream(dev)), "syn_conv1d_train_fwd (data gradient)")
+    elif pad == 0 and (cout, stride) in ((64, 6), (128, 6), (256, 3)) and (stride * cin) % 128 == 0:
+        _lib.check(lib.syn_conv1d_train_dgrad_strided(dy3.data_ptr(), n, l_in, cin, stride, cout, whi.data_ptr(), wlo.data_ptr(), dx.data_ptr(),
+                                                      _lib.current_stream(dev)), "syn_conv1d_train_dgrad_strided")
+    else:
+        raise _unsupported_conv("data gradient", cin, stride, pad, cout)
+    return dx
+
+
+def _wb_wgrad(x3, dy3, conv, first, in_aff=None, in_act=0):
+    """Weight gradient (Cout, Cin, 15) of `conv` from its input x (N, L_in, Cin) and dy (N, L_out, Cout)."""
+    lib, dev = _lib.load(), x3.device
+    n, l_in, cin = x3.shape
+    stride, pad, cout = conv.stride[0], conv.padding[0], conv.out_channels
+    l_out = dy3.shape[1]
+    gw = _grad_out(conv.weight, (cout, cin, 15))
+    st = _lib.current_stream(dev)
+    if first:
+        ws = torch.empty(lib.syn_conv1d_first_parts(n, l_out) * 64 * cin * 15, device=dev, dtype=torch.float32)
+        _lib.check(lib.syn_conv1d_first_wgrad(x3.data_ptr(), dy3.data_ptr(), n, l_in, cin, stride, pad, ws.data_ptr(), gw.data_ptr(), st),
+                   "syn_conv1d_first_wgrad")
+        return gw
+    kts = -(-15 // stride) * stride
+    ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l_out, stride * cin) * cout * kts * cin, device=dev, dtype=torch.float32)
+    _conv_terms(2)
+    if in_aff is None:
+        _lib.check(lib.syn_conv1d_train_wgrad(x3.data_ptr(), dy3.data_ptr(), n, l_in, cin, stride, pad, cout, ws.data_ptr(), gw.data_ptr(), st),
+                   "syn_conv1d_train_wgrad")
+    else:
+        _lib.check(lib.syn_conv1d_train_wgrad_norm(x3.data_ptr(), dy3.data_ptr(), n, l_in, cin, stride, pad, cout, in_aff.data_ptr(), int(in_act),
+                                                   ws.data_ptr(), gw.data_ptr(), st), "syn_conv1d_train_wgrad_norm")
+    return gw
+
+
+class WavBlockFn(torch.autograd.Function):
+    """act(bn2(conv2(act(bn1(conv1(x))))) + shortcut(x)) of one BasicBlock on batch statistics (see the comment above).
+    x: (N, Cin, 1, L) channels_last, or for the encoder's first block the waveform (N, L, cin); returns (N, Cout, 1, L_out) channels_last.
+    params: conv1.weight, conv1.bias, bn1.weight, bn1.bias, conv2.weight, conv2.bias, bn2.weight, bn2.bias [, shortcut conv.weight, .bias,
+    shortcut bn.weight, .bias] - listed so that autograd routes their gradients; the modules themselves come through `blk`."""
+
+    @staticmethod
+    def forward(ctx, x, blk, first, *params):
+        lib = _lib.load()
+        x3 = x.detach().float().contiguous() if first else _rows3(x)
+        n = x3.shape[0]
+        ds = blk.downsample is not None
+        y1, p1, c1 = _wb_conv_fwd(x3, blk.conv1, first)
+        rows = n * y1.shape[1]
+        st1, af1 = _wb_finalize(p1, c1, rows, blk.bn1, blk.conv1.bias)
+        ysc = sts = afs = None
+        if ds:
+            ysc, ps, cs = _wb_conv_fwd(x3, blk.downsample[0], first)
+            sts, afs = _wb_finalize(ps, cs, rows, blk.downsample[1], blk.downsample[0].bias)
+        y2, p2, c2 = _wb_conv_fwd(y1, blk.conv2, False, in_aff=af1, in_act=1)
+        st2, af2 = _wb_finalize(p2, c2, rows, blk.bn2, blk.conv2.bias)
+        c = y2.shape[2]
+        short = ysc if ds else x3
+        if not ds and tuple(x3.shape) != tuple(y2.shape):
+            raise _lib.SynHipError(f"identity shortcut of shape {tuple(x3.shape)} on a block output of shape {tuple(y2.shape)}")
+        out = torch.empty_like(y2)
+        _lib.check(lib.syn_bn_apply2(y2.data_ptr(), af2.data_ptr(), short.data_ptr(), _lib.ptr(afs), rows, c, 1, out.data_ptr(),
+                                     _lib.current_stream(out.device)), "syn_bn_apply2")
+        ctx.save_for_backward(x3, y1, y2, ysc, st1, af1, st2, af2, sts, afs)
+        ctx.blk, ctx.first = blk, bool(first)
+        return _as4(out)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x3, y1, y2, ysc, st1, af1, st2, af2, sts, afs = ctx.saved_tensors
+        blk, first = ctx.blk, ctx.first
+        ds = blk.downsample is not None
+        n, l1, c = y2.shape
+        rows = n * l1
+        dev = y2.device
+        d3 = _rows3(dout)
+        ws = torch.empty(3 * lib.syn_bn_chunks(rows) * c, device=dev, dtype=torch.float32)
+        dgb2 = torch.empty(3, c, device=dev, dtype=torch.float32)
+        dgbs = torch.empty(3, c, device=dev, dtype=torch.float32) if ds else None
+        dy2, dsh = torch.empty_like(y2), torch.empty_like(y2)
+        short = ysc if ds else x3
+        _lib.check(lib.syn_bn_block_bwd(d3.data_ptr(), y2.data_ptr(), short.data_ptr(), st2.data_ptr(), af2.data_ptr(), _lib.ptr(sts), _lib.ptr(afs),
+                                        rows, c, 1, ws.data_ptr(), dgb2.data_ptr(), _lib.ptr(dgbs), dy2.data_ptr(), dsh.data_ptr(),
+                                        _lib.current_stream(dev)), "syn_bn_block_bwd")
+        # conv2: data gradient to z1 = act(bn1(y1)), weight gradient with z1 recomputed from y1 while its rows are staged
+        dz1 = _wb_dgrad(dy2, blk.conv2, l1)
+        gw2 = _wb_wgrad(y1, dy2, blk.conv2, False, in_aff=af1, in_act=1)
+        # bn1 + activation (no shortcut entered it: the sign comes from y1)
+        ws1 = torch.empty(2 * lib.syn_bn_chunks(rows) * c, device=dev, dtype=torch.float32)
+        dgb1 = torch.empty(3, c, device=dev, dtype=torch.float32)
+        dy1 = torch.empty_like(y1)
+        g1, b1 = blk.bn1.weight.detach(), blk.bn1.bias.detach()
+        _lib.check(lib.syn_bn_act_bwd(dz1.data_ptr(), None, y1.data_ptr(), st1.data_ptr(), g1.data_ptr(), b1.data_ptr(), rows, c, 1, ws1.data_ptr(),
+                                      dgb1.data_ptr(), dy1.data_ptr(), None, _lib.current_stream(dev)), "syn_bn_act_bwd")
+        gw1 = _wb_wgrad(x3, dy1, blk.conv1, first)
+        dx = None
+        if not first and ctx.needs_input_grad[0]:
+            dx = _wb_dgrad(dy1, blk.conv1, x3.shape[1])
+        grads = [gw1, dgb1[2] if blk.conv1.bias is not None else None, dgb1[0], dgb1[1],
+                 gw2, dgb2[2] if blk.conv2.bias is not None else None, dgb2[0], dgb2[1]]
+        if ds:
+            gws = _wb_wgrad(x3, dsh, blk.downsample[0], first)
+            if dx is not None:
+                dx = dx + _wb_dgrad(dsh, blk.downsample[0], x3.shape[1])
+            grads += [gws, dgbs[2] if blk.downsample[0].bias is not None else None, dgbs[0], dgbs[1]]
+        elif dx is not None:
+            dx = dx + dsh
+        return (None if dx is None else _as4(dx), None, None, *grads)
+
+
+def _wav_block_fused_ok(blk, x, first) -> bool:
+    if not (WAV_BLOCK_FUSED and blk.training and torch.is_grad_enabled() and x.is_cuda):
+        return False
+    bns = [blk.bn1, blk.bn2] + ([blk.downsample[1]] if blk.downsample is not None else [])
+    if any(isinstance(b, nn.SyncBatchNorm) or not b.track_running_stats or b.momentum is None or b.weight is None for b in bns):
+        return False                                          # (SyncBatchNorm: the per-convolution path with its all-reduces, `_conv_bn_act`)
+    convs = [blk.conv1, blk.conv2] + ([blk.downsample[0]] if blk.downsample is not None else [])
+    for i, cv in enumerate(convs):
+        if cv.kernel_size[0] != 15 or cv.dilation[0] != 1 or cv.weight.dtype is not torch.float32:
+            return False
+        key = (cv.in_channels, cv.stride[0], cv.out_channels)
+        if first and i != 1:
+            if not (cv.in_channels in (1, 2) and cv.out_channels == 64 and 1 <= cv.stride[0] <= 8):
+                return False
+        elif key not in ConvSplitFn.SUPPORTED or cv.padding[0] % cv.stride[0]:
+            return False
+    c2 = blk.conv2
+    return c2.stride[0] == 1 and c2.padding[0] == 7 and c2.in_channels == c2.out_channels
+
+
+def _wav_block_params(blk):
+    ps = [blk.conv1.weight, blk.conv1.bias, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.conv2.bias, blk.bn2.weight, blk.bn2.bias]
+    if blk.downsample is not None:
+        ps += [blk.downsample[0].weight, blk.downsample[0].bias, blk.downsample[1].weight, blk.downsample[1].bias]
+    return ps
+
+
 def _wav_block(blk, x):
     """models/utils/layer.py:171-184 on channels_last (N, C, 1, L), train or eval statistics as the module says."""
     if blk.training:
         if not blk.bn1.track_running_stats:
             raise _lib.SynHipError("the audio encoder's BatchNorms must track running statistics (the reference's do)")
+        first = blk.conv1.in_channels in (1, 2) and not x.requires_grad
+        if _wav_block_fused_ok(blk, x, first):
+            if first:
+                n, cin, _, l = x.shape                           # channels_last (N, cin, 1, L) = the waveform (N, L, cin)
+                x = x.permute(0, 2, 3, 1).reshape(n, l, cin)
+            return WavBlockFn.apply(x, blk, first, *_wav_block_params(blk))
         z = _conv_bn_act(blk.conv1, blk.bn1, x, None, True)
         short = x if blk.downsample is None else _conv_bn_act(blk.downsample[0], blk.downsample[1], x, None, False)
         return _conv_bn_act(blk.conv2, blk.bn2, z, short, True)

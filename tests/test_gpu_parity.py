@@ -512,6 +512,47 @@ def test_train_mode_loss_gradients_and_bn_buffers_vs_golden(golden):
     assert float(params["WavEncoder.feat_extractor.1.conv1.bias"].grad.abs().max()) < 1e-6
 
 
+def test_fused_wav_block_equals_the_per_convolution_nodes():
+    """training.WavBlockFn (round 5: a BasicBlock of the audio encoder as one autograd node - bn1 + LeakyReLU applied by conv2 as it stages its
+    tile, the shortcut's BatchNorm inside the block's one elementwise pass, one statistics + one apply pass for both BatchNorms in the backward,
+    no z1 / shortcut / output saved) against the per-convolution nodes it replaces (`_conv_bn_act`: the path the train-mode golden was first
+    pinned on): same loss, every parameter gradient, the BatchNorm buffers.  Differences are fp32 reassociation (a(v) = v * scale + shift
+    against (v - mean) * rstd * gamma + beta) on top of the split-operand convolutions."""
+    from syntalker_amd import training
+    from syntalker_amd.process import create_gaussian_diffusion
+    y = synth.to_device(synth.synth_clip_inputs(4, seed=5), DEV)
+    x0, eps = synth.synth_latent(4, seed=5, name="x0").to(DEV), synth.synth_latent(4, seed=6, name="eps").to(DEV)
+    t4 = torch.tensor([0, 17, 500, 999], device=DEV)
+    d = create_gaussian_diffusion()
+    res = {}
+    keep = training.WAV_BLOCK_FUSED
+    try:
+        for fused in (False, True):
+            training.WAV_BLOCK_FUSED = fused
+            m = _model("beatx").train()
+            m.drop_path = 0.0
+            loss = d.training_losses(m, x0, t4, model_kwargs={"y": y}, noise=eps)["loss"]
+            loss.mean().backward()
+            res[fused] = (loss.detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None},
+                          {k: v.detach().cpu() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k})
+    finally:
+        training.WAV_BLOCK_FUSED = keep
+    (l0, g0, b0), (l1, g1, b1) = res[False], res[True]
+    assert torch.allclose(l0, l1, rtol=5e-4), (l0, l1)      # (bf16 operands downstream: an fp32-rounding difference in the conditioning flips bf16 roundings)
+    assert g0.keys() == g1.keys()
+    worst = ("", 0.0)
+    for n in g0:
+        if float(g0[n].norm()) < 1e-6:                      # conv biases in front of a batch-statistics BatchNorm: exactly zero in both
+            assert float(g1[n].norm()) < 1e-6, n
+            continue
+        e = rel_l2(g1[n], g0[n])
+        worst = max(worst, (n, e), key=lambda v: v[1])
+        assert e < 1e-2, (n, e)
+    print(f"fused block vs per-convolution nodes: loss ratio {float((l1 / l0).mean()):.7f}, worst gradient rel-L2 {worst[1]:.2e} ({worst[0]})")
+    for k in b0:
+        assert torch.allclose(b0[k].double(), b1[k].double(), rtol=1e-5, atol=1e-6), k
+
+
 def test_sync_batchnorm_model_on_the_native_path(golden):
     """train.py:90 converts every BatchNorm of the model to nn.SyncBatchNorm before DDP: the converted model keeps the audio encoder on
     the hand-written kernels (`SyncBnActFn`: fp64 sums -> all-reduce -> finalise) and, with a one-rank process group, reproduces the
