@@ -215,6 +215,13 @@ int64_t syn_conv1d_pack_bytes(int32_t cout, int32_t cin, int32_t stride, int32_t
  * transposed = 1).  A stride-1 convolution over dy whose output rows are `stride` consecutive positions x cin channels. */
 int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t cout,
                                    const void* w_hi, const void* w_lo, float* dx, void* stream);
+/* (ABI 7) The data gradient that reaches a BasicBlock's input, written once: dx [n_clips][l_in][cin] = conv^T dy [+ conv2^T dy2] [+ residual].
+ * Strided, unpadded layers (a down-sampling block: conv1 and the shortcut convolution share input and geometry): dy / dy2 [n_clips][l_out][cout] with their
+ * transposed fragment sets, both accumulated in one launch instead of two tensors and an add; residual must be NULL.  Stride 1, padding 7 (a block with an
+ * identity shortcut): dy2 NULL, residual (laid out like dx; the gradient arriving along the shortcut) added in the epilogue. */
+int syn_conv1d_train_dgrad_sum(const float* dy, const void* w_hi, const void* w_lo, const float* dy2, const void* w2_hi, const void* w2_lo,
+                               const float* residual, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, int32_t cout, float* dx,
+                               void* stream);
 int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
                          const void* w_hi, const void* w_lo, const float* bias, int32_t cout, float* y, float* bn_part, void* stream);
 /* bn_part (NULL, or syn_conv1d_train_fwd_tiles(...) x 2 x cout floats; bias must then be NULL): per-workgroup sum and sum of squares

@@ -3075,9 +3075,10 @@ int64_t syn_conv1d_pack_bytes(int32_t cout, int32_t cin, int32_t stride, int32_t
 
 // Data gradient of a strided, unpadded Conv1d(k = 15) of the encoder: dx [n][l_in][cin] from dy [n][l_out][cout] - a stride-1
 // convolution over dy whose output rows are stride consecutive positions x cin channels; three launches of 128 columns each.
-int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t cout,
-                                   const void* w_hi, const void* w_lo, float* dx, void* stream) {
+static int dgrad_strided_impl(const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t cout,
+                              const void* w_hi, const void* w_lo, const float* dy2, const void* w2_hi, const void* w2_lo, float* dx, void* stream) {
     if (!dy || !w_hi || !w_lo || !dx || n_clips <= 0 || l_in < 15 || stride < 2) return fail_msg("syn_conv1d_train_dgrad_strided: bad arguments");
+    if (dy2 && (!w2_hi || !w2_lo)) return fail_msg("syn_conv1d_train_dgrad_sum: the second gradient needs its fragment sets");
     const int l_out = (l_in - 15) / stride + 1, kt = dgrad_taps(stride, cout), q_rows = (l_in + stride - 1) / stride, np = stride * cin;
     if (np % 128) return fail_msg("syn_conv1d_train_dgrad_strided: stride * cin must be a multiple of 128");
     hipStream_t s = (hipStream_t)stream;
@@ -3087,7 +3088,8 @@ int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_i
         const size_t frag0 = (size_t)(c0 / 16) * (kt * cout / 32) * 64;
         a.Whi = (const uint4*)w_hi + frag0; a.Wlo = (const uint4*)w_lo + frag0; a.bias = nullptr;
         a.Y = dx; a.y_clip_stride = (long)l_in * cin; a.y_pitch = np; a.y_col0 = c0; a.y_elems = (long)l_in * cin; a.bn_part = nullptr;
-        a.in_aff = nullptr; a.in_act = 0;
+        a.in_aff = nullptr; a.in_act = 0; a.R = nullptr;
+        a.X2 = dy2; a.Whi2 = dy2 ? (const uint4*)w2_hi + frag0 : nullptr; a.Wlo2 = dy2 ? (const uint4*)w2_lo + frag0 : nullptr;
         int rc;
         if (cout == 64 && kt == 3) rc = launch_conv_train<64, 3, 2, 2, 4>(a, n_clips, s);
         // (a launch covers 128 of the stride x cin columns: tiles halved while it would not fill the chip twice - 32 clips: 45 -> 30 us and
@@ -3100,6 +3102,11 @@ int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_i
         if (rc) return rc;
     }
     return 0;
+}
+
+int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t cout,
+                                   const void* w_hi, const void* w_lo, float* dx, void* stream) {
+    return dgrad_strided_impl(dy, n_clips, l_in, cin, stride, cout, w_hi, w_lo, nullptr, nullptr, nullptr, dx, stream);
 }
 
 // row fragments (16 positions) per tile of the K-split kernel: 3 = 48 positions, 78 KB of LDS, so two workgroups share a CU and
@@ -3129,7 +3136,8 @@ int32_t syn_conv1d_train_fwd_tiles(int32_t n_clips, int32_t l_in, int32_t cin, i
 
 static int conv_train_fwd_impl(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
                                const void* w_hi, const void* w_lo, const float* bias, int32_t cout, const float* in_affine, int32_t in_act,
-                               float* y, float* bn_part, void* stream) {
+                               float* y, float* bn_part, void* stream, const float* residual = nullptr) {
+    if (residual && !(stride == 1 && cin * stride != 384)) return fail_msg("syn_conv1d_train_dgrad_sum: the residual rides the stride-1 kernel");
     if (!x || !w_hi || !w_lo || !y || n_clips <= 0 || l_in <= 0) return fail_msg("syn_conv1d_train_fwd: null pointer / empty batch");
     if (in_affine && stride != 1) return fail_msg("syn_conv1d_train_fwd_norm: the input affine is for the stride-1 layers (conv2 of a block)");
     if (stride < 1 || pad < 0 || pad % stride) return fail_msg("syn_conv1d_train_fwd: padding must be a multiple of the stride");
@@ -3140,6 +3148,7 @@ static int conv_train_fwd_impl(const float* x, int32_t n_clips, int32_t l_in, in
     a.Whi = (const uint4*)w_hi; a.Wlo = (const uint4*)w_lo; a.bias = bias; a.Y = y; a.y_clip_stride = (long)l_out * cout;
     a.y_pitch = 0; a.y_col0 = 0; a.y_elems = 0; a.bn_part = bn_part;
     a.in_aff = in_affine; a.in_act = in_act;
+    a.X2 = nullptr; a.Whi2 = a.Wlo2 = nullptr; a.R = residual;
     if (bn_part && bias) return fail_msg("syn_conv1d_train_fwd: the statistics are those of the convolution without its bias (pass bias = NULL)");
     hipStream_t s = (hipStream_t)stream;
     const int cinp = stride * cin;
@@ -3177,6 +3186,18 @@ int syn_conv1d_train_fwd_norm(const float* x, int32_t n_clips, int32_t l_in, int
                               void* stream) {
     if (!in_affine) return fail_msg("syn_conv1d_train_fwd_norm: in_affine is NULL (use syn_conv1d_train_fwd)");
     return conv_train_fwd_impl(x, n_clips, l_in, cin, stride, pad, w_hi, w_lo, nullptr, cout, in_affine, in_act, y, bn_part, stream);
+}
+
+int syn_conv1d_train_dgrad_sum(const float* dy, const void* w_hi, const void* w_lo, const float* dy2, const void* w2_hi, const void* w2_lo,
+                               const float* residual, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, int32_t cout, float* dx,
+                               void* stream) {
+    if (stride == 1) {
+        if (dy2) return fail_msg("syn_conv1d_train_dgrad_sum: two gradients are summed for the strided layers (a down-sampling block); stride 1 takes a residual");
+        if (pad != 7) return fail_msg("syn_conv1d_train_dgrad_sum: stride 1 means the padding-7 layers");
+        return conv_train_fwd_impl(dy, n_clips, l_in, cout, 1, 7, w_hi, w_lo, nullptr, cin, nullptr, 0, dx, nullptr, stream, residual);
+    }
+    if (residual || pad != 0) return fail_msg("syn_conv1d_train_dgrad_sum: the strided layers are unpadded and take no residual");
+    return dgrad_strided_impl(dy, n_clips, l_in, cin, stride, cout, w_hi, w_lo, dy2, w2_hi, w2_lo, dx, stream);
 }
 
 // Stage classes reported by syn_denoise_step_profile (index into ms[] / count[]).

@@ -1175,22 +1175,26 @@ def _wb_finalize(part, chunks, rows, bn, conv_bias):
     return stats, aff
 
 
-def _wb_dgrad(dy3, conv, l_in):
-    """Data gradient of `conv` (no bias): dy (N, L_out, Cout) -> dx (N, L_in, Cin)."""
+def _wb_dgrad(dy3, conv, l_in, dy3b=None, conv_b=None, residual=None):
+    """Data gradient of `conv` (no bias): dy (N, L_out, Cout) -> dx (N, L_in, Cin); with (dy3b, conv_b) - a second convolution of the same
+    geometry on the same input (a down-sampling block's shortcut) - the sum of both, with `residual` (N, L_in, Cin) that added: one launch,
+    dx written once (`syn_conv1d_train_dgrad_sum`)."""
     lib, dev = _lib.load(), dy3.device
     n, l_out, cout = dy3.shape
     cin, stride, pad = conv.in_channels, conv.stride[0], conv.padding[0]
     whi, wlo = _wb_pack(conv, True)
+    wb = _wb_pack(conv_b, True) if conv_b is not None else (None, None)
+    if conv_b is not None and (conv_b.in_channels, conv_b.stride[0], conv_b.padding[0], conv_b.out_channels) != (cin, stride, pad, cout):
+        raise _lib.SynHipError("the two convolutions of a summed data gradient must share their geometry")
+    ok = ((stride == 1 and pad == 7 and (cout, 1, cin) in ConvSplitFn.SUPPORTED and conv_b is None)
+          or (pad == 0 and (cout, stride) in ((64, 6), (128, 6), (256, 3)) and (stride * cin) % 128 == 0 and residual is None))
+    if not ok:
+        raise _unsupported_conv("data gradient", cin, stride, pad, cout)
     dx = torch.empty(n, l_in, cin, device=dev, dtype=torch.float32)
     _conv_terms(1)
-    if stride == 1 and pad == 7 and (cout, 1, cin) in ConvSplitFn.SUPPORTED:
-        _lib.check(lib.syn_conv1d_train_fwd(dy3.data_ptr(), n, l_out, cout, 1, 7, whi.data_ptr(), wlo.data_ptr(), None, cin, dx.data_ptr(), None,
-                                            _lib.current_stream(dev)), "syn_conv1d_train_fwd (data gradient)")
-    elif pad == 0 and (cout, stride) in ((64, 6), (128, 6), (256, 3)) and (stride * cin) % 128 == 0:
-        _lib.check(lib.syn_conv1d_train_dgrad_strided(dy3.data_ptr(), n, l_in, cin, stride, cout, whi.data_ptr(), wlo.data_ptr(), dx.data_ptr(),
-                                                      _lib.current_stream(dev)), "syn_conv1d_train_dgrad_strided")
-    else:
-        raise _unsupported_conv("data gradient", cin, stride, pad, cout)
+    _lib.check(lib.syn_conv1d_train_dgrad_sum(dy3.data_ptr(), whi.data_ptr(), wlo.data_ptr(), _lib.ptr(dy3b), _lib.ptr(wb[0]), _lib.ptr(wb[1]),
+                                              _lib.ptr(residual), n, l_in, cin, stride, pad, cout, dx.data_ptr(), _lib.current_stream(dev)),
+               "syn_conv1d_train_dgrad_sum")
     return dx
 
 
@@ -1282,16 +1286,14 @@ class WavBlockFn(torch.autograd.Function):
         gw1 = _wb_wgrad(x3, dy1, blk.conv1, first)
         dx = None
         if not first and ctx.needs_input_grad[0]:
-            dx = _wb_dgrad(dy1, blk.conv1, x3.shape[1])
+            # what reaches the block's input, written once: conv1^T dy1 + (shortcut^T dy_sc | the gradient along the identity shortcut)
+            dx = (_wb_dgrad(dy1, blk.conv1, x3.shape[1], dy3b=dsh, conv_b=blk.downsample[0]) if ds
+                  else _wb_dgrad(dy1, blk.conv1, x3.shape[1], residual=dsh))
         grads = [gw1, dgb1[2] if blk.conv1.bias is not None else None, dgb1[0], dgb1[1],
                  gw2, dgb2[2] if blk.conv2.bias is not None else None, dgb2[0], dgb2[1]]
         if ds:
             gws = _wb_wgrad(x3, dsh, blk.downsample[0], first)
-            if dx is not None:
-                dx = dx + _wb_dgrad(dsh, blk.downsample[0], x3.shape[1])
             grads += [gws, dgbs[2] if blk.downsample[0].bias is not None else None, dgbs[0], dgbs[1]]
-        elif dx is not None:
-            dx = dx + dsh
         return (None if dx is None else _as4(dx), None, None, *grads)
 
 
