@@ -193,6 +193,18 @@ int syn_conv1d_first_wgrad(const float* x, const float* dy, int32_t n_clips, int
 /* (ABI 7) the forward with the BatchNorm statistics of its output from the same launch: bn_part (NULL, or syn_conv1d_first_tiles(n_clips, l_out) x 2 x 64
  * floats) = per-workgroup sum and sum of squares of every output channel, what syn_bn_finalize takes (chunks = that tile count). */
 int32_t syn_conv1d_first_tiles(int32_t n_clips, int32_t l_out);
+/* (ABI 7) block 0's conv1 and its shortcut convolution (same input, kernel, stride, padding: models/utils/layer.py:150,158) as ONE launch over the waveform
+ * window: y_a / y_b and their statistics (both NULL or both given, syn_conv1d_first_tiles(...) x 2 x 64 floats each). */
+int syn_conv1d_first_fwd2(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, const float* w_a, const float* w_b,
+                          float* y_a, float* y_b, float* bn_part_a, float* bn_part_b, void* stream);
+/* (ABI 7) the first layer's weight gradient with the backward of the BatchNorm + LeakyReLU behind it folded in: dz = the gradient at the activation's output,
+ * y = the convolution's raw output, stats / affine from syn_bn_finalize, dgamma_dbeta from syn_bn_bwd_stats (below); dy = scale (dp - dbeta / M - xhat dgamma / M),
+ * dp = dz act'(a(y)), is formed as the values are loaded and never written.  stride 5 (the encoder's). */
+int syn_conv1d_first_wgrad_bn(const float* x, const float* dz, const float* y, const float* stats, const float* affine, const float* dgamma_dbeta,
+                              int32_t act, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws, float* dw, void* stream);
+/* (ABI 7) the statistics half of syn_bn_act_bwd: dgamma_dbeta [3][channels] only (ws as there). */
+int syn_bn_bwd_stats(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, const float* beta, int64_t rows,
+                     int32_t channels, int32_t act, float* ws, float* dgamma_dbeta, void* stream);
 int syn_conv1d_first_fwd_stats(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, const float* w, float* y,
                                float* bn_part, void* stream);
 

@@ -22,7 +22,8 @@ EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_ste
            "syn_step_advance", "syn_steps_advance", "syn_prefers_fragment_order", "syn_x_to_fragment", "syn_x_from_fragment", "syn_ln_fwd", "syn_ln_bwd", "syn_gelu_fwd", "syn_gelu_bwd", "syn_attn_fwd", "syn_attn_bwd",
            "syn_axis_angle_to_rot6d", "syn_rot6d_to_axis_angle", "syn_rotary", "syn_linear_wgrad_rows", "syn_masked_smooth_l1",
            "syn_bn_finalize", "syn_bn_apply2", "syn_bn_block_bwd", "syn_conv1d_train_fwd_norm", "syn_conv1d_train_wgrad_norm", "syn_conv1d_first_tiles",
-           "syn_conv1d_first_fwd_stats", "syn_test_mfma_rate", "syn_conv1d_train_dgrad_sum")
+           "syn_conv1d_first_fwd_stats", "syn_test_mfma_rate", "syn_conv1d_train_dgrad_sum", "syn_conv1d_first_fwd2", "syn_conv1d_first_wgrad_bn",
+           "syn_bn_bwd_stats")
 
 # the `void syn_debug_*` switches of the header's diagnostics section (process-wide, A/B runs and scripts/ only)
 DIAGNOSTICS = ("syn_debug_timing", "syn_debug_gemm_resident", "syn_debug_linear_tile", "syn_debug_conv_terms", "syn_debug_seq_skew", "syn_debug_seq_step")
@@ -167,6 +168,9 @@ def load():
     lib.syn_conv1d_first_tiles.argtypes = [i32, i32]
     lib.syn_conv1d_first_fwd_stats.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.syn_test_mfma_rate.argtypes = [i32, vp, vp, vp]
+    lib.syn_conv1d_first_fwd2.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.syn_conv1d_first_wgrad_bn.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.syn_bn_bwd_stats.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, i32, i32, vp, vp, vp]
     lib.syn_conv1d_train_dgrad_sum.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.syn_linear_bwd_prep.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.syn_pack_weights.argtypes = [vp, i32, C.c_int64, vp]

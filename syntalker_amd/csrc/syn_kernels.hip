@@ -2975,6 +2975,7 @@ static int first_layer_args(wav::FArgs& a, const float* x, int32_t n_clips, int3
     a.L_out = (l_in + 2 * pad - 15) / stride + 1;
     if (a.L_out <= 0) return fail_msg(who);
     a.W = nullptr; a.Y = nullptr; a.DY = nullptr; a.part = nullptr; a.chunks_per_clip = (a.L_out + wav::kF1Chunk - 1) / wav::kF1Chunk;
+    a.BY = nullptr; a.bn_stats = a.bn_aff = a.bn_dgb = nullptr; a.bn_inv_rows = 0.f; a.bn_act = 0; a.W2 = nullptr; a.Y2 = nullptr; a.part2 = nullptr;
     return 0;
 }
 
@@ -2998,23 +2999,71 @@ int syn_conv1d_first_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
     return syn_conv1d_first_fwd_stats(x, n_clips, l_in, cin, stride, pad, w, y, nullptr, stream);
 }
 
-int syn_conv1d_first_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws,
-                           float* dw, void* stream) {
+static int first_wgrad_impl(const float* x, const float* dy, const float* bn_y, const float* bn_stats, const float* bn_aff, const float* bn_dgb,
+                            int32_t bn_act, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws, float* dw, void* stream) {
     wav::FArgs a;
     if (!dy || !ws || !dw) return fail_msg("syn_conv1d_first_wgrad: bad arguments");
     if (int rc = first_layer_args(a, x, n_clips, l_in, cin, stride, pad, "syn_conv1d_first_wgrad: bad arguments (cin 1 | 2, 64 output channels)")) return rc;
     a.DY = dy; a.part = ws;
-    const size_t win = (size_t)((wav::kF1Chunk - 1) * stride + 15) * cin, red = (size_t)8 * cin * 15 * 64;
+    if (bn_y) {
+        if (stride != 5 || !bn_stats || !bn_aff || !bn_dgb) return fail_msg("syn_conv1d_first_wgrad_bn: stride 5 (the encoder's), statistics, affine and dgamma / dbeta");
+        a.BY = bn_y; a.bn_stats = bn_stats; a.bn_aff = bn_aff; a.bn_dgb = bn_dgb; a.bn_inv_rows = 1.0f / ((float)n_clips * (float)a.L_out); a.bn_act = bn_act;
+    }
+    static const bool blocked = getenv("SYN_FIRST_WGRAD_V1") == nullptr;       // (A/B: the one-position-per-step kernel)
+    const bool v5 = stride == 5 && (blocked || bn_y);
+    const size_t win = (size_t)((wav::kF1Chunk - 1 + (v5 ? 2 : 0)) * stride + 15) * cin, red = (size_t)8 * cin * 15 * 64;
     const size_t lds = (win > red ? win : red) * sizeof(float);
     if (lds > 64 * 1024) return fail_msg("syn_conv1d_first_wgrad: stride too large for the window");
     const dim3 grid(a.chunks_per_clip, n_clips);
     hipStream_t s = (hipStream_t)stream;
-    if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_wgrad<1>, grid, dim3(512), lds, s, a);
+    if (v5) {
+        if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_wgrad5<1>, grid, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL(wav::k_conv_first_wgrad5<2>, grid, dim3(512), lds, s, a);
+    } else if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_wgrad<1>, grid, dim3(512), lds, s, a);
     else hipLaunchKernelGGL(wav::k_conv_first_wgrad<2>, grid, dim3(512), lds, s, a);
     const int n = 64 * cin * 15;
     hipLaunchKernelGGL(wav::k_conv_first_wsum, dim3((n + 63) / 64), dim3(1024), 0, s, (const float*)ws, n_clips * a.chunks_per_clip, n, dw);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_first_wgrad launch", e);
+}
+
+int syn_conv1d_first_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws,
+                           float* dw, void* stream) {
+    return first_wgrad_impl(x, dy, nullptr, nullptr, nullptr, nullptr, 0, n_clips, l_in, cin, stride, pad, ws, dw, stream);
+}
+
+int syn_conv1d_first_wgrad_bn(const float* x, const float* dz, const float* y, const float* stats, const float* affine, const float* dgamma_dbeta,
+                              int32_t act, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws, float* dw, void* stream) {
+    if (!y) return fail_msg("syn_conv1d_first_wgrad_bn: y is NULL (use syn_conv1d_first_wgrad)");
+    return first_wgrad_impl(x, dz, y, stats, affine, dgamma_dbeta, act, n_clips, l_in, cin, stride, pad, ws, dw, stream);
+}
+
+int syn_conv1d_first_fwd2(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, const float* w_a, const float* w_b,
+                          float* y_a, float* y_b, float* bn_part_a, float* bn_part_b, void* stream) {
+    wav::FArgs a;
+    if (!w_a || !w_b || !y_a || !y_b || ((bn_part_a == nullptr) != (bn_part_b == nullptr))) return fail_msg("syn_conv1d_first_fwd2: bad arguments");
+    if (int rc = first_layer_args(a, x, n_clips, l_in, cin, stride, pad, "syn_conv1d_first_fwd2: bad arguments (cin 1 | 2, 64 output channels)")) return rc;
+    a.W = w_a; a.W2 = w_b; a.Y = y_a; a.Y2 = y_b; a.part = bn_part_a; a.part2 = bn_part_b;
+    const dim3 grid((a.L_out + wav::kF1Tile - 1) / wav::kF1Tile, n_clips);
+    size_t lds = (size_t)((wav::kF1Tile - 1) * stride + 15) * cin * sizeof(float);
+    if (lds < 2 * 4 * 2 * 64 * sizeof(float)) lds = 2 * 4 * 2 * 64 * sizeof(float);
+    if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_fwd2<1>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(wav::k_conv_first_fwd2<2>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv_first_fwd2 launch", e);
+}
+
+// backward statistics of a BatchNorm (+ activation) alone - dgamma_dbeta [3][channels] - for a consumer that forms dy itself (syn_conv1d_first_wgrad_bn)
+int syn_bn_bwd_stats(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, const float* beta, int64_t rows,
+                     int32_t channels, int32_t act, float* ws, float* dgamma_dbeta, void* stream) {
+    if (!dz || !y || !stats || !gamma || !ws || !dgamma_dbeta || rows <= 0 || channels % 4 || 256 % (channels / 4)) return fail_msg("syn_bn_bwd_stats: bad arguments");
+    if (act && !z && !beta) return fail_msg("syn_bn_bwd_stats: without z the activation's sign is recomputed and needs beta");
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = syn_bn_chunks(rows);
+    hipLaunchKernelGGL(trn::k_bn_bwd_stats, dim3(chunks), dim3(256), 0, s, dz, z, y, stats, gamma, beta, (long)rows, channels, act, ws);
+    hipLaunchKernelGGL(trn::k_bn_bwd_finalize, dim3(channels), dim3(256), 0, s, (const float*)ws, chunks, channels, dgamma_dbeta);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_bn_bwd_stats", e);
 }
 
 // taps of the strided data-gradient GEMM, padded so that taps * cout / 32 is a multiple of the weight ring's 3

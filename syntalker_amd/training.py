@@ -1102,6 +1102,8 @@ def _conv_bn_eval(conv, bn, x):
 #             act(bn1(y1)) as it stages | bn1 backward | conv1 (and shortcut) gradients                 -> 19 tensor passes in block 0
 # Saved for the backward: x, y1, y2, y_sc and four small per-channel tables - not z1, not the normalised shortcut, not the output.
 WAV_BLOCK_FUSED = bool(int(_os.environ.get("SYN_TRAIN_WAV_BLOCK_FUSED", "1")))     # (A/B: 0 = the per-convolution nodes above)
+FIRST_PAIR = bool(int(_os.environ.get("SYN_TRAIN_FIRST_PAIR", "1")))               # block 0: conv1 + shortcut convolution as one launch (A/B: 0)
+FIRST_WGRAD_BN = bool(int(_os.environ.get("SYN_TRAIN_FIRST_WGRAD_BN", "1")))       # block 0: bn1's backward apply folded into conv1's weight gradient (A/B: 0)
 
 
 def _rows3(t):
@@ -1235,12 +1237,25 @@ class WavBlockFn(torch.autograd.Function):
         x3 = x.detach().float().contiguous() if first else _rows3(x)
         n = x3.shape[0]
         ds = blk.downsample is not None
-        y1, p1, c1 = _wb_conv_fwd(x3, blk.conv1, first)
+        ysc = sts = afs = None
+        if first and ds and FIRST_PAIR:
+            # conv1 and the shortcut convolution of block 0 read the same waveform window: one launch
+            c0, c1m = blk.conv1, blk.downsample[0]
+            l_in, cin = x3.shape[1], x3.shape[2]
+            l_out = (l_in + 2 * c0.padding[0] - 15) // c0.stride[0] + 1
+            c1 = cs = lib.syn_conv1d_first_tiles(n, l_out)
+            y1, ysc = (torch.empty(n, l_out, 64, device=x3.device, dtype=torch.float32) for _ in range(2))
+            p1, ps = (torch.empty(c1, 2, 64, device=x3.device, dtype=torch.float32) for _ in range(2))
+            _lib.check(lib.syn_conv1d_first_fwd2(x3.data_ptr(), n, l_in, cin, c0.stride[0], c0.padding[0], c0.weight.detach().data_ptr(),
+                                                 c1m.weight.detach().data_ptr(), y1.data_ptr(), ysc.data_ptr(), p1.data_ptr(), ps.data_ptr(),
+                                                 _lib.current_stream(x3.device)), "syn_conv1d_first_fwd2")
+        else:
+            y1, p1, c1 = _wb_conv_fwd(x3, blk.conv1, first)
+            if ds:
+                ysc, ps, cs = _wb_conv_fwd(x3, blk.downsample[0], first)
         rows = n * y1.shape[1]
         st1, af1 = _wb_finalize(p1, c1, rows, blk.bn1, blk.conv1.bias)
-        ysc = sts = afs = None
         if ds:
-            ysc, ps, cs = _wb_conv_fwd(x3, blk.downsample[0], first)
             sts, afs = _wb_finalize(ps, cs, rows, blk.downsample[1], blk.downsample[0].bias)
         y2, p2, c2 = _wb_conv_fwd(y1, blk.conv2, False, in_aff=af1, in_act=1)
         st2, af2 = _wb_finalize(p2, c2, rows, blk.bn2, blk.conv2.bias)
@@ -1279,11 +1294,24 @@ class WavBlockFn(torch.autograd.Function):
         # bn1 + activation (no shortcut entered it: the sign comes from y1)
         ws1 = torch.empty(2 * lib.syn_bn_chunks(rows) * c, device=dev, dtype=torch.float32)
         dgb1 = torch.empty(3, c, device=dev, dtype=torch.float32)
-        dy1 = torch.empty_like(y1)
         g1, b1 = blk.bn1.weight.detach(), blk.bn1.bias.detach()
-        _lib.check(lib.syn_bn_act_bwd(dz1.data_ptr(), None, y1.data_ptr(), st1.data_ptr(), g1.data_ptr(), b1.data_ptr(), rows, c, 1, ws1.data_ptr(),
-                                      dgb1.data_ptr(), dy1.data_ptr(), None, _lib.current_stream(dev)), "syn_bn_act_bwd")
-        gw1 = _wb_wgrad(x3, dy1, blk.conv1, first)
+        if first and FIRST_WGRAD_BN and blk.conv1.stride[0] == 5:
+            # block 0: nothing but conv1's weight gradient reads dy1 (the waveform takes no gradient) - it forms dy1 itself from (dz1, y1)
+            _lib.check(lib.syn_bn_bwd_stats(dz1.data_ptr(), None, y1.data_ptr(), st1.data_ptr(), g1.data_ptr(), b1.data_ptr(), rows, c, 1, ws1.data_ptr(),
+                                            dgb1.data_ptr(), _lib.current_stream(dev)), "syn_bn_bwd_stats")
+            cv = blk.conv1
+            nn_, l_in, cin = x3.shape
+            wsg = torch.empty(lib.syn_conv1d_first_parts(nn_, l1) * 64 * cin * 15, device=dev, dtype=torch.float32)
+            gw1 = _grad_out(cv.weight, (64, cin, 15))
+            _lib.check(lib.syn_conv1d_first_wgrad_bn(x3.data_ptr(), dz1.data_ptr(), y1.data_ptr(), st1.data_ptr(), af1.data_ptr(), dgb1.data_ptr(), 1,
+                                                     nn_, l_in, cin, cv.stride[0], cv.padding[0], wsg.data_ptr(), gw1.data_ptr(), _lib.current_stream(dev)),
+                       "syn_conv1d_first_wgrad_bn")
+            dy1 = None
+        else:
+            dy1 = torch.empty_like(y1)
+            _lib.check(lib.syn_bn_act_bwd(dz1.data_ptr(), None, y1.data_ptr(), st1.data_ptr(), g1.data_ptr(), b1.data_ptr(), rows, c, 1, ws1.data_ptr(),
+                                          dgb1.data_ptr(), dy1.data_ptr(), None, _lib.current_stream(dev)), "syn_bn_act_bwd")
+            gw1 = _wb_wgrad(x3, dy1, blk.conv1, first)
         dx = None
         if not first and ctx.needs_input_grad[0]:
             # what reaches the block's input, written once: conv1^T dy1 + (shortcut^T dy_sc | the gradient along the identity shortcut)
