@@ -154,6 +154,39 @@ def cpu_baseline(budget_s: float):
                       f"value_b40 = as-written forwards at B=40 ({n40} forwards, {dt40:.1f} s, same thread count)"}
 
 
+def practical_peak(dev, seconds: float = 0.25):
+    """The matrix pipe alone on THIS box: `syn_test_mfma_rate` (one wave per SIMD like k_seq, 12 independent v_mfma_f32_32x32x16_bf16
+    accumulators, register operands, nothing else in the stream), hipEvent-timed over a few launches of ~40 ms after a warm-up long enough for
+    the clock to settle under the load.  2.5 PFLOP/s assumes 2.4 GHz; what the chip holds on this instruction under its power cap depends on the box
+    and on the operands' switching activity (pseudo-random operand images here).  Reported BESIDE the nominal peak (roofline.peak), never instead."""
+    import ctypes
+    from syntalker_amd import _lib
+    lib = _lib.load()
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    out = torch.empty(cus * 256, device=dev, dtype=torch.float32)
+    flops = ctypes.c_int64(0)
+    st = _lib.current_stream(dev)
+    iters = 20000                                   # 20000 x 192 MFMAs x ~34 cycles ~ 65 ms at 2 GHz
+    for _ in range(3):
+        _lib.check(lib.syn_test_mfma_rate(iters, out.data_ptr(), ctypes.byref(flops), st), "syn_test_mfma_rate")
+    torch.cuda.synchronize()
+    reps = max(2, int(seconds / 0.065))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.check(lib.syn_test_mfma_rate(iters, out.data_ptr(), ctypes.byref(flops), st), "syn_test_mfma_rate")
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    rate = flops.value / (ms * 1e-3)
+    mfmas_per_wave = iters * 192
+    return {"tflops": round(rate / 1e12, 1), "frac_of_nominal_peak": round(rate / PEAK_BF16, 4), "ms_per_launch": round(ms, 3),
+            "effective_ghz_at_32_cycles_per_mfma": round(mfmas_per_wave * 32 / (ms * 1e-3) / 1e9, 3),
+            "kernel": "syn_test_mfma_rate: bare v_mfma_f32_32x32x16_bf16 loop, one wave per SIMD, 12 accumulators, register operands",
+            "note": "the matrix pipe's own rate on this box at the clock it holds under that load (power cap); k_seq's instruction stream adds LDS fragment reads, "
+                    "tape DMA, a chunk barrier per 16 MFMAs, LayerNorm / softmax / GELU and the posterior update on top of this loop"}
+
+
 def small_batch_probe(pm, coef, dev, sizes=(1, 8, 16, 32, 64, 256), reps=300):
     """Step time at the batch sizes of the reference's own sampling scripts (test.py / demo.py denoise one window at
     a time): the library picks the persistent feature-split kernel there.  Same graph-replayed step as the headline
@@ -805,6 +838,13 @@ def run_sample(args, rank, local, world, dev, dist):
                     "timed_region_replay_ms": round(replay_ms, 4),
                     "timed_region_replays_ms_per_step": getattr(timed_loop, "last_replays_ms", None),
                     "eager_stage_ms_per_step": {rename.get(k, k): round(v, 4) for k, v in stage_ms.items()}}
+        if world == 1 and not args.no_extras:
+            try:
+                pp = practical_peak(dev)
+                roofline["practical_peak"] = pp
+                roofline["frac_of_practical_peak"] = round(achieved / 1e12 / pp["tflops"], 4)
+            except Exception as e:                               # noqa: BLE001 - a diagnostic must not take the line with it
+                roofline["practical_peak"] = {"error": f"{type(e).__name__}: {e}"}
         out = {
             "metric": "denoising-steps/sec (128-frame clips)", "value": round(value, 1), "unit": "clip-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
