@@ -331,6 +331,28 @@ int syn_bn_block_bwd(const float* dz, const float* y, const float* shortcut, con
                      const float* short_affine, int64_t rows, int32_t channels, int32_t act, float* ws, float* dgb, float* short_dgb, float* dy,
                      float* dshortcut, void* stream);
 
+/* (ABI 7) The eight transformer blocks of the TRAINING forward as one persistent launch (models/timm_transformer/transformer.py:154-198 in train() mode:
+ * h + drop_path(attn(norm1(h))), then h + drop_path(mlp(norm2(h))), x 8), 1 .. 64 sequences of 32 tokens: a sequence's 32 rows are shared by 4 workgroups of
+ * one XCD (head j / MLP slice j each, partial sums exchanged through that XCD's L2: the whole-step sampling kernel's tile-split mode).  Weights: the packed
+ * fragment sets of syn_layer (syn_pack_weight / syn_pack_weights).  drop_path: NULL, or the factors [16][n_seq] (row 2 l: attention branch of block l, row
+ * 2 l + 1: its MLP branch; 0 or 1 / keep).  Written for the backward, per block, with M = 32 n_seq rows: the two branch inputs h (fp32 [M][512]) and their LayerNorm
+ * mean / rstd [M]; qkv fp32 [M][1536]; the fc1 output + bias before the GELU, fp32 [M][1024]; and the transposed bf16 operands of the four weight-gradient GEMMs as
+ * packed fragments (what syn_linear_and_pack's xt_packed holds): LN1(h)^T, attention output^T, LN2(h)^T (512 x M each), GELU output^T (1024 x M).
+ * sync: 320 zeroed uint32 (left zeroed); xch: n_seq x 8 x 16384 floats of scratch. */
+typedef struct syn_train_block_save {
+    float* h_attn; float* mean_attn; float* rstd_attn; float* qkv; void* xt_ln1; void* xt_attn;
+    float* h_mlp; float* mean_mlp; float* rstd_mlp; float* pre; void* xt_ln2; void* xt_gelu;
+} syn_train_block_save;
+typedef struct syn_train_stack {
+    const float* h_in; float* h_out;                 /* fp32 [32 n_seq][512] */
+    syn_layer layer[SYN_LAYERS];
+    syn_train_block_save save[SYN_LAYERS];
+    const float* drop_path;
+    int32_t n_seq, reserved;
+    uint32_t* sync; float* xch;
+} syn_train_stack;
+int syn_train_stack_fwd(const syn_train_stack* a, void* stream);
+
 /* (ABI 5) The optimizer step of the reference's training loop (diffusion_rvqvae_trainer.py:351-356: clip_grad_norm_(grad_norm), then Adam)
  * over lists of <= SYN_OPT_MAX fp32 tensors, pointers as kernel arguments (a captured step holds them by value):
  *   syn_opt_sqnorm    partials[b] = sum of g^2 over workgroup b's 8192-element chunk, b < syn_opt_blocks(list)        (one read of the gradients)

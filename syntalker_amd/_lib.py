@@ -23,7 +23,7 @@ EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_ste
            "syn_axis_angle_to_rot6d", "syn_rot6d_to_axis_angle", "syn_rotary", "syn_linear_wgrad_rows", "syn_masked_smooth_l1",
            "syn_bn_finalize", "syn_bn_apply2", "syn_bn_block_bwd", "syn_conv1d_train_fwd_norm", "syn_conv1d_train_wgrad_norm", "syn_conv1d_first_tiles",
            "syn_conv1d_first_fwd_stats", "syn_test_mfma_rate", "syn_conv1d_train_dgrad_sum", "syn_conv1d_first_fwd2", "syn_conv1d_first_wgrad_bn",
-           "syn_bn_bwd_stats")
+           "syn_bn_bwd_stats", "syn_train_stack_fwd")
 
 # the `void syn_debug_*` switches of the header's diagnostics section (process-wide, A/B runs and scripts/ only)
 DIAGNOSTICS = ("syn_debug_timing", "syn_debug_gemm_resident", "syn_debug_linear_tile", "syn_debug_conv_terms", "syn_debug_seq_skew", "syn_debug_seq_step")
@@ -34,6 +34,15 @@ vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
 class SynLayer(C.Structure):
     _fields_ = [("ln1_g", vp), ("ln1_b", vp), ("w_qkv", vp), ("w_proj", vp), ("b_proj", vp),
                 ("ln2_g", vp), ("ln2_b", vp), ("w_fc1", vp), ("b_fc1", vp), ("w_fc2", vp), ("b_fc2", vp)]
+
+
+class SynTrainBlockSave(C.Structure):
+    _fields_ = [(n, vp) for n in ("h_attn", "mean_attn", "rstd_attn", "qkv", "xt_ln1", "xt_attn", "h_mlp", "mean_mlp", "rstd_mlp", "pre", "xt_ln2", "xt_gelu")]
+
+
+class SynTrainStack(C.Structure):
+    _fields_ = [("h_in", vp), ("h_out", vp), ("layer", SynLayer * SYN_LAYERS), ("save", SynTrainBlockSave * SYN_LAYERS), ("drop_path", vp),
+                ("n_seq", i32), ("reserved", i32), ("sync", vp), ("xch", vp)]
 
 
 class SynModel(C.Structure):
@@ -168,6 +177,7 @@ def load():
     lib.syn_conv1d_first_tiles.argtypes = [i32, i32]
     lib.syn_conv1d_first_fwd_stats.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.syn_test_mfma_rate.argtypes = [i32, vp, vp, vp]
+    lib.syn_train_stack_fwd.argtypes = [C.POINTER(SynTrainStack), vp]
     lib.syn_conv1d_first_fwd2.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.syn_conv1d_first_wgrad_bn.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.syn_bn_bwd_stats.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, i32, i32, vp, vp, vp]

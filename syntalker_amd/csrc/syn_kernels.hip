@@ -1962,6 +1962,7 @@ int launch_stack(const SArgs& a, int mt, hipStream_t s) {
     return e == hipSuccess ? 0 : fail("k_stack launch", e);
 }
 
+#include "syn_stack_train.inc"
 #include "syn_seq.inc"
 #include "syn_cond.inc"
 #include "syn_wavenc.inc"
@@ -2534,6 +2535,32 @@ int syn_test_handoff(uint32_t* sync_320_zeroed, uint32_t* buf_8x4096, const floa
     hipLaunchKernelGGL(lat::k_handoff_stress, dim3(256), dim3(512), 96 * 1024, (hipStream_t)stream_h, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_handoff_stress launch", e);
+}
+
+int syn_train_stack_fwd(const syn_train_stack* t, void* stream) {
+    if (!t || !t->h_in || !t->h_out || !t->sync || !t->xch || t->n_seq < 1 || t->n_seq > 64) return fail_msg("syn_train_stack_fwd: 1 .. 64 sequences, non-null pointers");
+    if (!latency_path_ok()) return fail_msg("syn_train_stack_fwd: needs a 256-CU (8 XCD x 32) device");
+    stk::TArgsS a;
+    memset(&a, 0, sizeof(a));
+    a.H = t->h_in; a.Hout = t->h_out; a.dp = t->drop_path; a.M = 32 * t->n_seq; a.tiles = t->n_seq; a.sync = t->sync; a.xch = t->xch; a.flags = t->reserved;
+    for (int l = 0; l < SYN_LAYERS; ++l) {
+        const syn_layer& L = t->layer[l];
+        const syn_train_block_save& S = t->save[l];
+        if (!L.ln1_g || !L.ln1_b || !L.w_qkv || !L.w_proj || !L.b_proj || !L.ln2_g || !L.ln2_b || !L.w_fc1 || !L.b_fc1 || !L.w_fc2 || !L.b_fc2)
+            return fail_msg("syn_train_stack_fwd: a block's weights are incomplete");
+        if (!S.h_attn || !S.mean_attn || !S.rstd_attn || !S.qkv || !S.xt_ln1 || !S.xt_attn || !S.h_mlp || !S.mean_mlp || !S.rstd_mlp || !S.pre || !S.xt_ln2 || !S.xt_gelu)
+            return fail_msg("syn_train_stack_fwd: a block's saved tensors are incomplete");
+        a.layer[l] = L;
+        stk::TrainSave& d = a.save[l];
+        d.hA = S.h_attn; d.meanA = S.mean_attn; d.rstdA = S.rstd_attn; d.qkv = S.qkv; d.xt_ln1 = (uint4*)S.xt_ln1; d.xt_o = (uint4*)S.xt_attn;
+        d.hM = S.h_mlp; d.meanM = S.mean_mlp; d.rstdM = S.rstd_mlp; d.pre = S.pre; d.xt_ln2 = (uint4*)S.xt_ln2; d.xt_a = (uint4*)S.xt_gelu;
+    }
+    static OncePerDevice once;
+    if (once.first()) { allow_lds(stk::k_stack_train, stk::kTrainLds); }
+    const int grid = lat::kGroups * 4 * ((t->n_seq + lat::kGroups - 1) / lat::kGroups);
+    hipLaunchKernelGGL(stk::k_stack_train, dim3(grid), dim3(kThreads), stk::kTrainLds, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_stack_train launch", e);
 }
 
 int syn_test_mfma_rate(int32_t iters, float* out, int64_t* flops, void* stream) {

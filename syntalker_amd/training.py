@@ -131,8 +131,18 @@ WEIGHT_PACKS = bool(int(__import__("os").environ.get("SYN_WEIGHT_PACKS", "1"))) 
 _packs: "WeightPacks | None" = None
 
 
+_packs_blocks: "WeightPacks | None" = None      # the transformer blocks' Linears: packed right in front of the blocks (see train_forward)
+
+
 def _lookup_packs(w):
-    return _packs.lookup(w) if (_packs is not None and WEIGHT_PACKS) else (None, None)
+    if not WEIGHT_PACKS:
+        return None, None
+    for pk in (_packs, _packs_blocks):
+        if pk is not None:
+            r = pk.lookup(w)
+            if r[0] is not None or r[1] is not None:
+                return r
+    return None, None
 
 
 _bias_counters = {}
@@ -476,6 +486,11 @@ GELU_FUSED = int(_os.environ.get("SYN_TRAIN_GELU_FUSED", "1"))         # bit 0: 
                                                                        # operand pass (same-box A/B: no gain - erf + exp in the transposing pass cost what the launch did)
 
 
+def engine_has_xcd_groups(device) -> bool:
+    """The tile-split kernels deal the workgroups of an XCD by hardware id: 256 CUs in 8 XCDs of 32 (MI355X)."""
+    return torch.cuda.get_device_properties(device).multi_processor_count == 256
+
+
 def _fused_ok(M, *layers) -> bool:
     """Every Linear of the branch has its step packs (W and W^T fragments) and the GEMM pair's shape constraints hold."""
     if not (BLOCK_FUSED and M % 128 == 0):
@@ -574,16 +589,23 @@ class AttnBranchFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         hc, gc, mean, rstd, qkv, wqkv, wproj, factor = ctx.saved_tensors
-        xt1, xt2 = ctx.packs
         B, T, _ = hc.shape
-        d = _f32c(dout).view(B * T, 512)
-        og, ob, owq, obq, owp, obp = ctx.owners
-        do, dwp, dbp = _lin_bwd(d, xt2, wproj, ctx.bias[1], factor, T, owners=(owp, obp))
-        dqkv = torch.empty_like(qkv)
-        _lib.check(_lib.load().syn_attn_bwd(qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), B, _lib.current_stream(d.device)), "syn_attn_bwd")
-        dz, dwq, dbq = _lin_bwd(dqkv, xt1, wqkv, ctx.bias[0], owners=(owq, obq))
-        dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d, owners=(og, ob))
+        dh, dg, db, dwq, dbq, dwp, dbp = _attn_branch_bwd(_f32c(dout).view(B * T, 512), hc, gc, mean, rstd, qkv, wqkv, wproj, factor, ctx.packs, ctx.bias,
+                                                          ctx.owners)
         return dh.view(B, T, 512), dg, db, dwq, dbq, dwp, dbp, None
+
+
+def _attn_branch_bwd(d, hc, gc, mean, rstd, qkv, wqkv, wproj, factor, packs, bias, owners):
+    """Backward of h + factor * proj(attention(qkv(LayerNorm(h)))) from d = the gradient at its output, (B * 32, 512) fp32 contiguous."""
+    xt1, xt2 = packs
+    B, T = hc.shape[0], hc.shape[1]
+    og, ob, owq, obq, owp, obp = owners
+    do, dwp, dbp = _lin_bwd(d, xt2, wproj, bias[1], factor, T, owners=(owp, obp))
+    dqkv = torch.empty_like(qkv)
+    _lib.check(_lib.load().syn_attn_bwd(qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), B, _lib.current_stream(d.device)), "syn_attn_bwd")
+    dz, dwq, dbq = _lin_bwd(dqkv.view(B * T, -1), xt1, wqkv, bias[0], owners=(owq, obq))
+    dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d, owners=(og, ob))
+    return dh, dg, db, dwq, dbq, dwp, dbp
 
 
 class MlpBranchFn(torch.autograd.Function):
@@ -610,19 +632,119 @@ class MlpBranchFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         hc, gc, mean, rstd, pre, w1, w2, factor = ctx.saved_tensors
-        xt1, xt2 = ctx.packs
         B, T, _ = hc.shape
-        d = _f32c(dout).view(B * T, 512)
-        og, ob, ow1, ob1, ow2, ob2 = ctx.owners
-        da, dw2, db2 = _lin_bwd(d, xt2, w2, ctx.bias[1], factor, T, owners=(ow2, ob2))
-        if GELU_FUSED & 2:
-            dz, dw1, db1 = _lin_bwd(da, xt1, w1, ctx.bias[0], gelu_pre=pre, owners=(ow1, ob1))    # GELU' in the operand pass of fc1's backward
-        else:
-            dpre = torch.empty_like(pre)
-            _lib.check(_lib.load().syn_gelu_bwd(pre.data_ptr(), da.data_ptr(), dpre.data_ptr(), pre.numel(), _lib.current_stream(d.device)), "syn_gelu_bwd")
-            dz, dw1, db1 = _lin_bwd(dpre, xt1, w1, ctx.bias[0], owners=(ow1, ob1))
-        dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d, owners=(og, ob))
+        dh, dg, db, dw1, db1, dw2, db2 = _mlp_branch_bwd(_f32c(dout).view(B * T, 512), hc, gc, mean, rstd, pre, w1, w2, factor, ctx.packs, ctx.bias, ctx.owners)
         return dh.view(B, T, 512), dg, db, dw1, db1, dw2, db2, None
+
+
+def _mlp_branch_bwd(d, hc, gc, mean, rstd, pre, w1, w2, factor, packs, bias, owners):
+    """Backward of h + factor * fc2(GELU(fc1(LayerNorm(h)))) from d = the gradient at its output, (B * 32, 512) fp32 contiguous."""
+    xt1, xt2 = packs
+    T = hc.shape[1]
+    og, ob, ow1, ob1, ow2, ob2 = owners
+    da, dw2, db2 = _lin_bwd(d, xt2, w2, bias[1], factor, T, owners=(ow2, ob2))
+    if GELU_FUSED & 2:
+        dz, dw1, db1 = _lin_bwd(da, xt1, w1, bias[0], gelu_pre=pre, owners=(ow1, ob1))    # GELU' in the operand pass of fc1's backward
+    else:
+        dpre = torch.empty_like(pre)
+        _lib.check(_lib.load().syn_gelu_bwd(pre.data_ptr(), da.data_ptr(), dpre.data_ptr(), pre.numel(), _lib.current_stream(d.device)), "syn_gelu_bwd")
+        dz, dw1, db1 = _lin_bwd(dpre, xt1, w1, bias[0], owners=(ow1, ob1))
+    dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d, owners=(og, ob))
+    return dh, dg, db, dw1, db1, dw2, db2
+
+
+# ---- the eight blocks' forward as ONE persistent launch (round 5) ------------------------------------------------------------------------------
+# `syn_train_stack_fwd` (csrc/syn_stack_train.inc): the sampling path's whole-step kernel in its tile-split mode, writing what the branch
+# backwards above take.  56 launches at their latency floor (0.55 ms at 32 clips) become one; the backward is the per-branch chain unchanged.
+PACK_BLOCKS_LATE = bool(int(_os.environ.get("SYN_TRAIN_PACK_BLOCKS_LATE", "1")))     # (A/B: 0 = all Linears packed at the top of the forward)
+STACK_FUSED = bool(int(_os.environ.get("SYN_TRAIN_STACK_FUSED", "1")))       # (A/B: 0 = one autograd node per residual branch, `AttnBranchFn` / `MlpBranchFn`)
+_stack_ws = {}
+
+
+def _stack_workspace(device, n_seq):
+    ws = _stack_ws.get(device)
+    if ws is None or ws[1].shape[0] < n_seq:
+        ws = _stack_ws[device] = (torch.zeros(320, dtype=torch.int32, device=device), torch.empty(max(n_seq, 64), 8, 32 * 512, dtype=torch.float32, device=device))
+    return ws
+
+
+class StackFn(torch.autograd.Function):
+    """mytimmblocks[0..7] on h (B, 32, 512), B <= 64; dp: DropPath factors (16, B, 1, 1) or None; params: per block norm1.weight, norm1.bias,
+    attn.qkv.weight, attn.proj.weight, attn.proj.bias, norm2.weight, norm2.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias."""
+
+    NP = 11
+
+    @staticmethod
+    def forward(ctx, h, dp, *params):
+        lib = _lib.load()
+        hc = _f32c(h)
+        B, T, _ = hc.shape
+        M, dev = B * T, hc.device
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)
+        a = _lib.SynTrainStack()
+        out = f32(B, T, 512)
+        a.h_in, a.h_out, a.n_seq = hc.data_ptr(), out.data_ptr(), B
+        dpc = None if dp is None else _f32c(dp).view(-1, B)
+        a.drop_path = _lib.ptr(dpc)
+        sync, xch = _stack_workspace(dev, B)
+        a.sync, a.xch = sync.data_ptr(), xch.data_ptr()
+        saves, packs, keep = [], [], [hc, dpc]
+        NP = StackFn.NP
+        for l in range(len(params) // NP):
+            g1, b1, wq, wp, bp, g2, b2, w1, bb1, w2, bb2 = params[l * NP:(l + 1) * NP]
+            L = a.layer[l]
+            fr = [_lookup_packs(w) for w in (wq, wp, w1, w2)]
+            if any(f[0] is None or f[1] is None for f in fr):
+                raise _lib.SynHipError("StackFn: every Linear of the blocks needs its step packs (training.WeightPacks)")
+            vecs = [_f32c(v) for v in (g1, b1, bp, g2, b2, bb1, bb2)]
+            keep += vecs
+            L.ln1_g, L.ln1_b, L.b_proj, L.ln2_g, L.ln2_b, L.b_fc1, L.b_fc2 = (v.data_ptr() for v in vecs)
+            L.w_qkv, L.w_proj, L.w_fc1, L.w_fc2 = (f[0].data_ptr() for f in fr)
+            sv = dict(h_attn=f32(B, T, 512), mean_attn=f32(M), rstd_attn=f32(M), qkv=f32(B, T, 1536), xt_ln1=u8(512 * M * 2), xt_attn=u8(512 * M * 2),
+                      h_mlp=f32(B, T, 512), mean_mlp=f32(M), rstd_mlp=f32(M), pre=f32(M, 1024), xt_ln2=u8(512 * M * 2), xt_gelu=u8(1024 * M * 2))
+            for k, v in sv.items():
+                setattr(a.save[l], k, v.data_ptr())
+            saves.append(sv)
+            packs.append(tuple(f[1] for f in fr))            # W^T fragment sets as of this forward (qkv, proj, fc1, fc2)
+        _lib.check(lib.syn_train_stack_fwd(C.byref(a), _lib.current_stream(dev)), "syn_train_stack_fwd")
+        ctx.saves, ctx.packs, ctx.dp, ctx.params, ctx.keep = saves, packs, dpc, params, keep
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        params, NP = ctx.params, StackFn.NP
+        n = len(params) // NP
+        d = _f32c(dout)
+        B, T, _ = d.shape
+        d = d.view(B * T, 512)
+        grads = [None] * len(params)
+        for l in reversed(range(n)):
+            g1, b1, wq, wp, bp, g2, b2, w1, bb1, w2, bb2 = params[l * NP:(l + 1) * NP]
+            sv, (tq, tp_, t1, t2) = ctx.saves[l], ctx.packs[l]
+            fa = None if ctx.dp is None else ctx.dp[2 * l]
+            fm = None if ctx.dp is None else ctx.dp[2 * l + 1]
+            d, dg2, db2, dw1, dbb1, dw2, dbb2 = _mlp_branch_bwd(d, sv["h_mlp"], _f32c(g2), sv["mean_mlp"], sv["rstd_mlp"], sv["pre"], w1, w2, fm,
+                                                                  ((sv["xt_ln2"], t1), (sv["xt_gelu"], t2)), (True, True), (g2, b2, w1, bb1, w2, bb2))
+            d = d.view(B * T, 512)
+            d, dg1, db1, dwq, _, dwp, dbp = _attn_branch_bwd(d, sv["h_attn"], _f32c(g1), sv["mean_attn"], sv["rstd_attn"], sv["qkv"], wq, wp, fa,
+                                                             ((sv["xt_ln1"], tq), (sv["xt_attn"], tp_)), (False, True), (g1, b1, wq, None, wp, bp))
+            d = d.view(B * T, 512)
+            grads[l * NP:(l + 1) * NP] = [dg1, db1, dwq, dwp, dbp, dg2, db2, dw1, dbb1, dw2, dbb2]
+        return (d.view(B, T, 512), None, *grads)
+
+
+def _stack_ok(m, bs, T) -> bool:
+    if not (STACK_FUSED and torch.is_grad_enabled() and T == 32 and 1 <= bs <= 64 and len(m.mytimmblocks) == 8):
+        return False
+    for blk in m.mytimmblocks:
+        if blk.attn.qkv.bias is not None or blk.attn.proj.bias is None or blk.mlp.fc1.bias is None or blk.mlp.fc2.bias is None:
+            return False
+        if not _fused_ok(bs * T, blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
+            return False
+        if (tuple(blk.attn.qkv.weight.shape), tuple(blk.mlp.fc1.weight.shape)) != ((1536, 512), (1024, 512)):
+            return False
+    return True
 
 
 class MaskedSmoothL1Fn(torch.autograd.Function):
@@ -1381,11 +1503,16 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     global _packs
     if WEIGHT_PACKS and torch.is_grad_enabled():
         pk = m.__dict__.get("_syn_weight_packs")
-        if pk is None or pk.owner() is not m or not pk.valid():          # (a deep copy of the model brings the original's cache along)
-            pk = m.__dict__["_syn_weight_packs"] = WeightPacks([mod.weight for mod in m.modules() if isinstance(mod, nn.Linear)])
-            pk.owner = __import__("weakref").ref(m)
-        pk.refresh()
-        _packs = pk
+        if pk is None or pk[0].owner() is not m or not (pk[0].valid() and pk[1].valid()):    # (a deep copy of the model brings the original's cache along)
+            in_blocks = {id(mod.weight) for blk in m.mytimmblocks for mod in blk.modules() if isinstance(mod, nn.Linear)}
+            lin_w = [mod.weight for mod in m.modules() if isinstance(mod, nn.Linear)]
+            pk = m.__dict__["_syn_weight_packs"] = (WeightPacks([w for w in lin_w if id(w) not in in_blocks]), WeightPacks([w for w in lin_w if id(w) in in_blocks]))
+            pk[0].owner = pk[1].owner = __import__("weakref").ref(m)
+        pk[0].refresh()
+        global _packs_blocks
+        _packs, _packs_blocks = pk
+        if not PACK_BLOCKS_LATE:
+            _packs_blocks.refresh()
         global _conv_packs
         cp = m.__dict__.get("_syn_conv_packs")
         if training and (cp is None or cp.owner() is not m or not cp.valid()):
@@ -1439,7 +1566,18 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     if training and drop_path > 0.:
         keep = 1. - drop_path
         dp = h.new_empty(2 * len(m.mytimmblocks), bs, 1, 1).bernoulli_(keep).div_(keep)
-    for i, blk in enumerate(m.mytimmblocks):
+    if WEIGHT_PACKS and torch.is_grad_enabled() and PACK_BLOCKS_LATE and _packs_blocks is not None:
+        # The blocks' fragment sets are packed HERE, not at the top of the forward: the audio encoder in between moves ~1 GB through the memory-side cache,
+        # and the persistent block kernel below - latency-bound, every phase waits for its first weight fragments - then finds them in HBM
+        _packs_blocks.refresh()
+    stack = _stack_ok(m, bs, T) and engine_has_xcd_groups(h.device)
+    if stack:
+        ps = []
+        for blk in m.mytimmblocks:
+            ps += [blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias,
+                   blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias]
+        h = StackFn.apply(h, dp, *ps)
+    for i, blk in enumerate(() if stack else m.mytimmblocks):
         if torch.is_grad_enabled() and _fused_ok(bs * T, blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
             h = AttnBranchFn.apply(h, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight,
                                    blk.attn.proj.bias, None if dp is None else dp[2 * i])

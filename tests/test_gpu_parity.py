@@ -553,6 +553,45 @@ def test_fused_wav_block_equals_the_per_convolution_nodes():
         assert torch.allclose(b0[k].double(), b1[k].double(), rtol=1e-5, atol=1e-6), k
 
 
+def test_persistent_stack_forward_equals_the_per_branch_nodes():
+    """training.StackFn (round 5: the eight blocks' training forward as ONE persistent launch, `syn_train_stack_fwd` = the sampling path's whole-step
+    kernel in its tile-split mode + DropPath + the tensors the backward takes) against the per-branch nodes it replaces (`AttnBranchFn` /
+    `MlpBranchFn`): loss and every parameter gradient, with DropPath factors drawn from the same generator state.  The two forwards differ where
+    the sampling kernels do: q / k / v and the softmax numerators are rounded to bf16 for the attention's MFMAs (fp32 in `syn_attn_fwd`)."""
+    from syntalker_amd import training
+    from syntalker_amd.process import create_gaussian_diffusion
+    y = synth.to_device(synth.synth_clip_inputs(8, seed=5, mask_batch=8), DEV)
+    x0, eps = synth.synth_latent(8, seed=5, name="x0").to(DEV), synth.synth_latent(8, seed=6, name="eps").to(DEV)
+    t5 = torch.tensor([0, 17, 500, 999, 250, 3, 750, 100], device=DEV)      # (8 clips: the fused paths take row counts that are multiples of 128)
+    d = create_gaussian_diffusion()
+    res = {}
+    keep = training.STACK_FUSED
+    try:
+        for fused in (False, True):
+            training.STACK_FUSED = fused
+            m = _model("beatx").train()
+            m.drop_path = 0.25
+            torch.manual_seed(1234)
+            loss = d.training_losses(m, x0, t5, model_kwargs={"y": y}, noise=eps)["loss"]
+            loss.mean().backward()
+            res[fused] = (loss.detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None})
+    finally:
+        training.STACK_FUSED = keep
+    (l0, g0), (l1, g1) = res[False], res[True]
+    print("persistent stack vs per-branch nodes, loss ratio:", (l1 / l0).numpy())
+    assert torch.allclose(l0, l1, rtol=1e-2), (l0, l1)
+    assert g0.keys() == g1.keys()
+    worst = ("", 0.0)
+    for n in g0:
+        if float(g0[n].norm()) < 1e-6:
+            assert float(g1[n].norm()) < 1e-6, n
+            continue
+        e = rel_l2(g1[n], g0[n])
+        worst = max(worst, (n, e), key=lambda v: v[1])
+        assert e < 3e-2, (n, e)
+    print(f"persistent stack vs per-branch nodes: worst gradient rel-L2 {worst[1]:.2e} ({worst[0]})")
+
+
 def test_sync_batchnorm_model_on_the_native_path(golden):
     """train.py:90 converts every BatchNorm of the model to nn.SyncBatchNorm before DDP: the converted model keeps the audio encoder on
     the hand-written kernels (`SyncBnActFn`: fp64 sums -> all-reduce -> finalise) and, with a one-rank process group, reproduces the
