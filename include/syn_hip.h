@@ -352,6 +352,28 @@ typedef struct syn_train_stack {
     uint32_t* sync; float* xch;
 } syn_train_stack;
 int syn_train_stack_fwd(const syn_train_stack* a, void* stream);
+/* (ABI 7) The backward of those eight blocks.  syn_train_stack_bwd: the data-gradient chain as one persistent launch (same decomposition: member = head / MLP
+ * slice, two exchanges per block): dh_in [M][512] from dh_out, reading what the forward wrote (`fwd`: the forward's own struct, unchanged) and the TRANSPOSED
+ * fragment sets of the weights (layer_t[l].w_* = fragments of W^T as syn_pack_weight_t / syn_pack_weights(transposed = 1) make them; ln1_g / ln2_g the gains;
+ * the other members unused).  It leaves, per block: the gradients at the outputs of fc2, fc1, proj, qkv TRANSPOSED in bf16 ([512 | 1024 | 512 | 1536][M]:
+ * the left operands of the weight-gradient GEMMs) and `part` [n_seq][4096], per-sequence partial sums of [dLN2 gain 512 | dLN2 shift 512 | dfc2 bias 512 |
+ * dfc1 bias 1024 | dLN1 gain 512 | dLN1 shift 512 | dproj bias 512].  stash: n_seq x 4 x 16384 floats of scratch.
+ * syn_train_stack_wgrad: the 32 weight-gradient GEMMs dW [n][k] = dY^T . X, four per launch (dw_* fp32, the module's layout), and the sums of `part` over the
+ * sequences, each of its seven segments into its own tensor (d_*). */
+typedef struct syn_train_block_grad {
+    void* dyt_fc2; void* dyt_fc1; void* dyt_proj; void* dyt_qkv; float* part;
+    float* dw_fc2; float* dw_fc1; float* dw_proj; float* dw_qkv;
+    float* d_ln2_g; float* d_ln2_b; float* d_fc2_b; float* d_fc1_b; float* d_ln1_g; float* d_ln1_b; float* d_proj_b;    /* [512] each, d_fc1_b [1024] */
+} syn_train_block_grad;
+typedef struct syn_train_stack_grad {
+    const syn_train_stack* fwd;
+    const float* dh_out; float* dh_in;
+    syn_layer layer_t[SYN_LAYERS];
+    syn_train_block_grad grad[SYN_LAYERS];
+    float* stash;
+} syn_train_stack_grad;
+int syn_train_stack_bwd(const syn_train_stack_grad* a, void* stream);
+int syn_train_stack_wgrad(const syn_train_stack_grad* a, void* stream);
 
 /* (ABI 5) The optimizer step of the reference's training loop (diffusion_rvqvae_trainer.py:351-356: clip_grad_norm_(grad_norm), then Adam)
  * over lists of <= SYN_OPT_MAX fp32 tensors, pointers as kernel arguments (a captured step holds them by value):

@@ -23,7 +23,7 @@ EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_ste
            "syn_axis_angle_to_rot6d", "syn_rot6d_to_axis_angle", "syn_rotary", "syn_linear_wgrad_rows", "syn_masked_smooth_l1",
            "syn_bn_finalize", "syn_bn_apply2", "syn_bn_block_bwd", "syn_conv1d_train_fwd_norm", "syn_conv1d_train_wgrad_norm", "syn_conv1d_first_tiles",
            "syn_conv1d_first_fwd_stats", "syn_test_mfma_rate", "syn_conv1d_train_dgrad_sum", "syn_conv1d_first_fwd2", "syn_conv1d_first_wgrad_bn",
-           "syn_bn_bwd_stats", "syn_train_stack_fwd")
+           "syn_bn_bwd_stats", "syn_train_stack_fwd", "syn_train_stack_bwd", "syn_train_stack_wgrad")
 
 # the `void syn_debug_*` switches of the header's diagnostics section (process-wide, A/B runs and scripts/ only)
 DIAGNOSTICS = ("syn_debug_timing", "syn_debug_gemm_resident", "syn_debug_linear_tile", "syn_debug_conv_terms", "syn_debug_seq_skew", "syn_debug_seq_step")
@@ -43,6 +43,16 @@ class SynTrainBlockSave(C.Structure):
 class SynTrainStack(C.Structure):
     _fields_ = [("h_in", vp), ("h_out", vp), ("layer", SynLayer * SYN_LAYERS), ("save", SynTrainBlockSave * SYN_LAYERS), ("drop_path", vp),
                 ("n_seq", i32), ("reserved", i32), ("sync", vp), ("xch", vp)]
+
+
+class SynTrainBlockGrad(C.Structure):
+    _fields_ = [(n, vp) for n in ("dyt_fc2", "dyt_fc1", "dyt_proj", "dyt_qkv", "part", "dw_fc2", "dw_fc1", "dw_proj", "dw_qkv",
+                                   "d_ln2_g", "d_ln2_b", "d_fc2_b", "d_fc1_b", "d_ln1_g", "d_ln1_b", "d_proj_b")]
+
+
+class SynTrainStackGrad(C.Structure):
+    _fields_ = [("fwd", C.POINTER(SynTrainStack)), ("dh_out", vp), ("dh_in", vp), ("layer_t", SynLayer * SYN_LAYERS), ("grad", SynTrainBlockGrad * SYN_LAYERS),
+                ("stash", vp)]
 
 
 class SynModel(C.Structure):
@@ -178,6 +188,8 @@ def load():
     lib.syn_conv1d_first_fwd_stats.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.syn_test_mfma_rate.argtypes = [i32, vp, vp, vp]
     lib.syn_train_stack_fwd.argtypes = [C.POINTER(SynTrainStack), vp]
+    lib.syn_train_stack_bwd.argtypes = [C.POINTER(SynTrainStackGrad), vp]
+    lib.syn_train_stack_wgrad.argtypes = [C.POINTER(SynTrainStackGrad), vp]
     lib.syn_conv1d_first_fwd2.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.syn_conv1d_first_wgrad_bn.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.syn_bn_bwd_stats.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, i32, i32, vp, vp, vp]

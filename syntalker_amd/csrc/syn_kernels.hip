@@ -668,6 +668,14 @@ __global__ __launch_bounds__(kThreads) void k_gemm_pair(const GPair p) {
     else gemm_body<MT, EPI_PLAIN, MODE == 1>(p.g[z], blockIdx.x, blockIdx.y);
 }
 
+// Four independent plain GEMMs in one launch on MT x 128 tiles: the weight gradients of one transformer block (syn_train_stack_wgrad)
+struct GQuad { GArgs g[4]; int gx[4], gy[4]; };
+__global__ __launch_bounds__(kThreads) void k_gemm_quad(const GQuad p) {
+    const int z = blockIdx.z;
+    if ((int)blockIdx.x >= p.gx[z] || (int)blockIdx.y >= p.gy[z]) return;
+    gemm_n128(p.g[z], blockIdx.x, blockIdx.y);
+}
+
 // A forward GEMM of the training step fills a quarter to three quarters of the chip (16-row tiles x n / 512 columns), and the
 // backward will need x^T as packed fragments (the weight-gradient GEMM's B operand): grid z = 1 packs them in the GEMM's shadow.
 struct GPack { GArgs g; const __bf16* src; uint4* out; int n, k; };          // pack: fragments of W = src^T, src row-major [k][n] (k_pack_t)
@@ -1896,6 +1904,7 @@ void n128_setup() {
         allow_lds(k_gemm_n128, kN128Lds);
         allow_lds(k_gemm_pair<16, 2>, kN128Lds);
         allow_lds(k_gemm_and_pack<16, 2>, kN128Lds);
+        allow_lds(k_gemm_quad, kN128Lds);
     }
 }
 
@@ -2561,6 +2570,74 @@ int syn_train_stack_fwd(const syn_train_stack* t, void* stream) {
     hipLaunchKernelGGL(stk::k_stack_train, dim3(grid), dim3(kThreads), stk::kTrainLds, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_stack_train launch", e);
+}
+
+int syn_train_stack_bwd(const syn_train_stack_grad* t, void* stream) {
+    if (!t || !t->fwd || !t->dh_out || !t->dh_in || !t->stash) return fail_msg("syn_train_stack_bwd: null argument");
+    const syn_train_stack& f = *t->fwd;
+    if (f.n_seq < 1 || f.n_seq > 64 || !f.sync || !f.xch) return fail_msg("syn_train_stack_bwd: 1 .. 64 sequences, the forward's sync / xch");
+    if (!latency_path_ok()) return fail_msg("syn_train_stack_bwd: needs a 256-CU (8 XCD x 32) device");
+    stk::TArgsB a;
+    memset(&a, 0, sizeof(a));
+    a.dH = t->dh_out; a.dHin = t->dh_in; a.dp = f.drop_path; a.M = 32 * f.n_seq; a.tiles = f.n_seq; a.sync = f.sync; a.xch = f.xch; a.stash = t->stash;
+    for (int l = 0; l < SYN_LAYERS; ++l) {
+        const syn_layer& L = t->layer_t[l];
+        const syn_train_block_save& S = f.save[l];
+        const syn_train_block_grad& G = t->grad[l];
+        if (!L.ln1_g || !L.w_qkv || !L.w_proj || !L.ln2_g || !L.w_fc1 || !L.w_fc2) return fail_msg("syn_train_stack_bwd: a block's transposed weights / LayerNorm gains are incomplete");
+        if (!G.dyt_fc2 || !G.dyt_fc1 || !G.dyt_proj || !G.dyt_qkv || !G.part) return fail_msg("syn_train_stack_bwd: a block's outputs are incomplete");
+        a.layer[l] = L;
+        stk::TrainSave& d = a.save[l];
+        d.hA = S.h_attn; d.meanA = S.mean_attn; d.rstdA = S.rstd_attn; d.qkv = S.qkv; d.xt_ln1 = (uint4*)S.xt_ln1; d.xt_o = (uint4*)S.xt_attn;
+        d.hM = S.h_mlp; d.meanM = S.mean_mlp; d.rstdM = S.rstd_mlp; d.pre = S.pre; d.xt_ln2 = (uint4*)S.xt_ln2; d.xt_a = (uint4*)S.xt_gelu;
+        stk::TrainGrad& o = a.grad[l];
+        o.dyt_fc2 = (__bf16*)G.dyt_fc2; o.dyt_fc1 = (__bf16*)G.dyt_fc1; o.dyt_proj = (__bf16*)G.dyt_proj; o.dyt_qkv = (__bf16*)G.dyt_qkv; o.part = G.part;
+    }
+    static OncePerDevice once;
+    if (once.first()) { allow_lds(stk::k_stack_train_bwd, stk::kTrainBwdLds); }
+    const int grid = lat::kGroups * 4 * ((f.n_seq + lat::kGroups - 1) / lat::kGroups);
+    hipLaunchKernelGGL(stk::k_stack_train_bwd, dim3(grid), dim3(kThreads), stk::kTrainBwdLds, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_stack_train_bwd launch", e);
+}
+
+// The weight gradients the backward chain left open: per block dW = dY^T . X for its four Linears - dY^T from syn_train_stack_bwd ([features][M] bf16),
+// X^T fragments from the forward - four GEMMs per launch; then the per-sequence partial sums of the bias / LayerNorm gradients added up.
+int syn_train_stack_wgrad(const syn_train_stack_grad* t, void* stream) {
+    if (!t || !t->fwd) return fail_msg("syn_train_stack_wgrad: null argument");
+    const syn_train_stack& f = *t->fwd;
+    const int M = 32 * f.n_seq;
+    if (f.n_seq < 1 || f.n_seq > 64 || M % 128) return fail_msg("syn_train_stack_wgrad: the row count must be a multiple of 128 (4 sequences)");
+    n128_setup();
+    hipStream_t s = (hipStream_t)stream;
+    for (int l = 0; l < SYN_LAYERS; ++l) {
+        const syn_train_block_save& S = f.save[l];
+        const syn_train_block_grad& G = t->grad[l];
+        if (!G.dw_fc2 || !G.dw_fc1 || !G.dw_proj || !G.dw_qkv || !G.d_ln2_g || !G.d_ln2_b || !G.d_fc2_b || !G.d_fc1_b || !G.d_ln1_g || !G.d_ln1_b || !G.d_proj_b) return fail_msg("syn_train_stack_wgrad: a block's gradient buffers are incomplete");
+        GQuad q;
+        memset(&q, 0, sizeof(q));
+        const void* xs[4] = {G.dyt_fc2, G.dyt_fc1, G.dyt_proj, G.dyt_qkv};
+        const void* ws[4] = {S.xt_gelu, S.xt_ln2, S.xt_attn, S.xt_ln1};
+        const int ns[4] = {512, 1024, 512, 1536}, ks[4] = {1024, 512, 512, 512};       // dW [n][k]
+        float* ys[4] = {G.dw_fc2, G.dw_fc1, G.dw_proj, G.dw_qkv};
+        int gx = 0, gy = 0, lds = 0;
+        for (int i = 0; i < 4; ++i) {
+            GArgs& a = q.g[i];
+            a.X = (const __bf16*)xs[i]; a.ldx = M; a.x_rows = ns[i]; a.W = (const uint4*)ws[i]; a.K = M; a.M = ns[i]; a.Yf = ys[i]; a.ldyf = ks[i];
+            const int mt = pick_mt128(ns[i], ks[i], M, 4);
+            if (!mt) return fail_msg("syn_train_stack_wgrad: row count too large for the resident GEMM");
+            a.mt128 = mt; q.gx[i] = (ns[i] + mt - 1) / mt; q.gy[i] = ks[i] / 128;
+            gx = q.gx[i] > gx ? q.gx[i] : gx; gy = q.gy[i] > gy ? q.gy[i] : gy;
+            lds = mt * M * 2 > lds ? mt * M * 2 : lds;
+        }
+        hipLaunchKernelGGL(k_gemm_quad, dim3(gx, gy, 4), dim3(kThreads), lds, s, q);
+        // bias / LayerNorm gradients: column sums over the sequences, in sequence order
+        stk::SmallOut so;
+        so.p[0] = G.d_ln2_g; so.p[1] = G.d_ln2_b; so.p[2] = G.d_fc2_b; so.p[3] = G.d_fc1_b; so.p[4] = G.d_ln1_g; so.p[5] = G.d_ln1_b; so.p[6] = G.d_proj_b;
+        hipLaunchKernelGGL(stk::k_part_sums, dim3((stk::kPartCols + 255) / 256), dim3(256), 0, s, (const float*)G.part, f.n_seq, so);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_train_stack_wgrad", e);
 }
 
 int syn_test_mfma_rate(int32_t iters, float* out, int64_t* flops, void* stream) {

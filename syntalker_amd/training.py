@@ -657,7 +657,8 @@ def _mlp_branch_bwd(d, hc, gc, mean, rstd, pre, w1, w2, factor, packs, bias, own
 # `syn_train_stack_fwd` (csrc/syn_stack_train.inc): the sampling path's whole-step kernel in its tile-split mode, writing what the branch
 # backwards above take.  56 launches at their latency floor (0.55 ms at 32 clips) become one; the backward is the per-branch chain unchanged.
 PACK_BLOCKS_LATE = bool(int(_os.environ.get("SYN_TRAIN_PACK_BLOCKS_LATE", "1")))     # (A/B: 0 = all Linears packed at the top of the forward)
-STACK_FUSED = bool(int(_os.environ.get("SYN_TRAIN_STACK_FUSED", "1")))       # (A/B: 0 = one autograd node per residual branch, `AttnBranchFn` / `MlpBranchFn`)
+STACK_FUSED = bool(int(_os.environ.get("SYN_TRAIN_STACK_FUSED", "1")))
+STACK_BWD_FUSED = bool(int(_os.environ.get("SYN_TRAIN_STACK_BWD_FUSED", "1")))   # (A/B: 0 = the per-branch backward chain behind the persistent forward)       # (A/B: 0 = one autograd node per residual branch, `AttnBranchFn` / `MlpBranchFn`)
 _stack_ws = {}
 
 
@@ -708,11 +709,53 @@ class StackFn(torch.autograd.Function):
             saves.append(sv)
             packs.append(tuple(f[1] for f in fr))            # W^T fragment sets as of this forward (qkv, proj, fc1, fc2)
         _lib.check(lib.syn_train_stack_fwd(C.byref(a), _lib.current_stream(dev)), "syn_train_stack_fwd")
-        ctx.saves, ctx.packs, ctx.dp, ctx.params, ctx.keep = saves, packs, dpc, params, keep
+        ctx.saves, ctx.packs, ctx.dp, ctx.params, ctx.keep, ctx.fwd = saves, packs, dpc, params, keep, a
         return out
 
     @staticmethod
+    def _backward_persistent(ctx, dout):
+        """The data-gradient chain as one launch (`syn_train_stack_bwd`), then the 32 weight-gradient GEMMs four per launch (`syn_train_stack_wgrad`)."""
+        lib = _lib.load()
+        params, NP = ctx.params, StackFn.NP
+        d = _f32c(dout)
+        B, T, _ = d.shape
+        M, dev = B * T, d.device
+        g = _lib.SynTrainStackGrad()
+        g.fwd = C.pointer(ctx.fwd)
+        dh_in = torch.empty(B, T, 512, dtype=torch.float32, device=dev)
+        stash = torch.empty(B, 4, 32 * 512, dtype=torch.float32, device=dev)
+        g.dh_out, g.dh_in, g.stash = d.data_ptr(), dh_in.data_ptr(), stash.data_ptr()
+        bf = lambda n: torch.empty(n, M, dtype=torch.bfloat16, device=dev)
+        keep, grads = [d, stash], [None] * len(params)
+        for l in range(len(params) // NP):
+            g1, b1, wq, wp, bp, g2, b2, w1, bb1, w2, bb2 = params[l * NP:(l + 1) * NP]
+            tq, tp_, t1, t2 = ctx.packs[l]
+            L = g.layer_t[l]
+            gains = (_f32c(g1), _f32c(g2))
+            L.ln1_g, L.ln2_g = gains[0].data_ptr(), gains[1].data_ptr()
+            L.w_qkv, L.w_proj, L.w_fc1, L.w_fc2 = tq.data_ptr(), tp_.data_ptr(), t1.data_ptr(), t2.data_ptr()
+            G = g.grad[l]
+            ten = dict(dyt_fc2=bf(512), dyt_fc1=bf(1024), dyt_proj=bf(512), dyt_qkv=bf(1536), part=torch.empty(B, 4096, dtype=torch.float32, device=dev),
+                       dw_fc2=_grad_out(w2), dw_fc1=_grad_out(w1), dw_proj=_grad_out(wp), dw_qkv=_grad_out(wq),
+                       d_ln2_g=_grad_out(g2), d_ln2_b=_grad_out(b2), d_fc2_b=_grad_out(bb2), d_fc1_b=_grad_out(bb1), d_ln1_g=_grad_out(g1), d_ln1_b=_grad_out(b1),
+                       d_proj_b=_grad_out(bp))
+            for k, v in ten.items():
+                setattr(G, k, v.data_ptr())
+            # (no second reference to a gradient tensor may survive this function: AccumulateGrad adopts a gradient only if it is the sole owner,
+            # and clones it otherwise - 88 device copies per step)
+            keep += [gains, [ten[k] for k in ("dyt_fc2", "dyt_fc1", "dyt_proj", "dyt_qkv", "part")]]
+            grads[l * NP:(l + 1) * NP] = [ten["d_ln1_g"], ten["d_ln1_b"], ten["dw_qkv"], ten["dw_proj"], ten["d_proj_b"], ten["d_ln2_g"], ten["d_ln2_b"],
+                                          ten["dw_fc1"], ten["d_fc1_b"], ten["dw_fc2"], ten["d_fc2_b"]]
+        st = _lib.current_stream(dev)
+        _lib.check(lib.syn_train_stack_bwd(C.byref(g), st), "syn_train_stack_bwd")
+        _lib.check(lib.syn_train_stack_wgrad(C.byref(g), st), "syn_train_stack_wgrad")
+        del ten, keep                             # (stream-ordered allocator: the launches above are enqueued, later work on this stream comes after them)
+        return (dh_in, None, *grads)
+
+    @staticmethod
     def backward(ctx, dout):
+        if STACK_BWD_FUSED and dout.shape[0] % 4 == 0:
+            return StackFn._backward_persistent(ctx, dout)
         params, NP = ctx.params, StackFn.NP
         n = len(params) // NP
         d = _f32c(dout)

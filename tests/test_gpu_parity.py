@@ -592,6 +592,47 @@ def test_persistent_stack_forward_equals_the_per_branch_nodes():
     print(f"persistent stack vs per-branch nodes: worst gradient rel-L2 {worst[1]:.2e} ({worst[0]})")
 
 
+def test_persistent_stack_backward_equals_the_per_branch_chain():
+    """`syn_train_stack_bwd` + `syn_train_stack_wgrad` (round 5: the blocks' data-gradient chain as one persistent launch - MFMA attention backward, GELU',
+    LayerNorm backward, DropPath - and the 32 weight-gradient GEMMs four per launch) against the per-branch backward chain (`_mlp_branch_bwd` /
+    `_attn_branch_bwd`: `syn_linear_bwd_prep` + `syn_linear_pair` + `syn_attn_bwd` + `syn_ln_bwd`) behind the SAME persistent forward: the forward is
+    bit-identical in both runs, so every difference is the backward's (bf16 attention operands where `syn_attn_bwd` is fp32)."""
+    from syntalker_amd import training
+    from syntalker_amd.process import create_gaussian_diffusion
+    y = synth.to_device(synth.synth_clip_inputs(8, seed=5, mask_batch=8), DEV)
+    x0, eps = synth.synth_latent(8, seed=5, name="x0").to(DEV), synth.synth_latent(8, seed=6, name="eps").to(DEV)
+    t8 = torch.tensor([0, 17, 500, 999, 250, 3, 750, 100], device=DEV)
+    d = create_gaussian_diffusion()
+    res = {}
+    keep = training.STACK_BWD_FUSED
+    try:
+        for fused in (False, True):
+            training.STACK_BWD_FUSED = fused
+            m = _model("beatx").train()
+            m.drop_path = 0.25
+            torch.manual_seed(1234)
+            loss = d.training_losses(m, x0, t8, model_kwargs={"y": y}, noise=eps)["loss"]
+            loss.mean().backward()
+            res[fused] = (loss.detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None})
+    finally:
+        training.STACK_BWD_FUSED = keep
+    (l0, g0), (l1, g1) = res[False], res[True]
+    assert torch.equal(l0, l1)
+    assert g0.keys() == g1.keys()
+    worst = ("", 0.0)
+    for n in g0:
+        if float(g0[n].norm()) < 1e-6:
+            assert float(g1[n].norm()) < 1e-6, n
+            continue
+        e = rel_l2(g1[n], g0[n])
+        worst = max(worst, (n, e), key=lambda v: v[1])
+        assert e < 2e-2, (n, e)
+    print(f"persistent backward vs per-branch chain: worst gradient rel-L2 {worst[1]:.2e} ({worst[0]})")
+    for n in ("mytimmblocks.7.mlp.fc2.bias", "mytimmblocks.7.mlp.fc2.weight", "mytimmblocks.7.norm2.weight", "mytimmblocks.7.mlp.fc1.weight", "mytimmblocks.7.attn.proj.weight",
+              "mytimmblocks.7.attn.qkv.weight", "mytimmblocks.7.norm1.weight", "mytimmblocks.0.attn.qkv.weight", "input_process2.weight"):
+        print(f"   {n}: {rel_l2(g1[n], g0[n]):.2e}")
+
+
 def test_sync_batchnorm_model_on_the_native_path(golden):
     """train.py:90 converts every BatchNorm of the model to nn.SyncBatchNorm before DDP: the converted model keeps the audio encoder on
     the hand-written kernels (`SyncBnActFn`: fp64 sums -> all-reduce -> finalise) and, with a one-rank process group, reproduces the
