@@ -2610,6 +2610,7 @@ int syn_train_stack_wgrad(const syn_train_stack_grad* t, void* stream) {
     if (f.n_seq < 1 || f.n_seq > 64 || M % 128) return fail_msg("syn_train_stack_wgrad: the row count must be a multiple of 128 (4 sequences)");
     n128_setup();
     hipStream_t s = (hipStream_t)stream;
+    stk::SmallOut so;
     for (int l = 0; l < SYN_LAYERS; ++l) {
         const syn_train_block_save& S = f.save[l];
         const syn_train_block_grad& G = t->grad[l];
@@ -2632,10 +2633,11 @@ int syn_train_stack_wgrad(const syn_train_stack_grad* t, void* stream) {
         }
         hipLaunchKernelGGL(k_gemm_quad, dim3(gx, gy, 4), dim3(kThreads), lds, s, q);
         // bias / LayerNorm gradients: column sums over the sequences, in sequence order
-        stk::SmallOut so;
-        so.p[0] = G.d_ln2_g; so.p[1] = G.d_ln2_b; so.p[2] = G.d_fc2_b; so.p[3] = G.d_fc1_b; so.p[4] = G.d_ln1_g; so.p[5] = G.d_ln1_b; so.p[6] = G.d_proj_b;
-        hipLaunchKernelGGL(stk::k_part_sums, dim3((stk::kPartCols + 255) / 256), dim3(256), 0, s, (const float*)G.part, f.n_seq, so);
+        float* const outs[7] = {G.d_ln2_g, G.d_ln2_b, G.d_fc2_b, G.d_fc1_b, G.d_ln1_g, G.d_ln1_b, G.d_proj_b};
+        so.part[l] = G.part;
+        for (int i = 0; i < 7; ++i) so.p[l][i] = outs[i];
     }
+    hipLaunchKernelGGL(stk::k_part_sums, dim3((stk::kPartCols + 255) / 256, SYN_LAYERS), dim3(256), 0, s, f.n_seq, so);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("syn_train_stack_wgrad", e);
 }

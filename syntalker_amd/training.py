@@ -1584,14 +1584,20 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     if _tracked:
         torch._foreach_add_(list(_tracked), 1)
         _tracked.clear()
-    a = a.squeeze(2)
-    a_feat = a.transpose(1, 2).permute(1, 0, 2)                                  # (128, B, 256)
-    w_feat = lin(_embed(m.text_pre_encoder_body, word), m.text_encoder_body).permute(1, 0, 2)
+    # From here on rows are (clip, frame), not the reference's (frame, clip) (denoiser.py:151-176): every op below is row-wise or acts along the
+    # frame axis of one clip, so the order is free - and this one needs no transposing copy between the encoder, the blocks and the output.
+    a_feat = a.squeeze(2).transpose(1, 2)                  # (B, 128, 256): the channels_last output of the encoder as it lies in memory
+    w_feat = lin(_embed(m.text_pre_encoder_body, word), m.text_encoder_body)        # (B, 128, 256)
     at = lin(torch.cat([a_feat, w_feat], dim=2), m.mix_audio_text)
-    at = F.avg_pool1d(at.permute(1, 2, 0), getattr(m.args, "vqvae_squeeze_scale", 4) if not h3d else 4).permute(2, 0, 1)
-    xt = x.reshape(bs, C, 1, T).permute(3, 0, 1, 2).reshape(T, bs, C)
+    pool = getattr(m.args, "vqvae_squeeze_scale", 4) if not h3d else 4
+    if at.shape[1] % pool:
+        at = at[:, :at.shape[1] // pool * pool]              # (F.avg_pool1d drops the incomplete window)
+    at = at.reshape(bs, at.shape[1] // pool, pool, at.shape[2]).mean(dim=2)         # F.avg_pool1d over the frame axis (denoiser.py:157) -> (B, T, 256)
+    xt = torch.empty(bs, T, C, dtype=torch.bfloat16, device=x.device)
+    xt.copy_(x.detach().reshape(bs, C, T).transpose(1, 2))                          # (B, T, C) GEMM operand: transpose + bf16 rounding as one pass
     x_ = lin(xt, m.input_process.poseEmbedding)
-    seq = lin(torch.cat(((emb_seed + emb_t).repeat(T, 1, 1), x_, at), dim=2), m.input_process2)
+    emb = (emb_seed + emb_t.reshape(bs, -1)).unsqueeze(1).expand(bs, T, emb_seed.shape[-1])
+    seq = lin(torch.cat((emb, x_, at), dim=2), m.input_process2)
     if m.uses_style:
         st = y["style_feature"]
         force = bool(y.get("uncond", False))
@@ -1601,8 +1607,8 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
         elif training and m.cond_mask_prob > 0.:
             mask = torch.bernoulli(torch.ones(bs, device=st.device) * m.cond_mask_prob).view(bs, 1)
             st = st * (1. - mask) + null * mask
-        seq = lin(torch.cat((seq, st.unsqueeze(0).repeat(T, 1, 1)), dim=2), m.input_process3)
-    h = _rotary(m, seq.permute(1, 0, 2))
+        seq = lin(torch.cat((seq, st.unsqueeze(1).expand(bs, T, st.shape[-1])), dim=2), m.input_process3)
+    h = _rotary(m, seq)
     # DropPath (timm_transformer/transformer.py:21-38: one Bernoulli(keep) / keep factor per sample and residual branch): all the
     # step's factors from one draw, and x + branch * factor as one fused multiply-add instead of bernoulli, div, mul, add per branch
     dp = None
@@ -1634,8 +1640,8 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
         z, h = HipLnForkFn.apply(h, blk.norm2.weight, blk.norm2.bias)
         br = lin(HipGeluFn.apply(lin(z, blk.mlp.fc1)), blk.mlp.fc2)
         h = h + br if dp is None else torch.addcmul(h, br, dp[2 * i + 1])
-    out = lin(h.permute(1, 0, 2), m.output_process.poseFinal)
-    return out.reshape(T, bs, C, 1).permute(1, 2, 3, 0)
+    out = lin(h, m.output_process.poseFinal)                # (B, T, C)
+    return out.permute(0, 2, 1).unsqueeze(2)                # (B, C, 1, T) as the reference returns it (a view: the loss kernel reads either layout)
 
 
 def unused_in_forward(model) -> tuple:
