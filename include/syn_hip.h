@@ -597,7 +597,8 @@ void syn_debug_gemm_resident(int on);
 /* pin syn_linear's row tile (16 / 32 / 64 / 128); 0 = automatic */
 void syn_debug_linear_tile(int rows);
 /* training-mode convolutions (syn_conv1d_train_*): which cross products of the hi / lo operand split the NEXT launches issue - bit 0: A_lo . B_hi
- * (A = weights, or dy in the weight gradient), bit 1: A_hi . B_lo (B = the activations: x, or dy in the data gradient); 3 (default) = both, fp32-grade */
+ * (A = weights, or dy in the weight gradient), bit 1: A_hi . B_lo (B = the activations: x, or dy in the data gradient); 3 = both, fp32-grade; a negative mask restores the defaults (3 forward / data gradient,
+ * 1 weight gradient: x is read rounded to bf16 there, the sum over positions averages it out) */
 void syn_debug_conv_terms(int mask);
 /* k_seq: delay workgroup i by (i % 8) * units_of_64_cycles * 64 cycles at launch (phase experiments); -1 = off */
 void syn_debug_seq_skew(int units_of_64_cycles);

@@ -2015,11 +2015,16 @@ int launch_conv(const wav::CArgs& a, int n_clips, hipStream_t s) {
 }
 
 // diagnostics (syn_debug_conv_terms): which of the two cross products of the split-operand convolutions are issued (3 = both)
-static int g_conv_terms = 3;
+// Default (-1): forward and data gradient issue both cross products (fp32-grade: the forward activations feed batch statistics, and rounding them to bf16
+// moved the first blocks' gradients by 14 %); the WEIGHT gradient drops the dy_hi . x_lo product, i.e. reads x rounded to bf16 - a sum over
+// 10^4 - 10^5 positions per element averages that rounding out (r4 A/B, profiles/r04_ab_conv_terms.txt: every gradient within the same error as with
+// the third product, -0.08 ms per step).
+static int g_conv_terms = -1;
+static inline int conv_terms(bool wgrad) { return g_conv_terms >= 0 ? g_conv_terms : (wgrad ? 1 : 3); }
 
 template <int CINP, int KT, int RF>
 int launch_conv_train_ks(const wav::TArgs& a0, int n_clips, hipStream_t s) {
-    wav::TArgs a = a0; a.terms = g_conv_terms;
+    wav::TArgs a = a0; a.terms = conv_terms(false);
     constexpr int MW = RF * 16, lds = 2 * (MW + KT - 1) * (CINP * 2 + 16);
     static_assert(lds <= 160 * 1024, "two bf16 planes of the input tile must fit the LDS");
     static OncePerDevice once;
@@ -2031,7 +2036,7 @@ int launch_conv_train_ks(const wav::TArgs& a0, int n_clips, hipStream_t s) {
 
 template <int CINP, int KT, int WN, int WM, int RF>
 int launch_conv_train(const wav::TArgs& a0, int n_clips, hipStream_t s) {
-    wav::TArgs a = a0; a.terms = g_conv_terms;
+    wav::TArgs a = a0; a.terms = conv_terms(false);
     constexpr int MW = WM * RF * 16, lds = 2 * (MW + KT - 1) * (CINP * 2 + 16);
     static_assert(lds <= 160 * 1024, "two bf16 planes of the input tile must fit the LDS");
     static OncePerDevice once;
@@ -2043,7 +2048,7 @@ int launch_conv_train(const wav::TArgs& a0, int n_clips, hipStream_t s) {
 
 template <int CO_T, int TAPS>
 int launch_wgrad_s(const wav::WArgs& a0, hipStream_t s) {
-    wav::WArgs a = a0; a.terms = g_conv_terms;
+    wav::WArgs a = a0; a.terms = conv_terms(true);
     static_assert(wav::wgrad_s_lds(CO_T) <= 160 * 1024, "dy and x' tiles must fit the LDS");
     static OncePerDevice once;
     if (once.first()) { allow_lds(wav::k_conv_wgrad_s<CO_T, TAPS>, wav::wgrad_s_lds(CO_T)); }
@@ -2054,7 +2059,7 @@ int launch_wgrad_s(const wav::WArgs& a0, hipStream_t s) {
 
 template <int CO, int TAPS>
 int launch_wgrad(const wav::WArgs& a0, hipStream_t s) {
-    wav::WArgs a = a0; a.terms = g_conv_terms;
+    wav::WArgs a = a0; a.terms = conv_terms(true);
     static OncePerDevice once;
     constexpr int CB = wav::wgrad_cb(CO);
     if (once.first()) { allow_lds(wav::k_conv_wgrad<CO, TAPS, CB>, wav::wgrad_lds(CO)); }
@@ -3586,7 +3591,7 @@ int syn_denoise_step(const syn_model* md, const syn_step* st, void* stream) {
     return step_impl(md, st, (hipStream_t)stream, nullptr);
 }
 
-void syn_debug_conv_terms(int mask) { g_conv_terms = mask & 3; }   /* diagnostics: cross products of the split-operand training convolutions (3 = all) */
+void syn_debug_conv_terms(int mask) { g_conv_terms = mask < 0 ? -1 : (mask & 3); }   /* diagnostics: cross products of the split-operand training convolutions (3 = all) */
 void syn_debug_seq_skew(int units_of_64_cycles) { g_seq_skew = units_of_64_cycles; }
 void syn_debug_seq_step(int step) { g_seq_dbg_step = step; }
 

@@ -933,17 +933,18 @@ def _unsupported_conv(what, cin, stride, pad, cout):
 def _parse_conv_terms(text: str) -> tuple:
     parts = text.split(",")
     if len(parts) != 3 or not all(p.strip() in ("0", "1", "2", "3") for p in parts):
-        raise ValueError(f"SYN_CONV_TERMS must be three masks 0..3 'forward,data-gradient,weight-gradient' (default 3,3,3), got {text!r}")
+        raise ValueError(f"SYN_CONV_TERMS must be three masks 0..3 'forward,data-gradient,weight-gradient' (default 3,3,1), got {text!r}")
     return tuple(int(p) for p in parts)
 
 
-CONV_TERMS = _parse_conv_terms(_os.environ.get("SYN_CONV_TERMS", "3,3,3"))
+CONV_TERMS = _parse_conv_terms(_os.environ.get("SYN_CONV_TERMS", "3,3,1"))
 
 
 def _conv_terms(role: int):
-    """Diagnostics only: with the default (3, 3, 3) the library's switch is never touched - the product path makes no `syn_debug_*` call.
+    """Diagnostics only: with the default (3, 3, 1 = the library's own: both cross products forward and in the data gradient, one in the weight
+    gradient) the library's switch is never touched - the product path makes no `syn_debug_*` call.
     An A/B run (SYN_CONV_TERMS set to something else) selects the role's mask in front of every convolution launch."""
-    if CONV_TERMS != (3, 3, 3):
+    if CONV_TERMS != (3, 3, 1):
         _lib.load().syn_debug_conv_terms(CONV_TERMS[role])
 
 

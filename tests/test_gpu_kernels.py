@@ -538,7 +538,20 @@ def test_training_conv_forward_on_split_operands_vs_fp32(cin, stride, cout, pad,
     y.backward(gy)
     x2, w2 = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
     torch.nn.functional.conv2d(x2, w2, None, stride=(1, stride), padding=(0, pad)).backward(gy)
-    assert rel_l2(x.grad.cpu(), x2.grad.cpu()) < 1e-5 and rel_l2(w.grad.cpu(), w2.grad.cpu()) < 1e-5
+    # data gradient: both cross products (fp32-grade).  Weight gradient, the library's default: x read rounded to bf16 (one cross product dropped,
+    # round 5) - 2^-9 per element, averaged down by the sum over positions in the real layers; with all three products (syn_debug_conv_terms(3)) fp32-grade
+    ew = rel_l2(w.grad.cpu(), w2.grad.cpu())
+    print(f"conv {cin}x{stride}->{cout}: weight gradient rel-L2 {ew:.2e} (default: two of three products)")
+    assert rel_l2(x.grad.cpu(), x2.grad.cpu()) < 1e-5 and ew < 4e-3
+    from syntalker_amd import _lib
+    lib = _lib.load()
+    try:
+        lib.syn_debug_conv_terms(3)
+        x3, w3 = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+        training.ConvSplitFn.apply(x3, w3, stride, pad).backward(gy)
+        assert rel_l2(w3.grad.cpu(), w2.grad.cpu()) < 1e-5 and rel_l2(x3.grad.cpu(), x2.grad.cpu()) < 1e-5
+    finally:
+        lib.syn_debug_conv_terms(-1)
 
 
 def test_embedding_gradient_vs_torch():
