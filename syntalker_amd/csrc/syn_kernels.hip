@@ -2433,8 +2433,8 @@ static int g_linear_mt = 0;
 
 static int linear_impl(const void* x_bf16, const void* w_packed, const float* bias, const float* res, const float* rscale, int rows_per_scale,
                        int32_t m_rows, int32_t n, int32_t k, float* y, void* xt_packed, void* stream, const char* who, void* gelu_bf16 = nullptr) {
-    if (!x_bf16 || !w_packed || !y || n % kNT || k % 128 || m_rows <= 0 || (rscale && (!res || rows_per_scale <= 0)))
-        return fail_msg("syn_linear*: need n % 512 == 0, k % 128 == 0, m_rows > 0, non-null pointers (a row scale needs the residual and rows_per_scale > 0)");
+    if (!x_bf16 || !w_packed || !y || n % 128 || k % 128 || m_rows <= 0 || (rscale && (!res || rows_per_scale <= 0)))
+        return fail_msg("syn_linear*: need n % 128 == 0 (n % 512 == 0 for the fused epilogues), k % 128 == 0, m_rows > 0, non-null pointers (a row scale needs the residual and rows_per_scale > 0)");
     if (xt_packed && (m_rows % 32 || k % 16)) return fail_msg("syn_linear_and_pack: the x^T pack needs m_rows % 32 == 0");
     GPack p;
     memset(&p, 0, sizeof(p));
@@ -2443,6 +2443,17 @@ static int linear_impl(const void* x_bf16, const void* w_packed, const float* bi
     a.bias = bias; a.Yf = y; a.ldyf = n;
     a.res = res; a.rscale = rscale; a.rows_per_scale = rows_per_scale;
     a.Y = (__bf16*)gelu_bf16;
+    if (n % kNT) {
+        // 128 or 256 output features (mix_audio_text: 512 -> 256): the 128-column tiles only
+        const int m128 = (g_gemm_resident == 2 && !res && !gelu_bf16) ? pick_mt128(m_rows, n, k) : 0;
+        if (!m128) return fail_msg("syn_linear: n % 512 != 0 needs the plain epilogue and k <= 4096 (128-column tiles)");
+        a.mt128 = m128;
+        n128_setup();
+        hipLaunchKernelGGL(k_gemm_n128, dim3((m_rows + m128 - 1) / m128, n / 128), dim3(kThreads), m128 * k * 2, (hipStream_t)stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(who, e);
+        return xt_packed ? syn_pack_weight_t(x_bf16, 1, k, m_rows, xt_packed, stream) : 0;
+    }
     if (!xt_packed && !res && !gelu_bf16 && m_rows <= 64 && k >= 2048 && g_linear_mt == 0 && g_gemm_resident) {       // a few rows, long K: split K over the waves
         hipLaunchKernelGGL(k_gemm_skinny, dim3(n / 16, (m_rows + 15) / 16), dim3(kThreads), 0, (hipStream_t)stream, a);
         hipError_t e = hipGetLastError();

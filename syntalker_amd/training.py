@@ -94,7 +94,7 @@ class WeightPacks:
                 continue
             dev = w.device
             N, K = w.shape
-            fwd = torch.empty(N * K * 2, dtype=torch.uint8, device=dev) if N % 512 == 0 and K % 128 == 0 else None
+            fwd = torch.empty(N * K * 2, dtype=torch.uint8, device=dev) if N % 128 == 0 and K % 128 == 0 else None    # (N % 512 != 0: the 128-column GEMM)
             tr = torch.empty(N * K * 2, dtype=torch.uint8, device=dev) if K % 512 == 0 and N % 128 == 0 else None
             if fwd is None and tr is None:
                 continue
