@@ -371,6 +371,8 @@ typedef struct syn_train_stack_grad {
     syn_layer layer_t[SYN_LAYERS];
     syn_train_block_grad grad[SYN_LAYERS];
     float* stash;
+    int32_t first_block, last_block;          /* the blocks a call covers, SYN_LAYERS > first_block >= last_block >= 0 (the chain walks them downwards): cut in pieces,
+                                               * the weight-gradient GEMMs of a finished piece can run on another stream beside the next piece of the chain */
 } syn_train_stack_grad;
 int syn_train_stack_bwd(const syn_train_stack_grad* a, void* stream);
 int syn_train_stack_wgrad(const syn_train_stack_grad* a, void* stream);

@@ -52,7 +52,7 @@ class SynTrainBlockGrad(C.Structure):
 
 class SynTrainStackGrad(C.Structure):
     _fields_ = [("fwd", C.POINTER(SynTrainStack)), ("dh_out", vp), ("dh_in", vp), ("layer_t", SynLayer * SYN_LAYERS), ("grad", SynTrainBlockGrad * SYN_LAYERS),
-                ("stash", vp)]
+                ("stash", vp), ("first_block", i32), ("last_block", i32)]
 
 
 class SynModel(C.Structure):

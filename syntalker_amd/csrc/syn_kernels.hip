@@ -2596,6 +2596,8 @@ int syn_train_stack_bwd(const syn_train_stack_grad* t, void* stream) {
     stk::TArgsB a;
     memset(&a, 0, sizeof(a));
     a.dH = t->dh_out; a.dHin = t->dh_in; a.dp = f.drop_path; a.M = 32 * f.n_seq; a.tiles = f.n_seq; a.sync = f.sync; a.xch = f.xch; a.stash = t->stash;
+    a.l_first = t->first_block; a.l_last = t->last_block;
+    if (a.l_first < a.l_last || a.l_last < 0 || a.l_first >= SYN_LAYERS) return fail_msg("syn_train_stack_bwd: blocks are walked downwards: SYN_LAYERS > first_block >= last_block >= 0");
     for (int l = 0; l < SYN_LAYERS; ++l) {
         const syn_layer& L = t->layer_t[l];
         const syn_train_block_save& S = f.save[l];
@@ -2627,7 +2629,9 @@ int syn_train_stack_wgrad(const syn_train_stack_grad* t, void* stream) {
     n128_setup();
     hipStream_t s = (hipStream_t)stream;
     stk::SmallOut so;
-    for (int l = 0; l < SYN_LAYERS; ++l) {
+    memset(&so, 0, sizeof(so));
+    if (t->first_block < t->last_block || t->last_block < 0 || t->first_block >= SYN_LAYERS) return fail_msg("syn_train_stack_wgrad: SYN_LAYERS > first_block >= last_block >= 0");
+    for (int l = t->last_block; l <= t->first_block; ++l) {
         const syn_train_block_save& S = f.save[l];
         const syn_train_block_grad& G = t->grad[l];
         if (!G.dw_fc2 || !G.dw_fc1 || !G.dw_proj || !G.dw_qkv || !G.d_ln2_g || !G.d_ln2_b || !G.d_fc2_b || !G.d_fc1_b || !G.d_ln1_g || !G.d_ln1_b || !G.d_proj_b) return fail_msg("syn_train_stack_wgrad: a block's gradient buffers are incomplete");
@@ -2653,7 +2657,7 @@ int syn_train_stack_wgrad(const syn_train_stack_grad* t, void* stream) {
         so.part[l] = G.part;
         for (int i = 0; i < 7; ++i) so.p[l][i] = outs[i];
     }
-    hipLaunchKernelGGL(stk::k_part_sums, dim3((stk::kPartCols + 255) / 256, SYN_LAYERS), dim3(256), 0, s, f.n_seq, so);
+    hipLaunchKernelGGL(stk::k_part_sums, dim3((stk::kPartCols + 255) / 256, t->first_block - t->last_block + 1), dim3(256), 0, s, f.n_seq, t->last_block, so);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("syn_train_stack_wgrad", e);
 }

@@ -658,6 +658,19 @@ def _mlp_branch_bwd(d, hc, gc, mean, rstd, pre, w1, w2, factor, packs, bias, own
 # backwards above take.  56 launches at their latency floor (0.55 ms at 32 clips) become one; the backward is the per-branch chain unchanged.
 PACK_BLOCKS_LATE = bool(int(_os.environ.get("SYN_TRAIN_PACK_BLOCKS_LATE", "1")))     # (A/B: 0 = all Linears packed at the top of the forward)
 STACK_FUSED = bool(int(_os.environ.get("SYN_TRAIN_STACK_FUSED", "1")))
+STACK_BWD_PIECES = int(_os.environ.get("SYN_TRAIN_STACK_BWD_PIECES", "1"))        # the backward chain in this many launches, the finished pieces' weight-gradient GEMMs on a
+                                                                                 # second stream.  Measured (one box, captured step): 1 -> 5.25 ms, 2 -> 5.28, 4 -> 5.27, 8 -> 5.42: the replayed
+                                                                                 # graph does not run the GEMMs beside the chain (as the side-stream weight gradients of round 4): default 1
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 STACK_BWD_FUSED = bool(int(_os.environ.get("SYN_TRAIN_STACK_BWD_FUSED", "1")))   # (A/B: 0 = the per-branch backward chain behind the persistent forward)       # (A/B: 0 = one autograd node per residual branch, `AttnBranchFn` / `MlpBranchFn`)
 _stack_ws = {}
 
@@ -746,9 +759,29 @@ class StackFn(torch.autograd.Function):
             keep += [gains, [ten[k] for k in ("dyt_fc2", "dyt_fc1", "dyt_proj", "dyt_qkv", "part")]]
             grads[l * NP:(l + 1) * NP] = [ten["d_ln1_g"], ten["d_ln1_b"], ten["dw_qkv"], ten["dw_proj"], ten["d_proj_b"], ten["d_ln2_g"], ten["d_ln2_b"],
                                           ten["dw_fc1"], ten["d_fc1_b"], ten["dw_fc2"], ten["d_fc2_b"]]
-        st = _lib.current_stream(dev)
-        _lib.check(lib.syn_train_stack_bwd(C.byref(g), st), "syn_train_stack_bwd")
-        _lib.check(lib.syn_train_stack_wgrad(C.byref(g), st), "syn_train_stack_wgrad")
+        # The chain occupies half the chip (32 sequences x 4 workgroups on 256 CUs) and the weight-gradient GEMMs of a block need nothing but that block's
+        # piece of it: the chain goes out in STACK_BWD_PIECES pieces on this stream, and the GEMMs of a finished piece on a second stream beside the next
+        # piece (a fork / join in the captured graph).
+        n_blk = len(params) // NP
+        pieces = max(1, min(STACK_BWD_PIECES, n_blk))
+        per = -(-n_blk // pieces)
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if pieces > 1 else main
+        cur, hi = d, n_blk - 1
+        while hi >= 0:
+            lo = max(0, hi - per + 1)
+            nxt = dh_in if lo == 0 else torch.empty(B, T, 512, dtype=torch.float32, device=dev)
+            g.dh_out, g.dh_in, g.first_block, g.last_block = cur.data_ptr(), nxt.data_ptr(), hi, lo
+            _lib.check(lib.syn_train_stack_bwd(C.byref(g), main.cuda_stream), "syn_train_stack_bwd")
+            if side is not main:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+            _lib.check(lib.syn_train_stack_wgrad(C.byref(g), side.cuda_stream), "syn_train_stack_wgrad")
+            keep.append(cur)
+            cur, hi = nxt, lo - 1
+        if side is not main:
+            main.wait_stream(side)
         del ten, keep                             # (stream-ordered allocator: the launches above are enqueued, later work on this stream comes after them)
         return (dh_in, None, *grads)
 
