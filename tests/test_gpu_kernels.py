@@ -815,3 +815,69 @@ def test_fused_masked_smooth_l1_vs_torch(monkeypatch):
         (loss * wgt).sum().backward()
         res[fused] = (loss.detach().clone(), b.grad.clone())
     assert res[True][0].shape == (6,) and rel_l2(res[True][0], res[False][0]) < 1e-6 and rel_l2(res[True][1], res[False][1]) < 1e-6
+
+
+@pytest.mark.parametrize("B,drop", [(4, False), (12, True), (32, True)])
+def test_persistent_block_stack_forward_backward_vs_torch_fp32(B, drop):
+    """`syn_train_stack_fwd` / `_bwd` / `_wgrad` (training.StackFn: the eight pre-LN blocks of the training forward as one persistent launch, their
+    data-gradient chain as another, the 32 weight-gradient GEMMs four per launch) against a plain PyTorch fp32 restatement of the same blocks
+    (models/timm_transformer/transformer.py:83-104, 145-151, 195-198; DropPath :21-38 with the same factors) and its autograd: output, the gradient
+    of the input and of every parameter.  Tolerance = the sampling kernels' (bf16 GEMM operands, q / k / v / softmax numerators in bf16): 1.5e-2 on the
+    output after eight blocks, 3e-2 per gradient tensor."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from syntalker_amd import training
+    dev = "cuda"
+    torch.manual_seed(100 + B)
+
+    class Blk(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.norm1, self.norm2 = nn.LayerNorm(512), nn.LayerNorm(512)
+            self.qkv, self.proj = nn.Linear(512, 1536, bias=False), nn.Linear(512, 512)
+            self.fc1, self.fc2 = nn.Linear(512, 1024), nn.Linear(1024, 512)
+    blocks = nn.ModuleList([Blk() for _ in range(8)]).to(dev)
+    with torch.no_grad():
+        for p in blocks.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))             # LayerNorm gains / shifts and biases off their initial values
+    h0 = torch.randn(B, 32, 512, device=dev).requires_grad_(True)
+    dp = (torch.empty(16, B, 1, 1, device=dev).bernoulli_(0.8).div_(0.8)) if drop else None
+    up = torch.randn(B, 32, 512, device=dev)
+
+    def reference(h):
+        for i, b in enumerate(blocks):
+            z = F.layer_norm(h, (512,), b.norm1.weight, b.norm1.bias, 1e-5)
+            q, k, v = b.qkv(z).reshape(B, 32, 3, 4, 128).permute(2, 0, 3, 1, 4)
+            o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, 32, 512)
+            br = b.proj(o)
+            h = h + (br if dp is None else br * dp[2 * i])
+            z = F.layer_norm(h, (512,), b.norm2.weight, b.norm2.bias, 1e-5)
+            br = b.fc2(F.gelu(b.fc1(z)))
+            h = h + (br if dp is None else br * dp[2 * i + 1])
+        return h
+    want = reference(h0)
+    want.backward(up)
+    ref = {n: p.grad.clone() for n, p in blocks.named_parameters()}
+    ref_h = h0.grad.clone()
+    blocks.zero_grad()
+    h0.grad = None
+    # the step's weight packs, as train_forward prepares them
+    pk = training.WeightPacks([m.weight for m in blocks.modules() if isinstance(m, nn.Linear)])
+    pk.refresh()
+    keep = training._packs_blocks
+    training._packs_blocks = pk
+    try:
+        ps = []
+        for b in blocks:
+            ps += [b.norm1.weight, b.norm1.bias, b.qkv.weight, b.proj.weight, b.proj.bias, b.norm2.weight, b.norm2.bias, b.fc1.weight, b.fc1.bias,
+                   b.fc2.weight, b.fc2.bias]
+        got = training.StackFn.apply(h0, dp, *ps)
+        e_out = rel_l2(got.detach().cpu(), want.detach().cpu())
+        got.backward(up)
+    finally:
+        training._packs_blocks = keep
+    e_h = rel_l2(h0.grad.cpu(), ref_h.cpu())
+    worst = max(((n, rel_l2(p.grad.cpu(), ref[n].cpu())) for n, p in blocks.named_parameters()), key=lambda v: v[1])
+    print(f"persistent block stack, B = {B}, DropPath {drop}: output rel-L2 {e_out:.2e}, input gradient {e_h:.2e}, worst parameter gradient {worst[1]:.2e} ({worst[0]})")
+    assert e_out < 1.5e-2 and e_h < 3e-2 and worst[1] < 3e-2
