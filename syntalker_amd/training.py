@@ -89,13 +89,25 @@ class WeightPacks:
         self.items = {}
         jobs, self.max_frag = [], 0
         dev = None
+        # two arenas - all forward sets, all transposed sets - so that either can be pulled into the memory-side cache with one pass (`prefetch`)
+        ok = [w for w in weights if w.is_cuda and w.dtype is torch.float32 and w.is_contiguous() and w.dim() == 2]
+        nb_f = sum(w.numel() * 2 for w in ok if w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0)
+        nb_t = sum(w.numel() * 2 for w in ok if w.shape[1] % 512 == 0 and w.shape[0] % 128 == 0)
+        self.arena_fwd = torch.empty(nb_f, dtype=torch.uint8, device=ok[0].device) if ok and nb_f else None
+        self.arena_tr = torch.empty(nb_t, dtype=torch.uint8, device=ok[0].device) if ok and nb_t else None
+        of = ot = 0
         for w in weights:
             if not (w.is_cuda and w.dtype is torch.float32 and w.is_contiguous() and w.dim() == 2) or id(w) in self.items:
                 continue
             dev = w.device
             N, K = w.shape
-            fwd = torch.empty(N * K * 2, dtype=torch.uint8, device=dev) if N % 128 == 0 and K % 128 == 0 else None    # (N % 512 != 0: the 128-column GEMM)
-            tr = torch.empty(N * K * 2, dtype=torch.uint8, device=dev) if K % 512 == 0 and N % 128 == 0 else None
+            fwd = tr = None
+            if N % 128 == 0 and K % 128 == 0:                        # (N % 512 != 0: the 128-column GEMM)
+                fwd = self.arena_fwd[of:of + N * K * 2]
+                of += N * K * 2
+            if K % 512 == 0 and N % 128 == 0:
+                tr = self.arena_tr[ot:ot + N * K * 2]
+                ot += N * K * 2
             if fwd is None and tr is None:
                 continue
             if fwd is not None:
@@ -111,6 +123,15 @@ class WeightPacks:
 
     def valid(self) -> bool:
         return all(r() is not None and r().data_ptr() == ptr for r, ptr, *_ in self.items.values())
+
+    def prefetch(self, transposed: bool):
+        """One read pass over the forward / transposed fragment sets (a byte per 64): whatever has been evicted from the memory-side cache since the
+        pack comes back before a latency-bound consumer asks for it fragment by fragment."""
+        a = self.arena_tr if transposed else self.arena_fwd
+        if a is not None and a.numel() >= 64:
+            n = a.numel() // 64 * 64
+            return a[:n].view(-1, 64)[:, 0].sum(dtype=torch.int32)
+        return None
 
     def refresh(self):
         if not self.n_jobs:
@@ -671,6 +692,7 @@ def _side_stream(device):
     return s
 
 
+STACK_BWD_PREFETCH = bool(int(_os.environ.get("SYN_TRAIN_STACK_BWD_PREFETCH", "1")))
 STACK_BWD_FUSED = bool(int(_os.environ.get("SYN_TRAIN_STACK_BWD_FUSED", "1")))   # (A/B: 0 = the per-branch backward chain behind the persistent forward)       # (A/B: 0 = one autograd node per residual branch, `AttnBranchFn` / `MlpBranchFn`)
 _stack_ws = {}
 
@@ -759,6 +781,8 @@ class StackFn(torch.autograd.Function):
             keep += [gains, [ten[k] for k in ("dyt_fc2", "dyt_fc1", "dyt_proj", "dyt_qkv", "part")]]
             grads[l * NP:(l + 1) * NP] = [ten["d_ln1_g"], ten["d_ln1_b"], ten["dw_qkv"], ten["dw_proj"], ten["d_proj_b"], ten["d_ln2_g"], ten["d_ln2_b"],
                                           ten["dw_fc1"], ten["d_fc1_b"], ten["dw_fc2"], ten["d_fc2_b"]]
+        if STACK_BWD_PREFETCH and _packs_blocks is not None:
+            ctx_pf = _packs_blocks.prefetch(True)              # (the transposed sets were packed in front of the forward; 150 MB of saved tensors went by since)
         # The chain occupies half the chip (32 sequences x 4 workgroups on 256 CUs) and the weight-gradient GEMMs of a block need nothing but that block's
         # piece of it: the chain goes out in STACK_BWD_PIECES pieces on this stream, and the GEMMs of a finished piece on a second stream beside the next
         # piece (a fork / join in the captured graph).
