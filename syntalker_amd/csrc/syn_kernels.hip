@@ -1949,14 +1949,15 @@ int launch_stack(const SArgs& a, int mt, hipStream_t s) {
     }
     dim3 grid((a.M + mt - 1) / mt), block(kThreads);
     if (a.tp > 1) {
-        if (mt != 32 || !a.sync || !a.xch) return fail_msg("stack: the tensor-parallel mode needs 32-row tiles, ws_sync and ws_xch");
+        if (!(mt == 32 || (mt == 64 && a.tp == 2)) || !a.sync || !a.xch) return fail_msg("stack: the tile-split mode needs 32-row tiles (or 64-row tiles split in two), ws_sync and ws_xch");
         grid.x = lat::kGroups * a.tp * ((a.tp_tiles + lat::kGroups - 1) / lat::kGroups);    // whole groups on every XCD
         if (grid.x > 256) return fail_msg("stack: the tensor-parallel mode needs all its workgroups resident (<= 256)");
     }
     if (a.tp > 1) {
         static OncePerDevice once_tp;
-        if (once_tp.first()) { allow_lds(k_stack<32, 2>, 32 * 2048 + 4096); allow_lds(k_stack<32, 4>, 32 * 2048 + 4096); }
-        if (a.tp == 4) hipLaunchKernelGGL((k_stack<32, 4>), grid, block, 32 * 2048 + 4096, s, a);
+        if (once_tp.first()) { allow_lds(k_stack<32, 2>, 32 * 2048 + 4096); allow_lds(k_stack<32, 4>, 32 * 2048 + 4096); allow_lds(k_stack<64, 2>, 64 * 2048 + 4096); }
+        if (mt == 64) hipLaunchKernelGGL((k_stack<64, 2>), grid, block, 64 * 2048 + 4096, s, a);
+        else if (a.tp == 4) hipLaunchKernelGGL((k_stack<32, 4>), grid, block, 32 * 2048 + 4096, s, a);
         else if (a.tp == 2) hipLaunchKernelGGL((k_stack<32, 2>), grid, block, 32 * 2048 + 4096, s, a);
         else return fail_msg("stack: tile split over 2 or 4 workgroups only");
         hipError_t e = hipGetLastError();
@@ -3459,8 +3460,14 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     // 32-row tile split over 4 (<= 64 sequences) or 2 workgroups of one XCD, see k_stack.  reserved bit 3 (value 8)
     // switches it off, and so does pinning a kernel (bit 2) or a tile size.
     const int tiles = V * B;
+    // 129..256 sequences as 64-row tiles (two sequences) split over 2 workgroups - 256 workgroups at 256 sequences, each streaming HALF the weight set for
+    // twice the rows of the one-tile-per-CU form - was measured in round 5 and is SLOWER (SYN_STACK64_TP=1; one box: 130 / 160 / 192 / 224 / 256 sequences
+    // 417 / 428 / 446 / 482 / 526 us per step against 401 / 406 / 415 / 426 / 448 us of one 32-row tile per CU): the 64-row instance lives at 256 registers and
+    // 130 KB of LDS and adds 16 exchanges of 128 KB partials per member.  Off by default.
+    static const bool tp64 = getenv("SYN_STACK64_TP") != nullptr && atoi(getenv("SYN_STACK64_TP")) != 0;
     const bool use_tp = mode == 0 && st->m_tile == 0 && !(st->reserved & 12) && st->ws_sync && st->ws_xch &&
-                        tiles >= 9 && tiles <= 128 && latency_path_ok();
+                        tiles >= 9 && tiles <= (tp64 ? 256 : 128) && latency_path_ok();
+    const bool tp_wide = use_tp && tiles > 128;
     if (mode == 0 && !use_tp && !(st->reserved & 4) && st->ws_sync && per_group <= 4 && latency_path_ok()) mode = 3;
     if (mode == 3) {
         // small-batch path: one persistent kernel, output features split over the CUs of an XCD
@@ -3525,7 +3532,7 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
         int tile_rows = mt > 64 ? 64 : mt;
         sa.tp = 1;
         if (use_tp) {
-            sa.tp = tiles <= 64 ? 4 : 2; sa.tp_tiles = tiles; sa.sync = st->ws_sync; sa.xch = st->ws_xch; tile_rows = 32;
+            sa.tp = tiles <= 64 ? 4 : 2; sa.tp_tiles = tp_wide ? (tiles + 1) / 2 : tiles; sa.sync = st->ws_sync; sa.xch = st->ws_xch; tile_rows = tp_wide ? 64 : 32;
         }
         if ((rc = launch_stack(sa, tile_rows, s))) return rc;
         mark(ST_FC2);

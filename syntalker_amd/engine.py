@@ -149,7 +149,7 @@ class StepBuffers:
         self.x0v = e(R, CH) if (V > 1 and B * V <= 32) else None
         s.ws_x0v = _lib.ptr(self.x0v)
         # 9..128 sequences: exchange slots for the whole-step kernel's tensor-parallel mode (a tile split over 2 / 4 CUs)
-        self.xch = e(V * B, 8, 32 * D) if 8 < V * B <= 128 else None
+        self.xch = e(V * B + 1, 8, 32 * D) if 8 < V * B <= 256 else None      # (129..256 sequences: 64-row tiles split in two, the same bytes per sequence)
         s.ws_xch = _lib.ptr(self.xch)
         s.x_fragment_order = int(self.fragment)
         self.c = s
