@@ -545,7 +545,7 @@ int syn_vq_codes(const int32_t* idx, const float* codebooks, float* q_f32, void*
  * and output).  The same entry point serves the backward passes with re-packed operands:
  *   dgrad  dx = dy . W      -> x := dy (m x n_out),   w_packed := pack(W^T)   (n_in x n_out)
  *   wgrad  dW = dy^T . x    -> x := dy^T (n_out x m), w_packed := pack(x^T)   (n_in x m)
- * n % 512 == 0, k % 128 == 0 (callers zero-pad).  Replaces torch.nn.functional.linear for
+ * n % 128 == 0, k % 128 == 0 (callers zero-pad; n % 512 != 0 runs on the 128-column tiles, ABI 7).  Replaces torch.nn.functional.linear for
  * models/timm_transformer/transformer.py:85,102,146,149 and models/denoiser.py:148,162,170,195 in training. */
 int syn_linear(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k, float* y,
                void* stream);
