@@ -2025,8 +2025,8 @@ static inline int conv_terms(bool wgrad) { return g_conv_terms >= 0 ? g_conv_ter
 
 template <int CINP, int KT, int RF>
 int launch_conv_train_ks(const wav::TArgs& a0, int n_clips, hipStream_t s) {
-    wav::TArgs a = a0; a.terms = conv_terms(false);
-    constexpr int MW = RF * 16, lds = 2 * (MW + KT - 1) * (CINP * 2 + 16);
+    wav::TArgs a = a0; a.terms = conv_terms(false); a.dbg = nullptr;
+    constexpr int MW = RF * 16, lds = 2 * (MW + KT - 1) * (CINP * 2 + wav::kTrainPad);
     static_assert(lds <= 160 * 1024, "two bf16 planes of the input tile must fit the LDS");
     static OncePerDevice once;
     if (once.first()) { allow_lds(wav::k_conv_train_ks<CINP, KT, RF>, lds); }
@@ -2035,14 +2035,16 @@ int launch_conv_train_ks(const wav::TArgs& a0, int n_clips, hipStream_t s) {
     return e == hipSuccess ? 0 : fail("k_conv_train_ks launch", e);
 }
 
-template <int CINP, int KT, int WN, int WM, int RF>
-int launch_conv_train(const wav::TArgs& a0, int n_clips, hipStream_t s) {
-    wav::TArgs a = a0; a.terms = conv_terms(false);
-    constexpr int MW = WM * RF * 16, lds = 2 * (MW + KT - 1) * (CINP * 2 + 16);
+// n_out: output channels this launch covers (a multiple of the instance's WN x NF x 16 channels per workgroup: grid z)
+template <int CINP, int KT, int WN, int WM, int RF, int NF = 4>
+int launch_conv_train(const wav::TArgs& a0, int n_clips, hipStream_t s, int n_out = WN * NF * 16) {
+    wav::TArgs a = a0; a.terms = conv_terms(false); a.dbg = g_dbg_attn;
+    constexpr int MW = WM * RF * 16, lds = 2 * (MW + KT - 1) * (CINP * 2 + wav::kTrainPad), NT = WN * NF * 16;
     static_assert(lds <= 160 * 1024, "two bf16 planes of the input tile must fit the LDS");
+    if (n_out % NT) return fail_msg("k_conv_train: the launch's channels are not a multiple of the instance's channel block");
     static OncePerDevice once;
-    if (once.first()) { allow_lds(wav::k_conv_train<CINP, KT, WN, WM, RF>, lds); }
-    hipLaunchKernelGGL((wav::k_conv_train<CINP, KT, WN, WM, RF>), dim3((a.L_out + MW - 1) / MW, n_clips), dim3(WN * WM * 64), lds, s, a);
+    if (once.first()) { allow_lds(wav::k_conv_train<CINP, KT, WN, WM, RF, NF>, lds); }
+    hipLaunchKernelGGL((wav::k_conv_train<CINP, KT, WN, WM, RF, NF>), dim3((a.L_out + MW - 1) / MW, n_clips, n_out / NT), dim3(WN * WM * 64), lds, s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_train launch", e);
 }
@@ -3249,6 +3251,8 @@ int64_t syn_conv1d_pack_bytes(int32_t cout, int32_t cin, int32_t stride, int32_t
     return (int64_t)cout * kts * cin * 2;
 }
 
+static int conv_variant(int cls);
+
 // Data gradient of a strided, unpadded Conv1d(k = 15) of the encoder: dx [n][l_in][cin] from dy [n][l_out][cout] - a stride-1
 // convolution over dy whose output rows are stride consecutive positions x cin channels; three launches of 128 columns each.
 static int dgrad_strided_impl(const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t cout,
@@ -3258,7 +3262,9 @@ static int dgrad_strided_impl(const float* dy, int32_t n_clips, int32_t l_in, in
     const int l_out = (l_in - 15) / stride + 1, kt = dgrad_taps(stride, cout), q_rows = (l_in + stride - 1) / stride, np = stride * cin;
     if (np % 128) return fail_msg("syn_conv1d_train_dgrad_strided: stride * cin must be a multiple of 128");
     hipStream_t s = (hipStream_t)stream;
-    for (int c0 = 0; c0 < np; c0 += 128) {
+    const int cls = cout == 64 ? 6 : cout == 128 ? 7 : 8;
+    const bool one_launch = conv_variant(cls) != 0;          // all stride x cin columns in one launch, 64 per workgroup (grid z)
+    for (int c0 = 0; c0 < np; c0 += one_launch ? np : 128) {
         wav::TArgs a;
         a.X = dy; a.x_clip_stride = (long)l_out * cout; a.x_elems = (long)l_out * cout; a.row0 = -(kt - 1); a.L_out = q_rows;
         const size_t frag0 = (size_t)(c0 / 16) * (kt * cout / 32) * 64;
@@ -3267,7 +3273,10 @@ static int dgrad_strided_impl(const float* dy, int32_t n_clips, int32_t l_in, in
         a.in_aff = nullptr; a.in_act = 0; a.R = nullptr;
         a.X2 = dy2; a.Whi2 = dy2 ? (const uint4*)w2_hi + frag0 : nullptr; a.Wlo2 = dy2 ? (const uint4*)w2_lo + frag0 : nullptr;
         int rc;
-        if (cout == 64 && kt == 3) rc = launch_conv_train<64, 3, 2, 2, 4>(a, n_clips, s);
+        if (one_launch && cout == 64 && kt == 3) rc = conv_variant(cls) == 1 ? launch_conv_train<64, 3, 4, 1, 8, 1>(a, n_clips, s, np) : launch_conv_train<64, 3, 4, 1, 4, 1>(a, n_clips, s, np);
+        else if (one_launch && cout == 128 && kt == 3) rc = conv_variant(cls) == 1 ? launch_conv_train<128, 3, 4, 1, 4, 1>(a, n_clips, s, np) : launch_conv_train<128, 3, 4, 1, 2, 1>(a, n_clips, s, np);
+        else if (one_launch && cout == 256 && kt == 6) rc = conv_variant(cls) == 1 ? launch_conv_train<256, 6, 4, 1, 3, 1>(a, n_clips, s, np) : launch_conv_train<256, 6, 4, 1, 2, 1>(a, n_clips, s, np);
+        else if (cout == 64 && kt == 3) rc = launch_conv_train<64, 3, 2, 2, 4>(a, n_clips, s);
         // (a launch covers 128 of the stride x cin columns: tiles halved while it would not fill the chip twice - 32 clips: 45 -> 30 us and
         // 76 -> 53 us for the three launches of the 128- / 256-channel layers)
         else if (cout == 128 && kt == 3) rc = (long)n_clips * ((q_rows + 127) / 128) >= 2 * device_cus() ? launch_conv_train<128, 3, 2, 2, 4>(a, n_clips, s)
@@ -3289,19 +3298,37 @@ int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_i
 // one's staging overlaps the other's MFMA phase (4 = 64 positions, 103 KB: one workgroup per CU)
 constexpr int kKsRf = 3;
 // positions per workgroup tile of syn_conv1d_train_fwd's kernel instance (0: not one of the encoder's layers)
+// decomposition of a layer class (diagnostics: SYN_CV = one digit per class - 0: 64x1->64, 1: 128x1->128, 2: 256x1->256, 3: 64x6->64, 4: 64x6->128,
+// 5: 128x3->256, 6 - 8: the strided data gradients of 3 - 5; digit 0 = the first version, 64 channels per wave)
+static int conv_variant(int cls) {
+    static int v[16] = {-1};
+    if (v[0] < 0) {
+        static const int dflt[16] = {1, 1, 2, 0, 0, 1, 1, 1, 2};
+        const char* e = getenv("SYN_CV");
+        const size_t n = e ? strlen(e) : 0;
+        for (int i = 15; i >= 0; --i) v[i] = (size_t)i < n && e[i] >= '0' && e[i] <= '9' ? e[i] - '0' : dflt[i];
+    }
+    return v[cls];
+}
 static int conv_train_tile(int cinp, int stride, int cout, int n_clips, int l_out) {
+    if (cinp == 384 && stride == 6 && cout == 64 && conv_variant(3)) return conv_variant(3) == 1 ? 32 : 64;
     if (cinp == 384 && stride == 6 && cout == 64 && !getenv("SYN_CONV_POS_SPLIT")) return 16 * kKsRf;
     const bool small = getenv("SYN_CONV_BIG_TILES") == nullptr;           // (diagnostics: the large tiles everywhere)
-    if (cinp == 64 && stride == 1 && cout == 64) return small && (long)n_clips * ((l_out + 255) / 256) < 2 * device_cus() ? 128 : 256;
-    if (cinp == 128 && stride == 1 && cout == 128) return small && (long)n_clips * ((l_out + 127) / 128) < 2 * device_cus() ? 64 : 128;
+    // (r5b: 224 positions - two planes of 238 rows x 160 B = 76 KB, two workgroups per CU with the 32-byte row padding)
+    if (cinp == 64 && stride == 1 && cout == 64) return small && (long)n_clips * ((l_out + 255) / 256) < 2 * device_cus() ? 128 : conv_variant(0) ? 224 : 256;
+    if (cinp == 128 && stride == 1 && cout == 128) return conv_variant(1) ? 64 : small && (long)n_clips * ((l_out + 127) / 128) < 2 * device_cus() ? 64 : 128;
     if (cinp == 256 && stride == 1 && cout == 256) {         // (32 clips x 128 positions: 155 us for forward + data gradient on 64-position tiles, 137 / 113 / 102 on 48 / 32 / 16)
+        if (conv_variant(2)) return conv_variant(2) == 2 ? 32 : 64;
         if (!small) return 48;
         for (int mw = 48; mw > 16; mw -= 16)
             if ((long)n_clips * ((l_out + mw - 1) / mw) >= 2 * device_cus()) return mw;
         return 16;
     }
-    if (cinp == 384 && stride == 6) return 64;
-    if (cinp == 384 && stride == 3) return small && (long)n_clips * ((l_out + 31) / 32) < 2 * device_cus() ? 16 : 32;
+    if (cinp == 384 && stride == 6) return conv_variant(4) == 1 ? 32 : 64;
+    if (cinp == 384 && stride == 3) {
+        if (conv_variant(5)) return conv_variant(5) == 1 ? 32 : 16;
+        return small && (long)n_clips * ((l_out + 31) / 32) < 2 * device_cus() ? 16 : 32;
+    }
     return 0;
 }
 
@@ -3331,21 +3358,42 @@ static int conv_train_fwd_impl(const float* x, int32_t n_clips, int32_t l_in, in
     // (rows of stride * cin floats, ceil(15 / stride) taps; tiles as the eval-mode encoder picks them, halved where two planes
     // of a 384-channel tile would not fit the LDS)
     // (short layers: smaller tiles, so that the launch still fills the chip and the last tile of a clip wastes less)
-    if (cinp == 64 && stride == 1 && cout == 64)
-        return conv_train_tile(cinp, stride, cout, n_clips, l_out) == 256 ? launch_conv_train<64, 15, 1, 4, 4>(a, n_clips, s)
-                                                                          : launch_conv_train<64, 15, 1, 4, 2>(a, n_clips, s);
-    if (cinp == 128 && stride == 1 && cout == 128)
+    if (cinp == 64 && stride == 1 && cout == 64) {
+        const bool big = conv_train_tile(cinp, stride, cout, n_clips, l_out) > 128;
+        switch (conv_variant(0)) {
+        case 1: return big ? launch_conv_train<64, 15, 2, 2, 7, 2>(a, n_clips, s, 64) : launch_conv_train<64, 15, 2, 2, 4, 2>(a, n_clips, s, 64);   // 32 channels x 112 / 64 positions per wave
+        case 2: return big ? launch_conv_train<64, 15, 4, 1, 14, 1>(a, n_clips, s, 64) : launch_conv_train<64, 15, 4, 1, 8, 1>(a, n_clips, s, 64);  // 16 channels x 224 / 128 positions per wave
+        default: return big ? launch_conv_train<64, 15, 1, 4, 4>(a, n_clips, s) : launch_conv_train<64, 15, 1, 4, 2>(a, n_clips, s);
+        }
+    }
+    if (cinp == 128 && stride == 1 && cout == 128) {
+        switch (conv_variant(1)) {
+        case 1: return launch_conv_train<128, 15, 4, 1, 4, 1>(a, n_clips, s, 128);      // 64 positions x 64 channels per workgroup (z: 2), a wave: 16 channels x 64 positions
+        case 2: return launch_conv_train<128, 15, 4, 1, 4, 2>(a, n_clips, s, 128);      // 64 positions x 128 channels per workgroup, a wave: 32 channels x 64 positions
+        default: break;
+        }
         return conv_train_tile(cinp, stride, cout, n_clips, l_out) == 128 ? launch_conv_train<128, 15, 2, 2, 4>(a, n_clips, s)
                                                                           : launch_conv_train<128, 15, 2, 2, 2>(a, n_clips, s);
+    }
     if (cinp == 256 && stride == 1 && cout == 256) {
+        if (conv_variant(2) == 1) return launch_conv_train<256, 15, 4, 1, 4, 1>(a, n_clips, s, 256);   // 64 positions x 64 channels per workgroup (z: 4)
+        if (conv_variant(2) == 2) return launch_conv_train<256, 15, 4, 1, 2, 1>(a, n_clips, s, 256);   // 32 positions x 64 channels
         const int mw = conv_train_tile(cinp, stride, cout, n_clips, l_out);
         return mw == 48 ? launch_conv_train<256, 15, 4, 1, 3>(a, n_clips, s)                                       // (48 positions: 65 KB, two workgroups per CU)
              : mw == 32 ? launch_conv_train<256, 15, 4, 1, 2>(a, n_clips, s) : launch_conv_train<256, 15, 4, 1, 1>(a, n_clips, s);
     }
     static const bool pos_split = getenv("SYN_CONV_POS_SPLIT") != nullptr;      // diagnostics: the waves split positions (the first version)
+    if (cinp == 384 && stride == 6 && cout == 64 && conv_variant(3))
+        return conv_variant(3) == 1 ? launch_conv_train<384, 3, 4, 1, 2, 1>(a, n_clips, s, 64) : launch_conv_train<384, 3, 4, 1, 4, 1>(a, n_clips, s, 64);   // a wave: 16 channels x 32 / 64 positions
     if (cinp == 384 && stride == 6 && cout == 64)
         return pos_split ? launch_conv_train<384, 3, 1, 4, 1>(a, n_clips, s) : launch_conv_train_ks<384, 3, kKsRf>(a, n_clips, s);
-    if (cinp == 384 && stride == 6 && cout == 128) return launch_conv_train<384, 3, 2, 2, 2>(a, n_clips, s);   // (32-position tiles, three workgroups per CU: 27 -> 30 us)
+    if (cinp == 384 && stride == 6 && cout == 128) {
+        if (conv_variant(4) == 1) return launch_conv_train<384, 3, 4, 1, 2, 1>(a, n_clips, s, 128);   // 32 positions x 64 channels per workgroup (z: 2)
+        if (conv_variant(4) == 2) return launch_conv_train<384, 3, 4, 1, 4, 1>(a, n_clips, s, 128);   // 64 positions x 64 channels
+        return launch_conv_train<384, 3, 2, 2, 2>(a, n_clips, s);   // (32-position tiles, three workgroups per CU: 27 -> 30 us)
+    }
+    if (cinp == 384 && stride == 3 && cout == 256 && conv_variant(5))
+        return conv_variant(5) == 1 ? launch_conv_train<384, 5, 4, 1, 2, 1>(a, n_clips, s, 256) : launch_conv_train<384, 5, 4, 1, 1, 1>(a, n_clips, s, 256);   // 32 / 16 positions x 64 channels (z: 4)
     if (cinp == 384 && stride == 3 && cout == 256)
         return conv_train_tile(cinp, stride, cout, n_clips, l_out) == 32 ? launch_conv_train<384, 5, 4, 1, 2>(a, n_clips, s)
                                                                          : launch_conv_train<384, 5, 4, 1, 1>(a, n_clips, s);
