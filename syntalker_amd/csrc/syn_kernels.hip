@@ -2051,7 +2051,7 @@ int launch_conv_train(const wav::TArgs& a0, int n_clips, hipStream_t s, int n_ou
 
 template <int CO_T, int TAPS>
 int launch_wgrad_s(const wav::WArgs& a0, hipStream_t s) {
-    wav::WArgs a = a0; a.terms = conv_terms(true);
+    wav::WArgs a = a0; a.terms = conv_terms(true); a.dbg = nullptr;
     static_assert(wav::wgrad_s_lds(CO_T) <= 160 * 1024, "dy and x' tiles must fit the LDS");
     static OncePerDevice once;
     if (once.first()) { allow_lds(wav::k_conv_wgrad_s<CO_T, TAPS>, wav::wgrad_s_lds(CO_T)); }
@@ -2062,7 +2062,7 @@ int launch_wgrad_s(const wav::WArgs& a0, hipStream_t s) {
 
 template <int CO, int TAPS>
 int launch_wgrad(const wav::WArgs& a0, hipStream_t s) {
-    wav::WArgs a = a0; a.terms = conv_terms(true);
+    wav::WArgs a = a0; a.terms = conv_terms(true); a.dbg = g_dbg_attn;
     static OncePerDevice once;
     constexpr int CB = wav::wgrad_cb(CO);
     if (once.first()) { allow_lds(wav::k_conv_wgrad<CO, TAPS, CB>, wav::wgrad_lds(CO)); }
