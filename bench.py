@@ -374,6 +374,7 @@ def run_train(args, rank, local, world, dev, dist):
     dt = timed_region(step, K, W, world, dist, torch.cuda.synchronize)
     loss = float(last["loss"])
     assert loss == loss, "non-finite training loss"
+    direct = training.direct_grad_report(model) if ddp else None   # gradients the backward wrote straight into the reducer's buckets
     # forward / backward / clip+Adam split of one EAGER step (hipEvents on the current stream; rank 0 only reports it).  After a captured
     # run the same three eager steps follow the timed region: issued from Python the step is host-bound, so these are upper bounds of the
     # device time of each part (the rocprofv3 kernel-time split of the replayed step is profiles/r04_train_step_split.txt)
@@ -410,7 +411,8 @@ def run_train(args, rank, local, world, dev, dist):
                                    "clip 0.99, Adam 5e-5 (0.5, 0.999), MDM denoiser 8x512 + trained WavEncoder, random-init",
                        "clips_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"dp{world}: one process per GPU, DDP bucketed all-reduce of 29.6 M gradients over RCCL" if ddp else "single GPU",
-                       "graph_replayed": graph, "ddp_wrapper": ddp, **({"graph_fallback": fallback} if fallback else {})},
+                       "graph_replayed": graph, "ddp_wrapper": ddp, **({"graph_fallback": fallback} if fallback else {}),
+                       **({"gradients_written_into_buckets": {"direct": direct[0], "bound": direct[1], "copied_by_the_reducer": direct[2][:24]}} if direct else {})},
             "loss": round(loss, 5), "step_split": split,
             "roofline": {"bound": "mfma", "achieved": round(value / world * F_TRAIN / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(value / world * F_TRAIN / PEAK_BF16, 4), "traffic": None,
