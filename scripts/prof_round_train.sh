@@ -5,7 +5,7 @@ set -u
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out/r05
 timeout 300 scripts/prof_stats.sh train --mode train --steps 100 --warmup 10 > /dev/null 2>&1
-python scripts/summarize_stats.py gpurun_out/prof_train/kernel_stats.csv gpurun_out/r05/train_kernel_stats.txt "r05: bench.py --mode train --steps 100 --warmup 10 (captured step replayed 110 times + 3 eager warm-up + 3 eager split steps: 116 steps; divide calls by 116)"
+python scripts/summarize_stats.py gpurun_out/prof_train/kernel_stats.csv gpurun_out/r05/train_kernel_stats.txt "r05b: bench.py --mode train --steps 100 --warmup 10 (captured step replayed 110 times + 3 eager warm-up + 3 eager split steps: 116 steps; divide calls by 116)"
 cp gpurun_out/prof_train/bench.json gpurun_out/r05/bench_train.json
 { echo "# scripts/prof_train_steady.py 32 90 (torch.profiler, device activities, 5 eager steps after warm-up; round 5 HEAD): device time per kernel of one training step at 32 clips"; python scripts/prof_train_steady.py 32 90 2>&1 | grep -v -i "warn\|amdgpu"; } > gpurun_out/r05/train_step_split.txt
 python bench.py --steps 20 --warmup 5 > gpurun_out/r05/bench_default.json 2> gpurun_out/r05/bench_default.err
