@@ -881,3 +881,24 @@ def test_persistent_block_stack_forward_backward_vs_torch_fp32(B, drop):
     worst = max(((n, rel_l2(p.grad.cpu(), ref[n].cpu())) for n, p in blocks.named_parameters()), key=lambda v: v[1])
     print(f"persistent block stack, B = {B}, DropPath {drop}: output rel-L2 {e_out:.2e}, input gradient {e_h:.2e}, worst parameter gradient {worst[1]:.2e} ({worst[0]})")
     assert e_out < 1.5e-2 and e_h < 3e-2 and worst[1] < 3e-2
+
+
+@pytest.mark.parametrize("cv", ["", "000000000", "222222222"])
+def test_training_convolution_decompositions_at_the_bench_shapes(cv):
+    """Every decomposition of the training-mode convolutions (`SYN_CV`, one digit per layer class: '' = the library's choice, 0 = 64 channels per wave -
+    the first version - and the alternative channel / position splits) at the bench shapes (32 clips: the 224-position tiles, the channel blocks on grid z,
+    the one-launch strided data gradients), forward with its BatchNorm partial sums and data gradient against torch's fp32 convolution.
+    `scripts/ubench_conv_variants.py` in a child process (the variant is read once per process)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SYN_CV=cv)
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "ubench_conv_variants.py"), "32"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [l for l in out.stdout.splitlines() if " fwd " in l]
+    assert len(rows) == 7, out.stdout
+    for l in rows:
+        f, s, q, d = (float(v) for v in re.search(r"\(rel ([\d.e+-]+), sums ([\d.e+-]+) / ([\d.e+-]+)\).*\(rel ([\d.e+-]+)\)", l).groups())
+        assert f < 2e-5 and d < 2e-5 and s < 1e-3 and q < 1e-4, l
