@@ -3048,8 +3048,9 @@ int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows
     int shares = strided ? device_cus() / blocks : (device_cus() + blocks - 1) / blocks;   // one workgroup per CU in total (the partial sums are read back once per share)
     if (shares > chunks) shares = chunks;
     // every share writes a partial sum of the whole gradient block and k_conv_wgrad_sum reads them all back: with few chunks per
-    // share that traffic outweighs the parallelism (time ~ chunks / shares x t_chunk + shares x t_partial, t_chunk / t_partial ~ 21)
-    const int balanced = (int)sqrtf(21.f * (float)chunks);
+    // share that traffic outweighs the parallelism (time ~ chunks / shares x t_chunk + shares x t_partial, t_chunk / t_partial ~ 60)
+    // (r5b: 21 -> 60 - the chunk got 1.4 x faster (streamed x rows), the partial sums did not: 608 chunks on 112 shares 57 us, on 155 - 220 shares 47 - 48 us)
+    const int balanced = (int)sqrtf(60.f * (float)chunks);
     if (!strided && shares > balanced) shares = balanced;
     return shares < 1 ? 1 : shares;
 }
