@@ -3080,7 +3080,7 @@ static int conv_train_wgrad_impl(const float* x, const float* dy, int32_t n_clip
     else return fail_msg("syn_conv1d_train_wgrad: 64 / 128 / 256 output channels; strided: (64 | 128, stride 6), (256, stride 3)");
     if (rc) return rc;
     const int total4 = cout * taps * cinp / 4;                   // (cin % 16 == 0: four consecutive channels share r)
-    hipLaunchKernelGGL(wav::k_conv_wgrad_sum, dim3((total4 + 255) / 256), dim3(256), 0, s, (const float*)ws, a.shares, cout, cin, stride, taps, dw);
+    hipLaunchKernelGGL(wav::k_conv_wgrad_sum, dim3((total4 + 31) / 32), dim3(256), 0, s, (const float*)ws, a.shares, cout, cin, stride, taps, dw);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_wgrad_sum launch", e);
 }
