@@ -592,7 +592,10 @@ int syn_test_attention(const void* q, const void* k, const void* vt, int32_t n_s
 /* ---- diagnostics (scripts/diag_*.py, scripts/ubench_*.py, A/B environment switches; never called by the product path in its default configuration:
  * syn_debug_conv_terms is reached from syntalker_amd/training.py only when SYN_CONV_TERMS asks for something other than 3,3,3) ------
  * Process-wide switches of the library, not thread-safe, no status to return.  They replace nothing in the reference. */
-/* per-phase cycle counters of the step kernels: the attention / MLP phases write s_memtime stamps into these device buffers (NULL: off) */
+/* per-phase cycle counters of the step kernels: the attention / MLP phases write s_memtime stamps into these device buffers (NULL: off).
+ * The first buffer also takes the training convolutions' stamps while it is set: k_conv_train 8 slots per workgroup (start, tile staged, barrier passed,
+ * k loop done, end, HW_ID: scripts/diag_conv_phases.py), k_conv_wgrad 8 per workgroup (cycles in the tile stores, in the k loop, in all, chunks:
+ * scripts/diag_wgrad_phases.py) - size it for the launch's workgroups. */
 void syn_debug_timing(long long* attn_buf, long long* mlp_buf);
 /* 16-row plain GEMMs of the training step: 1 (default) = activation block resident in the LDS, 0 = the streaming loop (A/B, bitwise equal) */
 void syn_debug_gemm_resident(int on);
