@@ -468,3 +468,43 @@ def test_rest_of_the_gaussian_diffusion_surface_matches_reference():
         resample.create_named_schedule_sampler("loss-second-moment", d)
     with pytest.raises(AssertionError):
         d.ddim_reverse_sample(toy, x, torch.tensor([0, 1, 2]), model_kwargs={"y": y}, eta=0.5)
+
+
+def test_small_gradients_move_into_bound_bucket_buffers():
+    """training._into_bound_buffers (the DDP-wrapped captured step): rows of the kernels' [3][C] outputs go into the parameters' bound gradient
+    buffers (DDP's bucket views) and the bound tensors are returned in their place - only for parameters that carry a bound buffer, hold no
+    gradient and have not been handed their buffer in this backward; everything else is left as it is.  `direct_grad_report` counts them."""
+    from syntalker_amd import training
+    bn = torch.nn.BatchNorm1d(8)
+    conv = torch.nn.Conv1d(4, 8, 15)
+    other = torch.nn.Parameter(torch.zeros(8))
+    bucket = torch.zeros(24)
+    bn.weight._syn_grad_buf, bn.bias._syn_grad_buf, conv.bias._syn_grad_buf = bucket[0:8], bucket[8:16], bucket[16:24]
+    try:
+        dgb = torch.arange(24, dtype=torch.float32).reshape(3, 8) + 1
+        gw = torch.ones(8, 4, 15)
+        grads = [gw, dgb[2], dgb[0], dgb[1], torch.full((8,), 7.0)]
+        owners = [None, conv.bias, bn.weight, bn.bias, other]          # (the weight gradient is written in place by its kernel: no owner here)
+        with torch.no_grad():
+            training._into_bound_buffers(grads, owners)
+        assert grads[0] is gw and torch.equal(grads[4], torch.full((8,), 7.0))                       # untouched
+        assert grads[2].data_ptr() == bucket[0:8].data_ptr() and grads[3].data_ptr() == bucket[8:16].data_ptr()
+        assert grads[1].data_ptr() == bucket[16:24].data_ptr()
+        assert torch.equal(bucket, torch.cat([dgb[0], dgb[1], dgb[2]]))
+        m = torch.nn.ModuleList([bn, conv])
+        direct, bound, rest = training.direct_grad_report(m)
+        assert (direct, bound, rest) == (3, 3, [])
+        # a second request in the same backward gets a fresh tensor, and the bucket is not written again
+        grads2 = [dgb[0] * 2]
+        with torch.no_grad():
+            training._into_bound_buffers(grads2, [bn.weight])
+        assert grads2[0].data_ptr() != bucket[0:8].data_ptr() and torch.equal(bucket[0:8], dgb[0])
+        training._reset_handed(m)
+        # a parameter that still holds a gradient keeps the autograd default (accumulation), not its bound buffer
+        bn.weight.grad = torch.zeros(8)
+        grads3 = [dgb[0] * 3]
+        with torch.no_grad():
+            training._into_bound_buffers(grads3, [bn.weight])
+        assert grads3[0].data_ptr() != bucket[0:8].data_ptr() and torch.equal(bucket[0:8], dgb[0])
+    finally:
+        training.unbind_grad_buffers(torch.nn.ModuleList([bn, conv]))
