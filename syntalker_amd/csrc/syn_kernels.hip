@@ -3096,7 +3096,17 @@ int syn_conv1d_train_wgrad_norm(const float* x, const float* dy, int32_t n_clips
     return conv_train_wgrad_impl(x, dy, n_clips, l_in, cin, stride, pad, cout, in_affine, in_act, ws, dw, stream);
 }
 
-int32_t syn_conv1d_first_parts(int32_t n_clips, int32_t l_out) { return n_clips * ((l_out + wav::kF1Chunk - 1) / wav::kF1Chunk); }
+// workgroups of the persistent first-layer weight gradient (k_conv_first_wgrad_m): four per CU once there is that much work, never more than there are
+// 64-pair work items per workgroup
+static int first_wgrad_groups(int n_clips, int l_out) {
+    const long pairs = (long)n_clips * ((l_out + 1) / 2);
+    const long want = 4L * device_cus(), by_work = (pairs + 255) / 256;      // (1 / 2 / 4 / 8 per CU at the bench shape: 190 / 123 / 108 / 107 us for the two launches)
+    return (int)(by_work < 1 ? 1 : by_work < want ? by_work : want);
+}
+int32_t syn_conv1d_first_parts(int32_t n_clips, int32_t l_out) {
+    const int chunks = n_clips * ((l_out + wav::kF1Chunk - 1) / wav::kF1Chunk), groups = first_wgrad_groups(n_clips, l_out);
+    return chunks > groups ? chunks : groups;                 // (partial sums: whichever of the kernels runs fits)
+}
 int32_t syn_conv1d_first_tiles(int32_t n_clips, int32_t l_out) { return n_clips > 0 && l_out > 0 ? n_clips * ((l_out + wav::kF1Tile - 1) / wav::kF1Tile) : 0; }
 
 static int first_layer_args(wav::FArgs& a, const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, const char* who) {
@@ -3139,13 +3149,23 @@ static int first_wgrad_impl(const float* x, const float* dy, const float* bn_y, 
         if (stride != 5 || !bn_stats || !bn_aff || !bn_dgb) return fail_msg("syn_conv1d_first_wgrad_bn: stride 5 (the encoder's), statistics, affine and dgamma / dbeta");
         a.BY = bn_y; a.bn_stats = bn_stats; a.bn_aff = bn_aff; a.bn_dgb = bn_dgb; a.bn_inv_rows = 1.0f / ((float)n_clips * (float)a.L_out); a.bn_act = bn_act;
     }
+    hipStream_t s = (hipStream_t)stream;
+    static const bool stream_mfma = getenv("SYN_FIRST_WGRAD_FMA") == nullptr;  // (A/B: the fp32-FMA kernels below)
+    if (stream_mfma) {
+        const int groups = first_wgrad_groups(n_clips, a.L_out);
+        if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_wgrad_m<1>, dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
+        else hipLaunchKernelGGL(wav::k_conv_first_wgrad_m<2>, dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
+        const int n = 64 * cin * 15;
+        hipLaunchKernelGGL(wav::k_conv_first_wsum, dim3((n + 63) / 64), dim3(1024), 0, s, (const float*)ws, groups, n, dw);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : fail("k_conv_first_wgrad_m launch", e);
+    }
     static const bool blocked = getenv("SYN_FIRST_WGRAD_V1") == nullptr;       // (A/B: the one-position-per-step kernel)
     const bool v5 = stride == 5 && (blocked || bn_y);
     const size_t win = (size_t)((wav::kF1Chunk - 1 + (v5 ? 2 : 0)) * stride + 15) * cin, red = (size_t)8 * cin * 15 * 64;
     const size_t lds = (win > red ? win : red) * sizeof(float);
     if (lds > 64 * 1024) return fail_msg("syn_conv1d_first_wgrad: stride too large for the window");
     const dim3 grid(a.chunks_per_clip, n_clips);
-    hipStream_t s = (hipStream_t)stream;
     if (v5) {
         if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_wgrad5<1>, grid, dim3(512), lds, s, a);
         else hipLaunchKernelGGL(wav::k_conv_first_wgrad5<2>, grid, dim3(512), lds, s, a);
