@@ -902,3 +902,40 @@ def test_training_convolution_decompositions_at_the_bench_shapes(cv):
     for l in rows:
         f, s, q, d = (float(v) for v in re.search(r"\(rel ([\d.e+-]+), sums ([\d.e+-]+) / ([\d.e+-]+)\).*\(rel ([\d.e+-]+)\)", l).groups())
         assert f < 2e-5 and d < 2e-5 and s < 1e-3 and q < 1e-4, l
+
+
+@pytest.mark.parametrize("n,L,fold", [(32, 68266, False), (32, 68266, True), (5, 20011, True)])
+def test_first_layer_weight_gradient_at_the_bench_shape_vs_fp64(n, L, fold):
+    """syn_conv1d_first_wgrad / _bn at the bench shape (32 clips of 68266 samples x 2 channels: 1024 persistent workgroups walking position pairs across
+    the batch, one partial gradient each) against torch's convolution weight gradient in float64; with `fold` the BatchNorm + LeakyReLU backward of the
+    convolution's output is formed from (dz, y, statistics, affine, dgamma / dbeta) as the values are loaded: dy = scale (dp - dbeta / M - xhat dgamma / M),
+    dp = dz act'(scale y + shift).  The goldens of the training step run 4-8 clips: this is the many-workgroup path of the kernel."""
+    from syntalker_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + L)
+    cin, stride, pad = 2, 5, 1700
+    l_out = (L + 2 * pad - 15) // stride + 1
+    x = torch.randn(n, L, cin, generator=g).cuda()
+    dz = torch.randn(n, l_out, 64, generator=g).cuda()
+    st = _lib.current_stream(x.device)
+    ws = torch.empty(lib.syn_conv1d_first_parts(n, l_out) * 64 * cin * 15, device="cuda")
+    dw = torch.empty(64, cin, 15, device="cuda")
+    if fold:
+        y = torch.randn(n, l_out, 64, generator=g).cuda()
+        mu, rs = torch.randn(64, generator=g).cuda() * 0.1, torch.rand(64, generator=g).cuda() + 0.5
+        sc, sh = torch.rand(64, generator=g).cuda() + 0.5, torch.randn(64, generator=g).cuda() * 0.3
+        dgb = torch.randn(3, 64, generator=g).cuda() * (n * l_out) ** 0.5
+        stats, aff = torch.cat([mu, rs]).contiguous(), torch.cat([sc, sh]).contiguous()
+        _lib.check(lib.syn_conv1d_first_wgrad_bn(x.data_ptr(), dz.data_ptr(), y.data_ptr(), stats.data_ptr(), aff.data_ptr(), dgb.data_ptr(), 1,
+                                                 n, L, cin, stride, pad, ws.data_ptr(), dw.data_ptr(), st), "syn_conv1d_first_wgrad_bn")
+        m = float(n * l_out)
+        dp = torch.where(y.double() * sc.double() + sh.double() > 0, dz.double(), 0.01 * dz.double())
+        dy = sc.double() * (dp - dgb[1].double() / m - (y.double() - mu.double()) * rs.double() * dgb[0].double() / m)
+    else:
+        _lib.check(lib.syn_conv1d_first_wgrad(x.data_ptr(), dz.data_ptr(), n, L, cin, stride, pad, ws.data_ptr(), dw.data_ptr(), st), "syn_conv1d_first_wgrad")
+        dy = dz.double()
+    x4 = x.permute(0, 2, 1).unsqueeze(2).double()                               # (N, cin, 1, L)
+    want = torch.nn.grad.conv2d_weight(x4, (64, cin, 1, 15), dy.permute(0, 2, 1).unsqueeze(2).contiguous(), stride=(1, stride), padding=(0, pad)).squeeze(2)
+    e = rel_l2(dw.double().cpu(), want.cpu())
+    print(f"first-layer weight gradient, {n} clips x {L} samples, fold {fold}: rel-L2 vs float64 {e:.2e}")
+    assert e < 1e-5
