@@ -939,3 +939,23 @@ def test_first_layer_weight_gradient_at_the_bench_shape_vs_fp64(n, L, fold):
     e = rel_l2(dw.double().cpu(), want.cpu())
     print(f"first-layer weight gradient, {n} clips x {L} samples, fold {fold}: rel-L2 vs float64 {e:.2e}")
     assert e < 1e-5
+
+
+@pytest.mark.parametrize("cin,stride,cout,pad,L", [(64, 1, 64, 7, 14331), (64, 6, 64, 0, 14331), (64, 1, 64, 7, 2387), (64, 6, 128, 0, 2387),
+                                                  (128, 1, 128, 7, 396), (128, 3, 256, 0, 396), (256, 1, 256, 7, 128)])
+def test_training_conv_weight_gradients_at_the_bench_shapes(cin, stride, cout, pad, L):
+    """Weight gradients of the encoder's convolutions at the bench shapes (32 clips: 256 / 155-220 / 64 / 16 shares of position chunks, the partial sums
+    added by k_conv_wgrad_sum; strided layers on k_conv_wgrad_s) against torch's fp32 weight gradient.  Default products (x read rounded to bf16:
+    two of three): 1.7e-3 = bf16's rounding of x, which independent random operands do not average down (signal and error are both random sums over
+    the positions; the training step's gradients against the oracle are the measure for real data)."""
+    from syntalker_amd import training
+    g = torch.Generator().manual_seed(cin + stride + L)
+    x = torch.randn(32, cin, 1, L, generator=g).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 1, 15, generator=g) / (cin * 15) ** 0.5).cuda().requires_grad_(True)
+    y = training.ConvSplitFn.apply(x, w, stride, pad)
+    gy = torch.randn(y.shape, generator=g).cuda()
+    y.backward(gy)
+    want = torch.nn.grad.conv2d_weight(x, w.shape, gy, stride=(1, stride), padding=(0, pad))
+    e = rel_l2(w.grad.cpu(), want.cpu())
+    print(f"conv {cin}x{stride}->{cout} at {L} positions x 32 clips: weight gradient rel-L2 vs torch fp32 {e:.2e}")
+    assert e < 4e-3
