@@ -1112,3 +1112,28 @@ def test_h3d_training_loss_and_gradient_norms_vs_reference():
     print("h3d grad norms got / want:", got / fx["h3d.train.gradnorm"])
     assert np.allclose(got, fx["h3d.train.gradnorm"], rtol=3e-2)
     assert m.uncon_text_embeddings.grad is None and m.uncon_audio_embeddings.grad is None      # eval(): the null prompt is not reached, as in the reference
+
+
+def test_training_step_gradients_are_run_to_run_identical():
+    """Every reduction of the training step adds in a fixed order (partial sums per workgroup / share / wave, no atomics on a result): two backward
+    passes from identical state give bit-identical gradients for every parameter - the audio encoder's convolution, first-layer and BatchNorm
+    gradients, the persistent block kernels, the embedding table."""
+    from syntalker_amd.process import create_gaussian_diffusion
+    y = synth.to_device(synth.synth_clip_inputs(8, seed=5, mask_batch=8), DEV)
+    x0, eps = synth.synth_latent(8, seed=5, name="x0").to(DEV), synth.synth_latent(8, seed=6, name="eps").to(DEV)
+    t = torch.tensor([0, 17, 500, 999, 250, 3, 750, 100], device=DEV)
+    d = create_gaussian_diffusion()
+    m = _model("beatx").train()
+    m.drop_path = 0.0
+    runs = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        loss = d.training_losses(m, x0, t, model_kwargs={"y": y}, noise=eps)["loss"]
+        loss.mean().backward()
+        torch.cuda.synchronize()
+        runs.append((loss.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = runs
+    assert torch.equal(l0, l1)
+    assert g0.keys() == g1.keys() and len(g0) > 100
+    diff = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+    assert not diff, diff[:8]
