@@ -181,7 +181,7 @@ int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int
 
 /* The encoder's first layer in training mode - Conv1d(cin = 1 | 2 -> 64, k 15, stride, padding) of block 0's conv1 and of its
  * shortcut (models/denoiser.py:308, models/utils/layer.py:150,158; stride 5, padding 1700 there) - without the bias (see
- * syn_bn_act_fwd): plain fp32 FMAs.  x fp32 [n_clips][l_in][cin] (the waveform as the reference passes it), w the module's weight
+ * syn_bn_act_fwd): exact fp32 - the forward on fp32 FMAs, the weight gradient on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, a persistent stream over the batch).  x fp32 [n_clips][l_in][cin] (the waveform as the reference passes it), w the module's weight
  * [64][cin][15], y / dy fp32 channels-last [n_clips][l_out][64], l_out = (l_in + 2 pad - 15) / stride + 1.  The weight gradient
  * needs ws of syn_conv1d_first_parts(n_clips, l_out) * 64 * cin * 15 floats (workgroup partial sums, added in a fixed order) and
  * writes dw [64][cin][15].  There is no data gradient: the waveform is an input. */
