@@ -30,7 +30,10 @@
 extern "C" {
 #endif
 
-#define SYN_ABI_VERSION 7     /* 7: fused tail of the audio encoder's BasicBlock in training (syn_bn_finalize / syn_bn_apply2 / syn_bn_block_bwd,
+#define SYN_ABI_VERSION 8     /* 8: the seams of the training step (syn_rows_concat_bf16, syn_embed_rows_bf16, syn_bct_to_rows_bf16, syn_rows_group_sum, syn_touch,
+                                * syn_masked_smooth_l1 / _grad on the output Linear's rows), syn_linear_bwd_prep reads a strided / row-repeated dy, syn_pack_job.src_dim,
+                                * syn_linear_pair on 128-column tiles, syn_embedding_wgrad ld; superseded kernels and their switches removed;
+                                * 7: fused tail of the audio encoder's BasicBlock in training (syn_bn_finalize / syn_bn_apply2 / syn_bn_block_bwd,
                                 * syn_conv1d_train_fwd_norm / _wgrad_norm, syn_conv1d_first_fwd_stats / _tiles), syn_test_mfma_rate;
                                 * 6: pose formats either side of the RVQ-VAEs - syn_axis_angle_to_rot6d, syn_rot6d_to_axis_angle;
                                 * 5: training block entry points - bf16 outputs of syn_ln_fwd / syn_gelu_fwd / syn_attn_fwd, syn_linear_res (residual + DropPath factor
@@ -252,7 +255,9 @@ int syn_conv1d_train_wgrad_norm(const float* x, const float* dy, int32_t n_clips
 /* Every bf16 fragment set the training step's Linear layers need, from the fp32 master weights in ONE launch (the weights change
  * once per step, in optimizer.step()): job j packs src (n x k row-major, transposed = 0: as syn_pack_weight; k x n row-major,
  * transposed = 1: as syn_pack_weight_t) into out.  jobs_dev: device array; max_fragments = max over the jobs of n / 16 * k / 32. */
-typedef struct syn_pack_job { const float* src; void* out; int32_t n, k, transposed, pad_; } syn_pack_job;
+/* (ABI 8) src_dim > 0: the source's real extent along a zero-PADDED dimension - k of a row-major [n][src_dim] source (transposed = 0), n of a
+ * row-major [k][src_dim] source (transposed = 1): text_encoder_body's 300 input features as 384 columns. */
+typedef struct syn_pack_job { const float* src; void* out; int32_t n, k, transposed, src_dim; } syn_pack_job;
 int syn_pack_weights(const syn_pack_job* jobs_dev, int32_t n_jobs, int64_t max_fragments, void* stream);
 
 /* ---- training path: fp32 forward / backward of the non-GEMM pieces of a transformer block ----
@@ -278,11 +283,40 @@ int syn_rotary(const float* x, const float* cos_t, const float* sin_t, int32_t n
  * 231-245): dw fp32 [n][k] = sum_m dy[m][n] x[m][k], db [n] = sum_m dy[m][n] (NULL to skip); dy fp32 [m_rows][n], x bf16 [m_rows][k] (the operand
  * the forward GEMM took), m_rows <= 64, n % 16 == 0.  fp32 FMAs in row order. */
 int syn_linear_wgrad_rows(const float* dy, const void* x_bf16, int32_t m_rows, int32_t n, int32_t k, float* dw, float* db, void* stream);
-/* (ABI 6) masked_l2 of training_losses (gaussian_diffusion.py:202-215, 1307-1314: SmoothL1(beta 1) x mask, summed, / (sum(mask) x C)) and its gradient
- * in one pass: target, out, dout fp32 [batch][per_sample] with the frame index innermost (per_sample = C x 1 x t_len), mask bytes [batch][t_len];
- * loss [batch]; dout = d loss[b] / d out (the caller scales it by the incoming gradient of loss[b]). */
-int syn_masked_smooth_l1(const float* target, const float* out, const uint8_t* mask, int32_t batch, int32_t per_sample, int32_t t_len, float* loss,
-                         float* dout, void* stream);
+/* (ABI 8) masked_l2 of training_losses (gaussian_diffusion.py:202-215, 1307-1314: SmoothL1(beta 1) x mask, summed, / (sum(mask) x C)).
+ * target fp32 (B, C, 1, T) as the reference lays it out; out either the same (out_rows = 0) or the output Linear's own rows [B][T][C] (out_rows = 1:
+ * what models/denoiser.py:294-300's reshape / permute is a view of); mask bytes [batch][t_len]; part: [batch][channels / 64] floats of scratch;
+ * loss [batch].  channels % 64 == 0, t_len <= 64.  Two launches (tile sums, then their sum in tile order).
+ * poison_flag (NULL or one device int): while it is nonzero every loss is NaN - pass syn_train_stack.sync + 256, the persistent block kernels' sticky
+ * barrier-timeout flag (see syn_train_stack_fwd), so that a step computed from partial sums that never arrived cannot pass for a step. */
+int syn_masked_smooth_l1(const float* target, const float* out, const uint8_t* mask, int32_t batch, int32_t channels, int32_t t_len, int32_t out_rows,
+                         float* part, const int32_t* poison_flag, float* loss, void* stream);
+/* Its gradient: dout (laid out like out) = sample_scale[b] (NULL: 1) x d loss[b] / d out - one pass in the backward, the incoming gradient of
+ * loss[b] folded in. */
+int syn_masked_smooth_l1_grad(const float* target, const float* out, const uint8_t* mask, int32_t batch, int32_t channels, int32_t t_len, int32_t out_rows,
+                              const float* sample_scale, float* dout, void* stream);
+/* (ABI 8) bf16 GEMM operand [m_rows][out_ld] = up to SYN_CONCAT_MAX fp32 sources side by side, columns beyond them zero (torch.cat along the feature
+ * axis + the operand rounding + the zero padding to the GEMM's 128-column granularity, models/denoiser.py:155-174, denoiser_h3d.py:187-200).  Source i:
+ * `width` columns of rows of pitch ld; operand row r reads source row r / row_div (a per-clip vector repeated over the clip's frames), p2 (NULL or
+ * like p) added first; or pool > 1: the mean of source rows r * pool .. + pool - 1 (F.avg_pool1d over the frame axis, denoiser.py:157).
+ * width % 4 == 0, ld % 4 == 0. */
+#define SYN_CONCAT_MAX 4
+typedef struct syn_concat_src { const float* p; const float* p2; int32_t width, ld, row_div, pool; } syn_concat_src;
+int syn_rows_concat_bf16(const syn_concat_src* srcs, int32_t n_src, int32_t m_rows, int32_t out_ld, void* out_bf16, void* stream);
+/* (ABI 8) nn.Embedding lookup (models/denoiser.py:72,152) written as the next Linear's operand: out bf16 [m_rows][out_ld], columns dim .. out_ld zero. */
+int syn_embed_rows_bf16(const int64_t* ids, const float* table, int32_t vocab, int32_t dim, int32_t m_rows, int32_t out_ld, void* out_bf16, void* stream);
+/* (ABI 8) (B, C, 1, T) fp32 -> bf16 rows [B * T][C]: the permute of models/denoiser.py:160 + the operand rounding; channels % 64 == 0, t_len == 32. */
+int syn_bct_to_rows_bf16(const float* x_bct, int32_t n_clips, int32_t channels, int32_t t_len, void* out_bf16, void* stream);
+/* (ABI 8) out [n_groups][width] = sums over the `group` consecutive rows (pitch ld) of each group, in row order: the gradient of a vector the forward
+ * repeated over a clip's frames. */
+int syn_rows_group_sum(const float* src, int32_t ld, int32_t width, int32_t group, int32_t n_groups, float* out, void* stream);
+/* (ABI 8) out fp32 [m_rows][width] = scale x src[r / row_div][0:width] (src rows of pitch ld): the backward of an average pool over row_div rows. */
+int syn_rows_expand(const float* src, int32_t ld, int32_t width, int32_t row_div, float scale, int32_t m_rows, float* out, void* stream);
+/* (ABI 8) out [n] = sum over i < rows of part [i][n], in order: a Linear's bias gradient from syn_linear_bwd_prep's colsum_part when no syn_linear_pair
+ * launch carries it (a Linear whose input takes no gradient). */
+int syn_colsum_parts(const float* part, int32_t rows, int32_t n, float* out, void* stream);
+/* (ABI 8) One read pass over a buffer (a dword per 64-byte line): pulls it back into the memory-side cache ahead of a latency-bound consumer. */
+int syn_touch(const void* p, int64_t bytes, void* stream);
 /* nn.BatchNorm1d in training mode (batch statistics, running statistics updated as PyTorch does) [+ shortcut] [+ LeakyReLU(0.01)]
  * of the audio encoder's BasicBlock (models/utils/layer.py:171-184) on channels-last fp32 [rows][channels], rows = clips x
  * positions: z = act(gamma (y - mean) rstd + beta [+ shortcut]).  ws: 2 * syn_bn_chunks(rows) * channels floats; stats
@@ -338,7 +372,12 @@ int syn_bn_block_bwd(const float* dz, const float* y, const float* shortcut, con
  * 2 l + 1: its MLP branch; 0 or 1 / keep).  Written for the backward, per block, with M = 32 n_seq rows: the two branch inputs h (fp32 [M][512]) and their LayerNorm
  * mean / rstd [M]; qkv fp32 [M][1536]; the fc1 output + bias before the GELU, fp32 [M][1024]; and the transposed bf16 operands of the four weight-gradient GEMMs as
  * packed fragments (what syn_linear_and_pack's xt_packed holds): LN1(h)^T, attention output^T, LN2(h)^T (512 x M each), GELU output^T (1024 x M).
- * sync: 320 zeroed uint32 (left zeroed); xch: n_seq x 8 x 16384 floats of scratch. */
+ * sync: 320 zeroed uint32 (left zeroed); xch: n_seq x 8 x 16384 floats of scratch.
+ * sync[256] is a STICKY ERROR FLAG shared by syn_train_stack_fwd and syn_train_stack_bwd: the XCD-local barrier waits of the member workgroups are
+ * bounded, and a wait that runs out (another kernel holding CUs of the XCD) sets it and lets the kernel finish on whatever partial sums it found - the
+ * results of that launch, and of every later one that finds the flag set (its waits give up after 256 polls), are wrong.  Nothing in the library clears it:
+ * the host reads it back now and then and zeroes `sync` (syntalker_amd.training.check_stack_sync), and syn_masked_smooth_l1's poison_flag turns the step's
+ * loss into NaN while it is set. */
 typedef struct syn_train_block_save {
     float* h_attn; float* mean_attn; float* rstd_attn; float* qkv; void* xt_ln1; void* xt_attn;
     float* h_mlp; float* mean_mlp; float* rstd_mlp; float* pre; void* xt_ln2; void* xt_gelu;
@@ -393,19 +432,19 @@ int syn_opt_scalars(const float* partials, int32_t n_partials, float max_norm, c
                     float* scal4, void* stream);
 int syn_opt_adam(const syn_opt_list* l, const float* scal4, float beta1, float beta2, float eps, float weight_decay, void* stream);
 /* Gradient of an nn.Embedding table (models/denoiser.py:72, the word embedding in front of text_encoder_body): dw [vocab][dim] =
- * sum over the positions p with ids[p] == v of dy[p][:], added in increasing p (no atomics on the result; every row written).
- * ids int64 [n_pos] (n_pos <= 8192 per call), dy fp32 [n_pos][dim]. */
-int syn_embedding_wgrad(const int64_t* ids, const float* dy, int32_t n_pos, int32_t vocab, int32_t dim, float* dw, void* stream);
-/* Backward of an nn.Linear, the operand preparation in one pass over dy [m_rows][n] fp32: its bf16 copy (data-gradient GEMM),
+ * sum over the positions p with ids[p] == v of dy[p][:], added in increasing p (no atomics on the result; a memset node zeroes dw first).
+ * ids int64 [n_pos] (n_pos <= 8192 per call), dy fp32 rows of pitch ld >= dim (ABI 8: a column slice of the next Linear's data gradient), dim <= 512. */
+int syn_embedding_wgrad(const int64_t* ids, const float* dy, int32_t ld, int32_t n_pos, int32_t vocab, int32_t dim, float* dw, void* stream);
+/* Backward of an nn.Linear, the operand preparation in one pass over its output gradient [m_rows][n] fp32: the bf16 copy (data-gradient GEMM),
  * the bf16 transpose [n][m_rows] (weight-gradient GEMM) and colsum_part [m_rows / 64][n] = column sums of every 64-row block
- * (NULL to skip; the bias gradient is their sum over the first index).  With colsum [n] (and counters: n / 64 ints, zero before the
- * first use, left zero by every launch) the launch also adds the partial sums up, in row-block order: the bias gradient itself.
- * (ABI 5) row_scale (NULL or one float per rows_per_scale rows): dy is multiplied by its row's factor first - the backward of
- * syn_linear_res's `residual + row_scale * (x W^T + b)`, i.e. of x + DropPath(branch) (timm_transformer/transformer.py:21-38,195-198).
- * gelu_pre (NULL or [m_rows][n]): the Linear's output went through nn.GELU() before dy was formed - dy is multiplied by GELU'(gelu_pre) here
- * (syn_gelu_bwd's arithmetic) instead of by a launch of its own: the backward of syn_linear_gelu. */
-int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, const float* row_scale, int32_t rows_per_scale, const float* gelu_pre,
-                        void* dy_bf16, void* dy_bf16_t, float* colsum_part, int32_t* counters, float* colsum, void* stream);
+ * (NULL to skip; the bias gradient is their sum over the first index: syn_linear_pair's bias_grad).
+ * (ABI 8) The gradient is read where its producer left it: row r = row r / row_div of `dy`, rows of pitch ld floats (a column slice of a wider
+ * data gradient = one piece of a torch.cat's backward; row_div > 1 = the backward of an average pool over row_div rows with const_scale = 1 / row_div),
+ * times const_scale.
+ * (ABI 5) row_scale (NULL or one float per rows_per_scale rows): times its row's factor - the backward of
+ * syn_linear_res's `residual + row_scale * (x W^T + b)`, i.e. of x + DropPath(branch) (timm_transformer/transformer.py:21-38,195-198). */
+int syn_linear_bwd_prep(const float* dy, int32_t ld, int32_t row_div, float const_scale, int32_t m_rows, int32_t n, const float* row_scale,
+                        int32_t rows_per_scale, void* dy_bf16, void* dy_bf16_t, float* colsum_part, void* stream);
 /* Attention core (transformer.py:83-104, 4 heads x 128, 32 tokens, no mask, no dropout) on the packed output of the
  * qkv Linear: qkv [n_seq][32][3][4][128] -> o [n_seq][32][512]; backward recomputes the probabilities. */
 /* (ABI 5) o fp32 and / or o_bf16 (either may be NULL), as syn_ln_fwd. */
@@ -554,7 +593,8 @@ int syn_linear(const void* x_bf16, const void* w_packed, const float* bias, int3
 int syn_linear_and_pack(const void* x_bf16, const void* w_packed, const float* bias, int32_t m_rows, int32_t n, int32_t k, float* y,
                         void* xt_packed, void* stream);
 /* Two independent syn_linear calls (no bias) as ONE launch: the data-gradient GEMM dy . W and the weight-gradient GEMM dy^T . x of
- * an nn.Linear's backward fill half the chip each and do not depend on each other.  Same result as two calls, bitwise. */
+ * an nn.Linear's backward fill half the chip each and do not depend on each other.  Same result as two calls, bitwise.
+ * (ABI 8) n % 128 == 0 (512-column or 128-column tiles; shapes neither form takes as a pair go out as two launches + the bias sum). */
 /* (ABI 5) bias_grad [part_n] (NULL to skip) = sum over i < part_rows of bias_parts [i][part_n], added in order by the same launch: the
  * Linear's bias gradient from syn_linear_bwd_prep's colsum_part without a reduction launch of its own. */
 int syn_linear_pair(const void* x1_bf16, const void* w1_packed, int32_t m1, int32_t n1, int32_t k1, float* y1,

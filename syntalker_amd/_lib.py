@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SYN_HIP_LIB") or os.path.join(_HERE, "csrc", "libsyn_hip.so")   # env override: kernel A/B builds
 
 SYN_LAYERS = 8
-ABI_VERSION = 7             # include/syn_hip.h SYN_ABI_VERSION: a library built from other sources is refused at load time
+ABI_VERSION = 8             # include/syn_hip.h SYN_ABI_VERSION: a library built from other sources is refused at load time
 EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_steps", "syn_denoise_step_profile", "syn_pack_weight", "syn_pack_weight_t", "syn_to_token_major",
            "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_linear_pair", "syn_linear_and_pack", "syn_linear_res", "syn_linear_gelu", "syn_opt_blocks", "syn_opt_sqnorm", "syn_opt_scalars", "syn_opt_adam", "syn_test_gemm", "syn_test_attention", "syn_test_handoff",
            "syn_wav_encode", "syn_wav_workspace_bytes", "syn_wav_out_frames", "syn_linear_bwd_prep", "syn_embedding_wgrad", "syn_pack_weights", "syn_bn_chunks", "syn_bn_act_fwd", "syn_bn_act_bwd", "syn_bn_sums", "syn_bn_act_apply", "syn_bn_bwd_sums", "syn_bn_act_bwd_apply", "syn_conv1d_train_fwd", "syn_conv1d_train_fwd_tiles", "syn_conv1d_pack_split", "syn_conv1d_pack_split_many", "syn_conv1d_pack_bytes", "syn_conv1d_train_dgrad_strided", "syn_conv1d_train_wgrad", "syn_conv1d_wgrad_shares", "syn_conv1d_first_parts", "syn_conv1d_first_fwd", "syn_conv1d_first_wgrad", "syn_cond_encode",
@@ -23,7 +23,9 @@ EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_ste
            "syn_axis_angle_to_rot6d", "syn_rot6d_to_axis_angle", "syn_rotary", "syn_linear_wgrad_rows", "syn_masked_smooth_l1",
            "syn_bn_finalize", "syn_bn_apply2", "syn_bn_block_bwd", "syn_conv1d_train_fwd_norm", "syn_conv1d_train_wgrad_norm", "syn_conv1d_first_tiles",
            "syn_conv1d_first_fwd_stats", "syn_test_mfma_rate", "syn_conv1d_train_dgrad_sum", "syn_conv1d_first_fwd2", "syn_conv1d_first_wgrad_bn",
-           "syn_bn_bwd_stats", "syn_train_stack_fwd", "syn_train_stack_bwd", "syn_train_stack_wgrad")
+           "syn_bn_bwd_stats", "syn_train_stack_fwd", "syn_train_stack_bwd", "syn_train_stack_wgrad",
+           "syn_masked_smooth_l1_grad", "syn_rows_concat_bf16", "syn_embed_rows_bf16", "syn_bct_to_rows_bf16", "syn_rows_group_sum", "syn_rows_expand",
+           "syn_colsum_parts", "syn_touch")
 
 # the `void syn_debug_*` switches of the header's diagnostics section (process-wide, A/B runs and scripts/ only)
 DIAGNOSTICS = ("syn_debug_timing", "syn_debug_gemm_resident", "syn_debug_linear_tile", "syn_debug_conv_terms", "syn_debug_seq_skew", "syn_debug_seq_step")
@@ -78,6 +80,10 @@ SYN_CONV_PACK_MAX = 40
 class SynOptList(C.Structure):
     _fields_ = [("p", vp * SYN_OPT_MAX), ("g", vp * SYN_OPT_MAX), ("m", vp * SYN_OPT_MAX), ("v", vp * SYN_OPT_MAX),
                 ("numel", i32 * SYN_OPT_MAX), ("n", i32)]
+
+
+class SynConcatSrc(C.Structure):
+    _fields_ = [("p", vp), ("p2", vp), ("width", i32), ("ld", i32), ("row_div", i32), ("pool", i32)]
 
 
 class SynConvPackReq(C.Structure):
@@ -162,7 +168,15 @@ def load():
     lib.syn_gelu_fwd.argtypes = [vp, vp, vp, i64, vp]
     lib.syn_gelu_bwd.argtypes = [vp, vp, vp, i64, vp]
     lib.syn_linear_wgrad_rows.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
-    lib.syn_masked_smooth_l1.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.syn_masked_smooth_l1.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.syn_masked_smooth_l1_grad.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    lib.syn_rows_concat_bf16.argtypes = [C.POINTER(SynConcatSrc), i32, i32, i32, vp, vp]
+    lib.syn_embed_rows_bf16.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.syn_bct_to_rows_bf16.argtypes = [vp, i32, i32, i32, vp, vp]
+    lib.syn_rows_group_sum.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    lib.syn_rows_expand.argtypes = [vp, i32, i32, i32, C.c_float, i32, vp, vp]
+    lib.syn_colsum_parts.argtypes = [vp, i32, i32, vp, vp]
+    lib.syn_touch.argtypes = [vp, i64, vp]
     lib.syn_rotary.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.syn_axis_angle_to_rot6d.argtypes = [vp, i64, vp, vp]
     lib.syn_rot6d_to_axis_angle.argtypes = [vp, i64, vp, vp]
@@ -194,9 +208,9 @@ def load():
     lib.syn_conv1d_first_wgrad_bn.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.syn_bn_bwd_stats.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, i32, i32, vp, vp, vp]
     lib.syn_conv1d_train_dgrad_sum.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
-    lib.syn_linear_bwd_prep.argtypes = [vp, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.syn_linear_bwd_prep.argtypes = [vp, i32, i32, C.c_float, i32, i32, vp, i32, vp, vp, vp, vp]
     lib.syn_pack_weights.argtypes = [vp, i32, C.c_int64, vp]
-    lib.syn_embedding_wgrad.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    lib.syn_embedding_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     lib.syn_conv1d_train_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.syn_conv1d_wgrad_shares.argtypes = [i32, i32, i32]
     lib.syn_conv1d_first_parts.argtypes = [i32, i32]

@@ -1686,7 +1686,9 @@ __global__ void k_pack_t(const T* __restrict__ S, int N, int K, uint4* __restric
 
 // The step's weight packs in ONE launch: job j packs src_j (fp32) as k_pack (transposed = 0: src [n][k]) or as k_pack_t
 // (transposed = 1: src [k][n]) into out_j.  Grid (blocks of the largest job, jobs).
-struct PackJob { const float* src; uint4* out; int n, k, transposed, pad_; };
+struct PackJob { const float* src; uint4* out; int n, k, transposed, src_dim; };
+// src_dim > 0: the source's real extent along the PADDED dimension - k of a row-major [n][src_dim] source (transposed = 0), n of a row-major
+// [k][src_dim] source (transposed = 1); fragments beyond it are zero (text_encoder_body: 300 -> 384 input features).
 __global__ void k_pack_many(const PackJob* __restrict__ jobs) {
     const PackJob j = jobs[blockIdx.y];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1695,9 +1697,15 @@ __global__ void k_pack_many(const PackJob* __restrict__ jobs) {
     const int lane = idx & 63, f = idx >> 6, ks = f % KS, nf = f / KS;
     bf16x8 r;
     if (j.transposed) {
-        const float* src = j.src + (size_t)(32 * ks + 8 * (lane >> 4)) * j.n + 16 * nf + (lane & 15);
+        const int ld = j.src_dim > 0 ? j.src_dim : j.n, n = 16 * nf + (lane & 15);
+        const float* src = j.src + (size_t)(32 * ks + 8 * (lane >> 4)) * ld + n;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = (__bf16)src[(size_t)e * j.n];
+        for (int e = 0; e < 8; ++e) r[e] = n < ld ? (__bf16)src[(size_t)e * ld] : (__bf16)0.f;
+    } else if (j.src_dim > 0) {
+        const int k0 = 32 * ks + 8 * (lane >> 4);
+        const float* src = j.src + (size_t)(16 * nf + (lane & 15)) * j.src_dim + k0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = k0 + e < j.src_dim ? (__bf16)src[e] : (__bf16)0.f;
     } else {
         const float* src = j.src + (size_t)(16 * nf + (lane & 15)) * j.k + 32 * ks + 8 * (lane >> 4);
         const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
@@ -1977,6 +1985,7 @@ int launch_stack(const SArgs& a, int mt, hipStream_t s) {
 #include "syn_cond.inc"
 #include "syn_wavenc.inc"
 #include "syn_train.inc"
+#include "syn_glue.inc"
 #include "syn_rvq.inc"
 #include "syn_pose.inc"
 
@@ -2508,12 +2517,19 @@ int syn_linear_pair(const void* x1_bf16, const void* w1_packed, int32_t m1, int3
                     const void* x2_bf16, const void* w2_packed, int32_t m2, int32_t n2, int32_t k2, float* y2,
                     const float* bias_parts, int32_t part_rows, int32_t part_n, float* bias_grad, void* stream) {
     if (bias_grad && (!bias_parts || part_rows <= 0 || part_n <= 0)) return fail_msg("syn_linear_pair: bias_grad needs bias_parts [part_rows][part_n]");
-    if (!x1_bf16 || !w1_packed || !y1 || !x2_bf16 || !w2_packed || !y2 || n1 % kNT || n2 % kNT || k1 % 128 || k2 % 128 || m1 <= 0 || m2 <= 0)
-        return fail_msg("syn_linear_pair: need n % 512 == 0, k % 128 == 0, m_rows > 0 and non-null pointers");
-    if (m1 > 2048 || m2 > 2048 || g_linear_mt > 0) {                 // larger row tiles: two launches
-        if (bias_grad) return fail_msg("syn_linear_pair: the bias-gradient sum rides the single launch (m <= 2048, automatic row tile)");
+    if (!x1_bf16 || !w1_packed || !y1 || !x2_bf16 || !w2_packed || !y2 || n1 % 128 || n2 % 128 || k1 % 128 || k2 % 128 || m1 <= 0 || m2 <= 0)
+        return fail_msg("syn_linear_pair: need n % 128 == 0, k % 128 == 0, m_rows > 0 and non-null pointers");
+    const bool n128 = g_gemm_resident == 2 && pick_mt128(m1, n1, k1) && pick_mt128(m2, n2, k2);
+    const bool wide = n1 % kNT == 0 && n2 % kNT == 0;
+    if (m1 > 2048 || m2 > 2048 || g_linear_mt > 0 || (!n128 && !wide)) {       // larger row tiles, or a shape only one of the tile forms takes: two launches
         if (int rc = syn_linear(x1_bf16, w1_packed, nullptr, m1, n1, k1, y1, stream)) return rc;
-        return syn_linear(x2_bf16, w2_packed, nullptr, m2, n2, k2, y2, stream);
+        if (int rc = syn_linear(x2_bf16, w2_packed, nullptr, m2, n2, k2, y2, stream)) return rc;
+        if (bias_grad) {
+            hipLaunchKernelGGL(glu::k_colsum_parts, dim3((part_n + 63) / 64), dim3(64), 0, (hipStream_t)stream, bias_parts, part_rows, part_n, bias_grad);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail("k_colsum_parts launch", e);
+        }
+        return 0;
     }
     GPair p;
     memset(&p, 0, sizeof(p));
@@ -2528,7 +2544,6 @@ int syn_linear_pair(const void* x1_bf16, const void* w1_packed, int32_t m1, int3
     }
     const bool fits = k1 <= kResidentMaxK && k2 <= kResidentMaxK;
     int lds128 = 0;
-    const bool n128 = g_gemm_resident == 2 && pick_mt128(m1, n1, k1) && pick_mt128(m2, n2, k2);
     if (n128)                                                                  // 128-column tiles, the row tile per shape (half a chip each)
         for (int i = 0; i < 2; ++i) {
             const int mt = pick_mt128(ms[i], ns[i], ks[i], 2);
@@ -2719,13 +2734,93 @@ int syn_linear_wgrad_rows(const float* dy, const void* x_bf16, int32_t m_rows, i
     return e == hipSuccess ? 0 : fail("k_linear_wgrad_rows launch", e);
 }
 
-int syn_masked_smooth_l1(const float* target, const float* out, const uint8_t* mask, int32_t batch, int32_t per_sample, int32_t t_len, float* loss,
-                         float* dout, void* stream) {
-    if (!target || !out || !mask || !loss || !dout || batch <= 0 || per_sample <= 0 || per_sample % 4 || t_len <= 0 || t_len > 64 || per_sample % t_len)
-        return fail_msg("syn_masked_smooth_l1: per_sample must be a multiple of 4 and of t_len <= 64");
-    hipLaunchKernelGGL(trn::k_masked_smooth_l1, dim3(batch), dim3(256), 0, (hipStream_t)stream, target, out, mask, per_sample, t_len, loss, dout);
+int syn_masked_smooth_l1(const float* target, const float* out, const uint8_t* mask, int32_t batch, int32_t channels, int32_t t_len, int32_t out_rows,
+                         float* part, const int32_t* poison_flag, float* loss, void* stream) {
+    if (!target || !out || !mask || !loss || !part || batch <= 0 || channels <= 0 || channels % 64 || t_len <= 0 || t_len > 64)
+        return fail_msg("syn_masked_smooth_l1: channels must be a multiple of 64, t_len <= 64, part [batch][channels / 64]");
+    const int chunks = channels / 64;
+    hipLaunchKernelGGL(glu::k_sl1_tiles<false>, dim3(chunks, batch), dim3(256), 0, (hipStream_t)stream, target, out, mask, channels, t_len, out_rows,
+                       (const float*)nullptr, part, (float*)nullptr);
+    hipLaunchKernelGGL(glu::k_sl1_final, dim3((batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, mask, batch, chunks, channels, t_len, poison_flag, loss);
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("k_masked_smooth_l1 launch", e);
+    return e == hipSuccess ? 0 : fail("k_sl1_tiles launch", e);
+}
+
+int syn_masked_smooth_l1_grad(const float* target, const float* out, const uint8_t* mask, int32_t batch, int32_t channels, int32_t t_len, int32_t out_rows,
+                              const float* sample_scale, float* dout, void* stream) {
+    if (!target || !out || !mask || !dout || batch <= 0 || channels <= 0 || channels % 64 || t_len <= 0 || t_len > 64)
+        return fail_msg("syn_masked_smooth_l1_grad: channels must be a multiple of 64, t_len <= 64");
+    hipLaunchKernelGGL(glu::k_sl1_tiles<true>, dim3(channels / 64, batch), dim3(256), 0, (hipStream_t)stream, target, out, mask, channels, t_len, out_rows,
+                       sample_scale, (float*)nullptr, dout);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_sl1_tiles (gradient) launch", e);
+}
+
+int syn_rows_concat_bf16(const syn_concat_src* srcs, int32_t n_src, int32_t m_rows, int32_t out_ld, void* out_bf16, void* stream) {
+    if (!srcs || n_src < 1 || n_src > SYN_CONCAT_MAX || m_rows <= 0 || out_ld <= 0 || out_ld % 4 || !out_bf16) return fail_msg("syn_rows_concat_bf16: 1 .. 4 sources, out_ld % 4 == 0");
+    glu::CatArgs a;
+    memset(&a, 0, sizeof(a));
+    int total = 0;
+    for (int i = 0; i < n_src; ++i) {
+        const syn_concat_src& c = srcs[i];
+        if (!c.p || c.width <= 0 || c.width % 4 || c.ld % 4 || c.ld < c.width || c.row_div < 1 || c.pool < 1 || (c.pool > 1 && (c.row_div != 1 || c.p2)))
+            return fail_msg("syn_rows_concat_bf16: a source needs width % 4 == 0, ld % 4 == 0, ld >= width, row_div >= 1, pool >= 1 (a pooled source: row_div 1, no addend)");
+        a.s[i].p = c.p; a.s[i].p2 = c.p2; a.s[i].width = c.width; a.s[i].ld = c.ld; a.s[i].row_div = c.row_div; a.s[i].pool = c.pool;
+        total += c.width;
+    }
+    if (total > out_ld) return fail_msg("syn_rows_concat_bf16: the sources are wider than out_ld");
+    a.n_src = n_src; a.M = m_rows; a.out_ld = out_ld; a.out = (__bf16*)out_bf16;
+    const long n = (long)m_rows * (out_ld / 4);
+    hipLaunchKernelGGL(glu::k_rows_concat_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_rows_concat_bf16 launch", e);
+}
+
+int syn_embed_rows_bf16(const int64_t* ids, const float* table, int32_t vocab, int32_t dim, int32_t m_rows, int32_t out_ld, void* out_bf16, void* stream) {
+    if (!ids || !table || !out_bf16 || vocab <= 0 || dim <= 0 || dim % 4 || m_rows <= 0 || out_ld < dim || out_ld % 4) return fail_msg("syn_embed_rows_bf16: dim % 4 == 0, out_ld >= dim, out_ld % 4 == 0");
+    const long n = (long)m_rows * (out_ld / 4);
+    hipLaunchKernelGGL(glu::k_embed_rows_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const long*>(ids), table, vocab,
+                       dim, m_rows, out_ld, (__bf16*)out_bf16);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_embed_rows_bf16 launch", e);
+}
+
+int syn_bct_to_rows_bf16(const float* x_bct, int32_t n_clips, int32_t channels, int32_t t_len, void* out_bf16, void* stream) {
+    if (!x_bct || !out_bf16 || n_clips <= 0 || channels <= 0 || channels % 64 || t_len != 32) return fail_msg("syn_bct_to_rows_bf16: channels % 64 == 0, t_len == 32");
+    hipLaunchKernelGGL(glu::k_bct_to_rows_bf16, dim3(channels / 64, n_clips), dim3(256), 0, (hipStream_t)stream, x_bct, channels, (__bf16*)out_bf16);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_bct_to_rows_bf16 launch", e);
+}
+
+int syn_rows_group_sum(const float* src, int32_t ld, int32_t width, int32_t group, int32_t n_groups, float* out, void* stream) {
+    if (!src || !out || ld < width || width <= 0 || group <= 0 || n_groups <= 0) return fail_msg("syn_rows_group_sum: bad arguments");
+    hipLaunchKernelGGL(glu::k_rows_group_sum, dim3((n_groups * width + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, ld, width, group, n_groups, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_rows_group_sum launch", e);
+}
+
+int syn_rows_expand(const float* src, int32_t ld, int32_t width, int32_t row_div, float scale, int32_t m_rows, float* out, void* stream) {
+    if (!src || !out || width <= 0 || width % 4 || ld < width || ld % 4 || row_div < 1 || m_rows <= 0) return fail_msg("syn_rows_expand: width % 4 == 0, ld >= width, ld % 4 == 0, row_div >= 1");
+    const long n = (long)m_rows * (width / 4);
+    hipLaunchKernelGGL(glu::k_rows_expand, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, ld, width, row_div, scale, m_rows, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_rows_expand launch", e);
+}
+
+int syn_colsum_parts(const float* part, int32_t rows, int32_t n, float* out, void* stream) {
+    if (!part || !out || rows <= 0 || n <= 0) return fail_msg("syn_colsum_parts: bad arguments");
+    hipLaunchKernelGGL(glu::k_colsum_parts, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, part, rows, n, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_colsum_parts launch", e);
+}
+
+int syn_touch(const void* p, int64_t bytes, void* stream) {
+    if (!p || bytes < 64) return fail_msg("syn_touch: at least one 64-byte line");
+    const long lines = bytes / 64;
+    const long blocks = (lines + 255) / 256;
+    hipLaunchKernelGGL(glu::k_touch, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, (hipStream_t)stream, (const unsigned*)p, lines, (unsigned*)nullptr);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_touch launch", e);
 }
 
 int syn_rotary(const float* x, const float* cos_t, const float* sin_t, int32_t n_seq, int32_t inverse, float* y, void* stream) {
@@ -2866,13 +2961,12 @@ int syn_bn_act_bwd_apply(const float* dz, const float* z, const float* y, const 
     return e == hipSuccess ? 0 : fail("syn_bn_act_bwd_apply", e);
 }
 
-int syn_linear_bwd_prep(const float* dy, int32_t m_rows, int32_t n, const float* row_scale, int32_t rows_per_scale, const float* gelu_pre,
-                        void* dy_bf16, void* dy_bf16_t, float* colsum_part, int32_t* counters, float* colsum, void* stream) {
-    if (!dy || !dy_bf16 || !dy_bf16_t || m_rows <= 0 || n <= 0 || m_rows % 64 || n % 64 || (row_scale && rows_per_scale <= 0))
-        return fail_msg("syn_linear_bwd_prep: need m_rows % 64 == 0, n % 64 == 0 and non-null pointers");
-    if (colsum && (!colsum_part || !counters)) return fail_msg("syn_linear_bwd_prep: colsum needs colsum_part and counters");
-    hipLaunchKernelGGL(trn::k_linear_bwd_prep, dim3(n / 64, m_rows / 64), dim3(256), 0, (hipStream_t)stream, dy, m_rows, n, row_scale, rows_per_scale, gelu_pre,
-                       (__bf16*)dy_bf16, (__bf16*)dy_bf16_t, colsum_part, counters, colsum);
+int syn_linear_bwd_prep(const float* dy, int32_t ld, int32_t row_div, float const_scale, int32_t m_rows, int32_t n, const float* row_scale,
+                        int32_t rows_per_scale, void* dy_bf16, void* dy_bf16_t, float* colsum_part, void* stream) {
+    if (!dy || !dy_bf16 || !dy_bf16_t || m_rows <= 0 || n <= 0 || m_rows % 64 || n % 64 || (row_scale && rows_per_scale <= 0) || ld < n || ld % 4 || row_div < 1)
+        return fail_msg("syn_linear_bwd_prep: need m_rows % 64 == 0, n % 64 == 0, ld >= n, ld % 4 == 0, row_div >= 1 and non-null pointers");
+    hipLaunchKernelGGL(trn::k_linear_bwd_prep, dim3(n / 64, m_rows / 64), dim3(256), 0, (hipStream_t)stream, dy, ld, row_div, const_scale, m_rows, n, row_scale,
+                       rows_per_scale, (__bf16*)dy_bf16, (__bf16*)dy_bf16_t, colsum_part);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_linear_bwd_prep launch", e);
 }
@@ -2926,12 +3020,14 @@ int syn_opt_adam(const syn_opt_list* l, const float* scal4, float beta1, float b
     return e == hipSuccess ? 0 : fail("k_opt_adam launch", e);
 }
 
-int syn_embedding_wgrad(const int64_t* ids, const float* dy, int32_t n_pos, int32_t vocab, int32_t dim, float* dw, void* stream) {
-    if (!ids || !dy || !dw || n_pos <= 0 || n_pos > trn::kEmbMaxPos || vocab <= 0 || dim <= 0)
-        return fail_msg("syn_embedding_wgrad: bad arguments (at most 8192 positions per call)");
-    hipLaunchKernelGGL(trn::k_embedding_wgrad, dim3((vocab + trn::kEmbRows - 1) / trn::kEmbRows), dim3(320), 0, (hipStream_t)stream,
-                       reinterpret_cast<const long*>(ids), dy, n_pos, vocab, dim, dw);
-    hipError_t e = hipGetLastError();
+int syn_embedding_wgrad(const int64_t* ids, const float* dy, int32_t ld, int32_t n_pos, int32_t vocab, int32_t dim, float* dw, void* stream) {
+    if (!ids || !dy || !dw || n_pos <= 0 || n_pos > glu::kEmbMaxPos || vocab <= 0 || dim <= 0 || dim > glu::kEmbMaxD || ld < dim)
+        return fail_msg("syn_embedding_wgrad: bad arguments (at most 8192 positions per call, dim <= 512, ld >= dim)");
+    hipError_t e = hipMemsetAsync(dw, 0, (size_t)vocab * dim * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return fail("syn_embedding_wgrad memset", e);
+    hipLaunchKernelGGL(glu::k_embedding_wgrad, dim3((n_pos + glu::kEmbWaves - 1) / glu::kEmbWaves), dim3(glu::kEmbWaves * 64), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long*>(ids), dy, ld, n_pos, vocab, dim, dw);
+    e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_embedding_wgrad launch", e);
 }
 

@@ -1,65 +1,52 @@
-"""Training path of the denoiser (e): `training_losses` forward + backward.
+"""Training path of the denoiser (e): `training_losses` forward + backward, every op on hand-written HIP kernels.
 
-  * every nn.Linear of the denoiser (qkv, proj, fc1, fc2, poseEmbedding, input_process2/3, poseFinal, embed_text,
-    time MLP, word/mix projections) runs forward, dgrad and wgrad on the hand-written MFMA GEMM through the C ABI
-    (`syn_linear`, `syn_linear_pair`: bf16 operands, fp32 accumulate/output) — `HipLinearFn`;
-  * LayerNorm, the 32-token softmax attention and GELU of the 8 blocks run forward and backward on fp32 HIP kernels
-    (`syn_ln_*`, `syn_attn_*`, `syn_gelu_*`; `HipLnForkFn`, `HipAttentionFn`, `HipGeluFn`);
-  * the WavEncoder (78 % of the training FLOPs, cannot be hoisted in training): every Conv1d forward / data gradient / weight
-    gradient on split-operand MFMA kernels (fp32-grade), the 1-2-channel first layer on plain fp32 FMAs, BatchNorm on batch
-    statistics + shortcut + LeakyReLU fused (`ConvSplitFn`, `ConvFirstFn`, `BnActFn`).  No library convolution is on this
-    path: a layer geometry the kernels do not cover raises;
-  * rotary, DropPath's multiply-add and the SmoothL1 loss are fp32 PyTorch elementwise ops;
-  * data parallelism: one process per GPU, torch DDP over RCCL (`make_ddp`), gradients averaged by bucketed
-    all-reduce overlapped with backward.  SyncBatchNorm (the reference's DDP branch converts every BatchNorm, train.py:90) runs on the
-    same kernels: per-channel fp64 sums -> one small all-reduce -> finalise (`SyncBnActFn`, `syn_bn_sums` / `syn_bn_act_apply` / ...).
-Train-mode semantics follow the reference: BatchNorm batch statistics, DropPath(0.1) per sample with
-scale-by-keep (timm_transformer/transformer.py:21-38), h3d Bernoulli(0.3) style dropout
-(denoiser_h3d.py:116-124).  There is no CPU fallback: CPU tensors raise.
+  * every nn.Linear (time MLP, embed_text, the input stage's five, the blocks' four, poseFinal) runs forward, data gradient and weight gradient on
+    the MFMA GEMM through the C ABI (bf16 operands, fp32 accumulate / output): `HipLinearFn` for a Linear on its own, `InputStageFn` for the
+    input stage as one autograd node, `StackFn` / `AttnBranchFn` / `MlpBranchFn` for the eight pre-LN blocks;
+  * the seams between them - the reference's torch.cat / avg_pool1d / permute / embedding / masked_l2 (models/denoiser.py:147-176,
+    gaussian_diffusion.py:202-215) - are the kernels of csrc/syn_glue.inc: GEMM operands are written in the form the GEMM takes them, gradients
+    are read where the GEMM left them;
+  * the WavEncoder (78 % of the training FLOPs, cannot be hoisted in training): every Conv1d forward / data gradient / weight gradient on
+    split-operand MFMA kernels (fp32-grade), the 1-2-channel first layer on fp32 FMAs / the fp32 matrix pipe, BatchNorm on batch statistics
+    folded into its neighbours (`WavBlockFn`: a BasicBlock as one autograd node; `ConvSplitFn` / `BnActFn` / `SyncBnActFn`: the per-convolution
+    nodes SyncBatchNorm and eval-mode statistics take).  No library convolution is on this path: a layer geometry the kernels do not cover raises;
+  * data parallelism, optimizer, captured step: `optim.py` (re-exported here).
+Train-mode semantics follow the reference: BatchNorm batch statistics, DropPath(0.1) per sample with scale-by-keep
+(timm_transformer/transformer.py:21-38), h3d Bernoulli(0.3) style dropout (denoiser_h3d.py:116-124).  There is no CPU fallback: CPU tensors raise.
+Batches whose size is not a multiple of 4 are padded with empty clips behind the audio encoder (the kernels work on 128-row tiles); the padding
+rows carry zero gradients and are dropped from the output.
 """
 from __future__ import annotations
 
 import ctypes as C
 import math
+import os as _os
+import weakref
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib, engine
+from .optim import (DDP_BUCKET_MB, ClipAdam, GraphedTrainStep, _avg_comm_hook, _check_clip, _grad_out, _into_bound_buffers,   # noqa: F401 (re-exports)
+                    _reset_handed, bind_grad_buffers, ddp_bucket_sizes, direct_grad_report, make_ddp, train_step, unbind_grad_buffers,
+                    unused_in_forward)
 
 
 def _ceil_to(a: int, m: int) -> int:
     return (a + m - 1) // m * m
 
 
-def hip_matmul_nt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
-    """fp32 y[M, N] = x[M, K] @ w[N, K]^T (+ bias) on the MFMA GEMM (operands rounded to bf16).
-    Shapes are zero-padded to the kernel's granularity (N % 512, K % 128)."""
-    engine._require_cuda(x, "training input")
-    M, K = x.shape
-    N = w.shape[0]
-    Kp, Np = _ceil_to(K, 128), _ceil_to(N, 512)
-    xb = x.to(torch.bfloat16)
-    wf = w.float()
-    if Kp != K:
-        xb = F.pad(xb, (0, Kp - K))
-        wf = F.pad(wf, (0, Kp - K))
-    if Np != N:
-        wf = F.pad(wf, (0, 0, 0, Np - N))
-    xb = xb.contiguous()
-    wp = engine.pack_weight(wf.contiguous())
-    b = None
-    if bias is not None:
-        b = bias.float()
-        if Np != N:
-            b = F.pad(b, (0, Np - N))
-        b = b.contiguous()
-    y = torch.empty(M, Np, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().syn_linear(xb.data_ptr(), wp.data_ptr(), _lib.ptr(b), M, Np, Kp, y.data_ptr(),
-                                      _lib.current_stream(y.device)), "syn_linear")
-    return y if Np == N else y[:, :N]
+def _f32c(t):
+    t = t.detach()
+    if t.dtype is not torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
 
+
+# ---- nn.Linear on the MFMA GEMM --------------------------------------------------------------------------------------------------------------
+# A weight W [N][K] (fp32 master) is used through two bf16 fragment sets: W for the forward GEMM x W^T and W^T for the data-gradient GEMM dy W.
+# K is zero-padded to the GEMM's 128-column granularity (text_encoder_body: 300 -> 384); N % 128 == 0 for every Linear of the model.
 
 def _pack_t(src: torch.Tensor, n: int, k: int) -> torch.Tensor:
     """Packed fragments of W = src^T for a row-major src [k][n] (fp32 or bf16), no transposed copy."""
@@ -69,69 +56,51 @@ def _pack_t(src: torch.Tensor, n: int, k: int) -> torch.Tensor:
     return out
 
 
-def _gemm_packed(xb: torch.Tensor, wp: torch.Tensor, n: int, k: int) -> torch.Tensor:
-    """fp32 y[M][n] = xb[M][k] (bf16, contiguous) . W^T for packed W[n][k]; n % 512 == 0, k % 128 == 0."""
-    y = torch.empty(xb.shape[0], n, dtype=torch.float32, device=xb.device)
-    _lib.check(_lib.load().syn_linear(xb.data_ptr(), wp.data_ptr(), None, xb.shape[0], n, k, y.data_ptr(), _lib.current_stream(y.device)),
-               "syn_linear")
-    return y
-
-
 class WeightPacks:
     """The bf16 fragment sets the step's Linear layers take - W for the forward GEMM, W^T for the data-gradient GEMM - packed from
-    the fp32 master weights in ONE launch per step (`syn_pack_weights`) instead of one launch per use (82 per step): the weights
-    only change in optimizer.step().  `refresh()` at the top of every training forward; HipLinearFn looks a weight up by object
-    identity and in-place version, so a stale or foreign tensor simply takes the per-call packing path."""
+    the fp32 master weights in ONE launch per step (`syn_pack_weights`) instead of one launch per use: the weights only change in
+    optimizer.step().  `refresh()` at the top of every training forward; a weight is looked up by object identity and in-place version,
+    so a stale or foreign tensor simply takes the pack-on-the-spot path (`_packs_of`)."""
 
     def __init__(self, weights):
         import numpy as np
         self.owner = lambda: None                                # the model the cache belongs to (weak reference, set by its user)
         self.items = {}
         jobs, self.max_frag = [], 0
-        dev = None
-        # two arenas - all forward sets, all transposed sets - so that either can be pulled into the memory-side cache with one pass (`prefetch`)
-        ok = [w for w in weights if w.is_cuda and w.dtype is torch.float32 and w.is_contiguous() and w.dim() == 2]
-        nb_f = sum(w.numel() * 2 for w in ok if w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0)
-        nb_t = sum(w.numel() * 2 for w in ok if w.shape[1] % 512 == 0 and w.shape[0] % 128 == 0)
-        self.arena_fwd = torch.empty(nb_f, dtype=torch.uint8, device=ok[0].device) if ok and nb_f else None
-        self.arena_tr = torch.empty(nb_t, dtype=torch.uint8, device=ok[0].device) if ok and nb_t else None
-        of = ot = 0
+        ok = []
         for w in weights:
-            if not (w.is_cuda and w.dtype is torch.float32 and w.is_contiguous() and w.dim() == 2) or id(w) in self.items:
-                continue
-            dev = w.device
+            if w.is_cuda and w.dtype is torch.float32 and w.is_contiguous() and w.dim() == 2 and w.shape[0] % 128 == 0 and not any(w is o for o in ok):
+                ok.append(w)
+        # two arenas - all forward sets, all transposed sets - so that either can be pulled into the memory-side cache with one pass (`prefetch`)
+        nb = sum(w.shape[0] * _ceil_to(w.shape[1], 128) * 2 for w in ok)
+        dev = ok[0].device if ok else None
+        self.arena_fwd = torch.empty(nb, dtype=torch.uint8, device=dev) if ok else None
+        self.arena_tr = torch.empty(nb, dtype=torch.uint8, device=dev) if ok else None
+        of = 0
+        for w in ok:
             N, K = w.shape
-            fwd = tr = None
-            if N % 128 == 0 and K % 128 == 0:                        # (N % 512 != 0: the 128-column GEMM)
-                fwd = self.arena_fwd[of:of + N * K * 2]
-                of += N * K * 2
-            if K % 512 == 0 and N % 128 == 0:
-                tr = self.arena_tr[ot:ot + N * K * 2]
-                ot += N * K * 2
-            if fwd is None and tr is None:
-                continue
-            if fwd is not None:
-                jobs.append((w.data_ptr(), fwd.data_ptr(), N, K, 0, 0))
-            if tr is not None:
-                jobs.append((w.data_ptr(), tr.data_ptr(), K, N, 1, 0))       # fragments of W^T [K][N] from the row-major [N][K]
-            self.max_frag = max(self.max_frag, (N // 16) * (K // 32))
-            self.items[id(w)] = [__import__("weakref").ref(w), w.data_ptr(), -1, fwd, tr]
+            Kp = _ceil_to(K, 128)
+            fwd, tr = self.arena_fwd[of:of + N * Kp * 2], self.arena_tr[of:of + N * Kp * 2]
+            of += N * Kp * 2
+            pad = K if Kp != K else 0
+            jobs.append((w.data_ptr(), fwd.data_ptr(), N, Kp, 0, pad))       # fragments of W [N][Kp]
+            jobs.append((w.data_ptr(), tr.data_ptr(), Kp, N, 1, pad))        # fragments of W^T [Kp][N] from the row-major [N][K]
+            self.max_frag = max(self.max_frag, (N // 16) * (Kp // 32))
+            self.items[id(w)] = [weakref.ref(w), w.data_ptr(), -1, fwd, tr]
         self.n_jobs = len(jobs)
         if jobs:
-            arr = np.array(jobs, dtype=np.dtype([("src", "<u8"), ("out", "<u8"), ("n", "<i4"), ("k", "<i4"), ("t", "<i4"), ("pad", "<i4")]))
+            arr = np.array(jobs, dtype=np.dtype([("src", "<u8"), ("out", "<u8"), ("n", "<i4"), ("k", "<i4"), ("t", "<i4"), ("src_dim", "<i4")]))
             self.jobs = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
 
     def valid(self) -> bool:
         return all(r() is not None and r().data_ptr() == ptr for r, ptr, *_ in self.items.values())
 
     def prefetch(self, transposed: bool):
-        """One read pass over the forward / transposed fragment sets (a byte per 64): whatever has been evicted from the memory-side cache since the
+        """One read pass over the forward / transposed fragment sets: whatever has been evicted from the memory-side cache since the
         pack comes back before a latency-bound consumer asks for it fragment by fragment."""
         a = self.arena_tr if transposed else self.arena_fwd
         if a is not None and a.numel() >= 64:
-            n = a.numel() // 64 * 64
-            return a[:n].view(-1, 64)[:, 0].sum(dtype=torch.int32)
-        return None
+            _lib.check(_lib.load().syn_touch(a.data_ptr(), a.numel(), _lib.current_stream(a.device)), "syn_touch")
 
     def refresh(self):
         if not self.n_jobs:
@@ -148,282 +117,186 @@ class WeightPacks:
         return it[3], it[4]
 
 
-WEIGHT_PACKS = bool(int(__import__("os").environ.get("SYN_WEIGHT_PACKS", "1")))       # training forward: pack every Linear weight (and its transpose) in one launch per step
-_packs: "WeightPacks | None" = None
-
-
+_packs: "WeightPacks | None" = None             # the step's packs of every Linear outside the blocks
 _packs_blocks: "WeightPacks | None" = None      # the transformer blocks' Linears: packed right in front of the blocks (see train_forward)
 
 
 def _lookup_packs(w):
-    if not WEIGHT_PACKS:
-        return None, None
     for pk in (_packs, _packs_blocks):
         if pk is not None:
             r = pk.lookup(w)
-            if r[0] is not None or r[1] is not None:
+            if r[0] is not None:
                 return r
     return None, None
 
 
-_bias_counters = {}
+def _packs_of(w):
+    """(W fragments, W^T fragments) of a Linear weight [N][K], K zero-padded to 128: the step's packs, or packed on the spot."""
+    fwd, tr = _lookup_packs(w)
+    if fwd is not None:
+        return fwd, tr
+    N, K = w.shape
+    if N % 128 or w.dim() != 2:
+        raise _lib.SynHipError(f"Linear weight {tuple(w.shape)}: the GEMM kernels take output widths that are multiples of 128 (every Linear of the "
+                               "reference's denoiser is: models/denoiser.py:86-109)")
+    engine._require_cuda(w, "Linear weight")
+    Kp = _ceil_to(K, 128)
+    wf = w.detach().float()
+    if Kp != K:
+        wf = F.pad(wf, (0, Kp - K))
+    wf = wf.contiguous()
+    return engine.pack_weight(wf), _pack_t(wf, Kp, N)
 
 
-def _counters(device):
-    """Arrival counters of syn_linear_bwd_prep's in-launch bias-gradient sum: zero before the first use, left zero by every launch."""
-    c = _bias_counters.get(device)
-    if c is None:
-        c = _bias_counters[device] = torch.zeros(1024, dtype=torch.int32, device=device)
-    return c
+def _bf16_rows(x, K: int, Kp: int):
+    """(..., K) -> bf16 contiguous [M][Kp] GEMM operand (columns K .. Kp zero)."""
+    xb = x.detach().reshape(-1, K)
+    if xb.dtype is not torch.bfloat16:
+        xb = xb.to(torch.bfloat16)
+    if Kp != K:
+        xb = F.pad(xb, (0, Kp - K))
+    return xb.contiguous()
+
+
+def _gemm(xb, wp, n: int, k: int, bias=None):
+    """fp32 y[M][n] = xb[M][k] (bf16, contiguous) . W^T (+ bias) for packed W[n][k]; n % 128 == 0, k % 128 == 0."""
+    y = torch.empty(xb.shape[0], n, dtype=torch.float32, device=xb.device)
+    _lib.check(_lib.load().syn_linear(xb.data_ptr(), wp.data_ptr(), _lib.ptr(bias), xb.shape[0], n, k, y.data_ptr(), _lib.current_stream(y.device)),
+               "syn_linear")
+    return y
+
+
+def _lin_fwd(xb, w, b, res=None, scale=None, rows_per_scale=1, gelu_out=None):
+    """bf16 rows [M][Kp] -> fp32 [M][N] = x W^T + b, or res + scale[row // rows_per_scale] * (x W^T + b), or (gelu_out given) also
+    bf16(GELU(.)) into gelu_out; and what the backward takes: the x^T fragments of the weight-gradient GEMM (packed by the same launch
+    while M <= 2048) and the W^T fragments as of THIS forward (the step's pack cache may have moved on by then).  M % 32 == 0."""
+    pk, wt = _packs_of(w)
+    M, K = xb.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=xb.device)
+    xt = torch.empty(K * M * 2, dtype=torch.uint8, device=xb.device)
+    lib, st = _lib.load(), _lib.current_stream(xb.device)
+    bc = None if b is None else _f32c(b)
+    if gelu_out is not None:                   # fc1: y stays fp32 for the backward, gelu_out receives bf16(GELU(y)) - fc2's operand
+        _lib.check(lib.syn_linear_gelu(xb.data_ptr(), pk.data_ptr(), _lib.ptr(bc), M, N, K, y.data_ptr(), gelu_out.data_ptr(), xt.data_ptr(), st),
+                   "syn_linear_gelu")
+    elif res is not None:
+        _lib.check(lib.syn_linear_res(xb.data_ptr(), pk.data_ptr(), _lib.ptr(bc), res.data_ptr(), _lib.ptr(scale), rows_per_scale, M, N, K,
+                                      y.data_ptr(), xt.data_ptr(), st), "syn_linear_res")
+    else:
+        _lib.check(lib.syn_linear_and_pack(xb.data_ptr(), pk.data_ptr(), _lib.ptr(bc), M, N, K, y.data_ptr(), xt.data_ptr(), st), "syn_linear_and_pack")
+    return y, (xt, wt)
+
+
+def _lin_bwd(dy, packs, w, has_bias, scale=None, rows_per_scale=1, owners=(None, None), ld=None, row_div=1, cscale=1.0, rows=None, want_dx=True):
+    """Backward of y = x W^T + b from its output gradient: dx [M][Kp] (None unless want_dx), dW [N][Kp], db [N].  The gradient is `dy`, fp32
+    [M][N] contiguous - or, with ld, a DEVICE POINTER to rows of pitch ld floats of which row r / row_div is this Linear's row r (`rows` of
+    them) - times cscale, times its rows' factors (scale).  packs: (x^T fragments, W^T fragments) from `_lin_fwd`.  M % 128 == 0."""
+    xt, wt = packs
+    N = w.shape[0]
+    K = wt.numel() // (2 * N)                    # the padded width the forward ran at
+    if ld is None:
+        M, ptr_, ld = dy.shape[0], dy.data_ptr(), N
+        dev = dy.device
+    else:
+        M, ptr_, dev = rows, dy, w.device
+    lib, st = _lib.load(), _lib.current_stream(dev)
+    dyb = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    dybt = torch.empty(N, M, dtype=torch.bfloat16, device=dev)
+    part = torch.empty(M // 64, N, dtype=torch.float32, device=dev) if has_bias else None
+    _lib.check(lib.syn_linear_bwd_prep(ptr_, ld, row_div, float(cscale), M, N, _lib.ptr(scale), rows_per_scale, dyb.data_ptr(), dybt.data_ptr(), _lib.ptr(part),
+                                       st), "syn_linear_bwd_prep")
+    exact = K == w.shape[1]                      # (a zero-padded K: the weight gradient comes out padded and its columns are cut below)
+    dw = _grad_out(owners[0], (N, K)) if (owners[0] is not None and exact) else torch.empty(N, K, dtype=torch.float32, device=dev)
+    db = (_grad_out(owners[1], (N,)) if owners[1] is not None else torch.empty(N, dtype=torch.float32, device=dev)) if has_bias else None
+    dx = None
+    if want_dx:
+        dx = torch.empty(M, K, dtype=torch.float32, device=dev)
+        _lib.check(lib.syn_linear_pair(dyb.data_ptr(), wt.data_ptr(), M, K, N, dx.data_ptr(), dybt.data_ptr(), xt.data_ptr(), N, K, M, dw.data_ptr(),
+                                       _lib.ptr(part), M // 64, N, _lib.ptr(db), st), "syn_linear_pair")
+    else:
+        _lib.check(lib.syn_linear(dybt.data_ptr(), xt.data_ptr(), None, N, K, M, dw.data_ptr(), st), "syn_linear")
+        if has_bias:
+            _lib.check(lib.syn_colsum_parts(part.data_ptr(), M // 64, N, db.data_ptr(), st), "syn_colsum_parts")
+    if not exact:
+        dw = dw[:, :w.shape[1]].contiguous()
+    return dx, dw, db
 
 
 class HipLinearFn(torch.autograd.Function):
-    """y = x W^T + b with forward, dgrad and wgrad on syn_linear."""
+    """y = x W^T + b for x (..., K): forward, data gradient and weight gradient on the MFMA GEMM (bf16 operands, fp32 accumulate).
+    Up to 64 rows (the timestep MLP, embed_text: one row per clip) the weight / bias gradient is one fp32 launch (`syn_linear_wgrad_rows`)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
-        K = x.shape[-1]
-        xb = x.reshape(-1, K).to(torch.bfloat16)
-        pk, ctx.pack_t = _lookup_packs(w)
-        xt = None
-        if pk is not None and (b is None or (b.dtype is torch.float32 and b.is_contiguous())):
-            xb = xb.contiguous()
-            M = xb.shape[0]
-            y = torch.empty(M, w.shape[0], dtype=torch.float32, device=x.device)
-            if LINEAR_FWD_PACK and ctx.needs_input_grad[1] and K % 512 == 0 and M % 128 == 0 and M <= 2048:
-                # the weight gradient's B operand (x^T as fragments) packed in the shadow of this GEMM instead of by a launch in the backward
-                xt = torch.empty(K * M * 2, dtype=torch.uint8, device=x.device)
-                _lib.check(_lib.load().syn_linear_and_pack(xb.data_ptr(), pk.data_ptr(), _lib.ptr(b), M, w.shape[0], K, y.data_ptr(), xt.data_ptr(),
-                                                           _lib.current_stream(y.device)), "syn_linear_and_pack")
-            else:
-                _lib.check(_lib.load().syn_linear(xb.data_ptr(), pk.data_ptr(), _lib.ptr(b), M, w.shape[0], K, y.data_ptr(),
-                                                  _lib.current_stream(y.device)), "syn_linear")
+        engine._require_cuda(x, "Linear input")
+        N, K = w.shape
+        Kp = _ceil_to(K, 128)
+        pk, ctx.wt = _packs_of(w)
+        xb = _bf16_rows(x, K, Kp)
+        M = xb.shape[0]
+        bc = None if b is None else _f32c(b)
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        ctx.xt = None
+        lib, st = _lib.load(), _lib.current_stream(x.device)
+        if ctx.needs_input_grad[1] and M % 128 == 0 and M <= 2048:
+            # the weight gradient's B operand (x^T as fragments) packed in the shadow of this GEMM instead of by a launch in the backward
+            ctx.xt = torch.empty(Kp * M * 2, dtype=torch.uint8, device=x.device)
+            _lib.check(lib.syn_linear_and_pack(xb.data_ptr(), pk.data_ptr(), _lib.ptr(bc), M, N, Kp, y.data_ptr(), ctx.xt.data_ptr(), st), "syn_linear_and_pack")
         else:
-            y = hip_matmul_nt(xb, w, b)
-        ctx.xt = xt
+            _lib.check(lib.syn_linear(xb.data_ptr(), pk.data_ptr(), _lib.ptr(bc), M, N, Kp, y.data_ptr(), st), "syn_linear")
         ctx.save_for_backward(xb, w)
-        ctx.owners = (w, b)
-        ctx.has_bias = b is not None
-        ctx.in_shape = x.shape
-        return y.reshape(*x.shape[:-1], w.shape[0])
+        ctx.owners, ctx.has_bias, ctx.in_shape = (w, b), b is not None, x.shape
+        return y.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         xb, w = ctx.saved_tensors
         N, K = w.shape
-        M = xb.shape[0]
+        M, Kp = xb.shape
+        want_dx, want_dw, want_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dy2 = dy.reshape(-1, N)
-        dx = dw = db = dybt = None
-        if SMALL_M_WGRAD and 0 < M <= 64 and N % 16 == 0 and dy2.is_cuda and ctx.needs_input_grad[1] and w.dtype is torch.float32:
-            # a Linear that saw one row per clip (timestep MLP, embed_text): weight + bias gradient in ONE fp32 launch instead of the GEMM path's
-            # pads / transposes / packs around a nearly empty MFMA tile
-            dyc, xc = _f32c(dy2), xb.contiguous()
-            dw = _grad_out(ctx.owners[0], (N, K))
-            want_db = ctx.has_bias and ctx.needs_input_grad[2]
-            db = _grad_out(ctx.owners[1], (N,)) if want_db else None
-            _lib.check(_lib.load().syn_linear_wgrad_rows(dyc.data_ptr(), xc.data_ptr(), M, N, K, dw.data_ptr(), _lib.ptr(db), _lib.current_stream(dy.device)),
-                       "syn_linear_wgrad_rows")
-            if ctx.needs_input_grad[0]:
-                dyb = dyc.to(torch.bfloat16)
-                if K % 512 == 0 and N % 128 == 0 and w.is_contiguous():
-                    dx = _gemm_packed(dyb, ctx.pack_t if ctx.pack_t is not None else _pack_t(w, K, N), K, N).reshape(ctx.in_shape)
-                else:
-                    dx = hip_matmul_nt(dyb, w.t()).reshape(ctx.in_shape)
+        lib, st = _lib.load(), _lib.current_stream(dy.device)
+        if M <= 64:
+            dyc = _f32c(dy2)
+            dx = dw = db = None
+            if want_dw or want_db:
+                dw = _grad_out(ctx.owners[0], (N, K)) if Kp == K else torch.empty(N, Kp, dtype=torch.float32, device=dy.device)
+                db = _grad_out(ctx.owners[1], (N,)) if want_db else None
+                _lib.check(lib.syn_linear_wgrad_rows(dyc.data_ptr(), xb.data_ptr(), M, N, Kp, dw.data_ptr(), _lib.ptr(db), st), "syn_linear_wgrad_rows")
+                if Kp != K:
+                    dw = dw[:, :K].contiguous()
+                if not want_dw:
+                    dw = None
+            if want_dx:
+                dx = _gemm(dyc.to(torch.bfloat16), ctx.wt, Kp, N)[:, :K].reshape(ctx.in_shape)
             return dx, dw, db
-        pair = (LINEAR_BWD_PAIR and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and K % 512 == 0 and N % 128 == 0
-                and M % 128 == 0 and w.dtype is torch.float32 and w.is_contiguous() and xb.is_contiguous())
-        part = None
-        if LINEAR_BWD_PREP and M % 64 == 0 and N % 64 == 0 and dy2.dtype is torch.float32 and dy2.is_cuda:
-            # one pass over dy: bf16 copy, bf16 transpose (weight gradient) and the bias gradient's per-64-row partial sums
-            dy2 = dy2.contiguous()
-            dyb = torch.empty(M, N, dtype=torch.bfloat16, device=dy.device)
-            dybt = torch.empty(N, M, dtype=torch.bfloat16, device=dy.device)
-            want_db = ctx.has_bias and ctx.needs_input_grad[2] and LINEAR_BWD_PREP > 1
-            part = torch.empty(M // 64, N, dtype=torch.float32, device=dy.device) if want_db else None
-            in_launch = want_db and LINEAR_BWD_PREP > 2 and N // 64 <= 1024
-            if in_launch:
-                db = torch.empty(N, dtype=torch.float32, device=dy.device)
-            _lib.check(_lib.load().syn_linear_bwd_prep(dy2.data_ptr(), M, N, None, 0, None, dyb.data_ptr(), dybt.data_ptr(), _lib.ptr(part),
-                                                       _lib.ptr(_counters(dy.device)) if in_launch else None, _lib.ptr(db) if in_launch else None,
-                                                       _lib.current_stream(dy.device)), "syn_linear_bwd_prep")
-            if want_db and not in_launch and not (pair and M <= 2048):
-                db = part.sum(0)
+        # the GEMM pair works on 128-row tiles: other row counts (a batch that is not a multiple of 4 clips) are zero-padded by PyTorch ops
+        Mp = _ceil_to(M, 128)
+        xt = ctx.xt
+        if Mp != M:
+            src = F.pad(_f32c(dy2), (0, 0, 0, Mp - M))
+            xb, xt = F.pad(xb, (0, 0, 0, Mp - M)), None
+            ld = N
+        elif dy2.dtype is torch.float32 and dy2.stride(1) == 1 and dy2.stride(0) >= N and dy2.stride(0) % 4 == 0 and dy2.data_ptr() % 16 == 0:
+            src, ld = dy2, dy2.stride(0)                     # read in place (contiguous, or a column slice of a wider gradient)
         else:
-            dyb = dy2.to(torch.bfloat16).contiguous()
-        if pair and dybt is not None:
-            # dy . W and dy^T . x - independent, half a chip each - as one launch, which also adds the bias gradient's partial sums up
-            wt = ctx.pack_t if ctx.pack_t is not None else _pack_t(w, K, N)
-            dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
-            dw = _grad_out(ctx.owners[0], (N, K))
-            sum_here = part is not None and db is None
-            if sum_here:
-                db = _grad_out(ctx.owners[1], (N,))
-            _lib.check(_lib.load().syn_linear_pair(dyb.data_ptr(), wt.data_ptr(), M, K, N, dx.data_ptr(),
-                                                   dybt.data_ptr(), (ctx.xt if ctx.xt is not None else _pack_t(xb, K, M)).data_ptr(), N, K, M, dw.data_ptr(),
-                                                   _lib.ptr(part) if sum_here else None, M // 64, N, _lib.ptr(db) if sum_here else None,
-                                                   _lib.current_stream(dy.device)), "syn_linear_pair")
-            dx = dx.reshape(ctx.in_shape)
-            if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
-                db = dy2.sum(0)
-            return dx, dw.to(w.dtype), db
-        if part is not None and db is None:
-            db = part.sum(0)
-        if ctx.needs_input_grad[0]:
-            if K % 512 == 0 and N % 128 == 0 and w.dtype is torch.float32 and w.is_contiguous():
-                wt = ctx.pack_t if ctx.pack_t is not None else _pack_t(w, K, N)          # W^T: the step's pack, or packed in place
-                dx = _gemm_packed(dyb, wt, K, N).reshape(ctx.in_shape)                    # dy . W
-            else:
-                dx = hip_matmul_nt(dyb, w.t()).reshape(ctx.in_shape)
-        if ctx.needs_input_grad[1]:
-            if K % 512 == 0 and M % 128 == 0 and xb.is_contiguous():
-                dw = _gemm_packed(dybt if dybt is not None else dyb.t().contiguous(), _pack_t(xb, K, M), K, M).to(w.dtype)   # dy^T . x, x^T packed in place
-            else:
-                dw = hip_matmul_nt(dyb.t(), xb.t()).to(w.dtype)                    # contraction over tokens
-        if ctx.has_bias and ctx.needs_input_grad[2] and db is None:
-            db = dy2.sum(0)
-        return dx, dw, db
-
-
-class EmbeddingFn(torch.autograd.Function):
-    """nn.Embedding lookup (models/denoiser.py:72,147: the word ids in front of text_encoder_body) whose table gradient comes from
-    `syn_embedding_wgrad` - one deterministic launch - instead of PyTorch-ROCm's embedding_dense_backward (a chain of ~15 sort /
-    scan / segment launches, and the op that made the captured training step abort in the HIP runtime)."""
-
-    @staticmethod
-    def forward(ctx, ids, weight):
-        ctx.save_for_backward(ids)
-        ctx.wshape, ctx.wdtype = weight.shape, weight.dtype
-        ctx.owner = weight
-        return weight.detach()[ids]
-
-    @staticmethod
-    def backward(ctx, dy):
-        (ids,) = ctx.saved_tensors
-        V, D = ctx.wshape
-        idc = ids.reshape(-1).to(torch.int64).contiguous()
-        dyc = dy.reshape(-1, D).float().contiguous()
-        dw = _grad_out(ctx.owner, (V, D))
-        lib = _lib.load()
-        first = True
-        for lo in range(0, idc.numel(), 8192):                  # (the bench's 32 clips x 128 frames are one call)
-            n = min(8192, idc.numel() - lo)
-            tgt = dw if first else torch.empty_like(dw)
-            _lib.check(lib.syn_embedding_wgrad(idc[lo:].data_ptr(), dyc[lo:].data_ptr(), n, V, D, tgt.data_ptr(), _lib.current_stream(dy.device)),
-                       "syn_embedding_wgrad")
-            if not first:
-                dw += tgt
-            first = False
-        return None, dw.to(ctx.wdtype)
-
-
-def _embed(module: nn.Embedding, ids):
-    w = module.weight
-    if (w.is_cuda and w.requires_grad and torch.is_grad_enabled() and module.padding_idx is None and module.max_norm is None
-            and not _os.environ.get("SYN_TORCH_EMBEDDING_GRAD")):   # (set: PyTorch's op, to reproduce the captured step's abort)
-        return EmbeddingFn.apply(ids, w)
-    return module(ids)
-
-
-import os as _os
-SMALL_M_WGRAD = bool(int(_os.environ.get("SYN_SMALL_M_WGRAD", "1")))          # Linears with <= 64 input rows: weight / bias gradient on syn_linear_wgrad_rows
-LINEAR_FWD_PACK = bool(int(_os.environ.get("SYN_LINEAR_FWD_PACK", "1")))   # x^T fragments for the weight gradient from the forward GEMM's launch
-LINEAR_BWD_PAIR = bool(int(_os.environ.get("SYN_LINEAR_BWD_PAIR", "1")))   # a Linear's two backward GEMMs as one launch (syn_linear_pair)
-LINEAR_BWD_PREP = int(_os.environ.get("SYN_LINEAR_BWD_PREP", "2"))    # 0: PyTorch cast / transpose / sum; 1: fused cast + transpose (syn_linear_bwd_prep);
-                                                                      # 2: + per-64-row partial column sums from the same pass, the bias gradient = their (16-row) sum;
-                                                                      # 3: the bias gradient itself from that launch (last block of a column block adds the partial
-                                                                      #    sums) - correct (test_step_weight_packs_and_in_launch_bias_gradient) but 21 us per launch
-                                                                      #    against 4 + 4: the agent-scope release in front of the arrival counter writes the XCD's L2 back.
-                                                                      # (2 and 3 used to abort the captured bench-size step: that was PyTorch-ROCm's
-                                                                      #  embedding_dense_backward inside the graph, not these - see EmbeddingFn and DESIGN.md 7)
+            src, ld = _f32c(dy2), N
+        if xt is None:
+            xt = _pack_t(xb, Kp, Mp)
+        dx, dw, db = _lin_bwd(src.data_ptr(), (xt, ctx.wt), w, want_db, owners=ctx.owners, ld=ld, rows=Mp, want_dx=want_dx)
+        if dx is not None:
+            dx = dx[:M, :K].reshape(ctx.in_shape)
+        return dx, (dw if want_dw else None), db
 
 
 def lin(x, module: nn.Linear):
     return HipLinearFn.apply(x, module.weight, module.bias)
 
 
-# (the fp32 block ops - LayerNorm, attention, GELU - run on the hand-written kernels below; their PyTorch-op twins live in
-# tests/test_gpu_kernels.py::test_training_block_ops_vs_torch_autograd, which checks them against each other to 1e-5)
-
-
-def _grad_out(param, shape=None):
-    """The tensor a parameter's gradient is written into.  Normally a fresh buffer.  When the parameter carries a bound gradient buffer
-    (`bind_grad_buffers`: DDP's bucket view of it, inside `GraphedTrainStep`) and holds no gradient yet, a NEW tensor object over that
-    buffer: autograd's AccumulateGrad adopts it without a copy, and DDP's reducer, finding the gradient already inside its bucket, skips its
-    per-parameter copy-and-divide launch (169 launches of ~2 us per step; the division moves into the collective, `_avg_comm_hook`)."""
-    shape = tuple(shape if shape is not None else param.shape)
-    buf = getattr(param, "_syn_grad_buf", None) if param is not None else None
-    if (buf is not None and param.grad is None and buf.dtype is torch.float32 and buf.is_contiguous() and buf.numel() == math.prod(shape)
-            and torch.is_grad_enabled() is False and not getattr(param, "_syn_grad_handed", False)):
-        # handed out ONCE per backward: a parameter used by two nodes of one backward (tied weights, a module applied twice) gets a fresh
-        # tensor the second time, which autograd accumulates as usual (cleared by `_reset_handed` at the top of the next step)
-        param._syn_grad_handed = True
-        return buf.view(shape)
-    dev = param.device if param is not None else None
-    return torch.empty(shape, dtype=torch.float32, device=dev)
-
-
-def _into_bound_buffers(grads, owners):
-    """The small per-channel gradients of a block (BatchNorm gains / shifts, the convolution biases' zeros) come out of the kernels as rows of
-    [3][C] tensors.  Where their parameters carry bound gradient buffers (DDP's bucket views, `_grad_out`) they are moved there in ONE
-    multi-tensor launch per block and the bound tensors are returned in their place: the reducer, finding a gradient already inside its
-    bucket, skips its own copy - which is a hipMemcpyAsync node of ~4 us per parameter in the captured step (48 of them: 0.2 ms, the whole
-    difference between the DDP-wrapped and the plain step of round 5).  Without bound buffers nothing happens."""
-    dst, src, at = [], [], []
-    for i, (g, p) in enumerate(zip(grads, owners)):
-        if g is None or p is None or getattr(p, "_syn_grad_buf", None) is None:
-            continue
-        t = _grad_out(p, g.shape)
-        if t.data_ptr() == p._syn_grad_buf.data_ptr():        # (a fresh tensor otherwise: handed out already, or the parameter still holds a gradient)
-            dst.append(t); src.append(g); at.append(i)
-    if dst:
-        torch._foreach_copy_(dst, src)
-        for i, t in zip(at, dst):
-            grads[i] = t
-
-
-def bind_grad_buffers(model) -> int:
-    """Make the CURRENT gradient tensors of the model's parameters the buffers their next gradients are written into (see `_grad_out`).
-    Under `make_ddp(..., capturable=True)` those are views of the reducer's buckets once it has rebuilt them (after its second iteration).
-    Only valid while every step starts from `zero_grad(set_to_none=True)` - `GraphedTrainStep` - since a bound buffer is overwritten, not
-    accumulated into (a parameter that still holds a gradient is never given its bound buffer).  Returns the number of parameters bound."""
-    n = 0
-    for p in model.parameters():
-        g = p.grad
-        if g is not None and g.dtype is torch.float32 and g.is_contiguous() and g.shape == p.shape:
-            p._syn_grad_buf = g
-            n += 1
-    return n
-
-
-def direct_grad_report(model):
-    """(gradients the last backward wrote straight into their bound buffers, parameters with a bound buffer, names of the others - those
-    the DDP reducer still copies into its buckets, one memcpy node each in the captured step)."""
-    bound = [(n, p) for n, p in model.named_parameters() if getattr(p, "_syn_grad_buf", None) is not None]
-    rest = [n for n, p in bound if not getattr(p, "_syn_grad_handed", False)]
-    return len(bound) - len(rest), len(bound), rest
-
-
-def unbind_grad_buffers(model):
-    for p in model.parameters():
-        if hasattr(p, "_syn_grad_buf"):
-            del p._syn_grad_buf
-        if hasattr(p, "_syn_grad_handed"):
-            del p._syn_grad_handed
-
-
-def _reset_handed(model):
-    """Start of a step: every bound gradient buffer may be handed out again (`_grad_out`)."""
-    for p in model.parameters():
-        if getattr(p, "_syn_grad_handed", False):
-            p._syn_grad_handed = False
-
-
-def _f32c(t):
-    t = t.detach()
-    if t.dtype is not torch.float32:
-        t = t.float()
-    return t if t.is_contiguous() else t.contiguous()
-
+# ---- the fp32 block ops as autograd nodes of their own ---------------------------------------------------------------------------------------
+# LayerNorm, the 32-token attention and GELU on the kernels the fused branches below are built from.  The product path runs the fused nodes;
+# these are what tests/test_gpu_kernels.py composes the op-by-op reference of a branch from (and checks against PyTorch's own ops to 1e-5).
 
 class HipLayerNormFn(torch.autograd.Function):
     """nn.LayerNorm(512, eps 1e-5): fp32 forward / backward kernels (syn_ln_fwd / syn_ln_bwd)."""
@@ -462,8 +335,7 @@ class HipLayerNormFn(torch.autograd.Function):
 
 class HipLnForkFn(torch.autograd.Function):
     """A pre-LN residual block's entry (transformer.py:195-198: x + f(norm(x))): returns (LayerNorm(x), x).  x feeds both the
-    norm and the residual add, and autograd would add the two gradients with a copy and an in-place add per block half; here the
-    residual path's gradient goes into the LayerNorm backward kernel as its addend - one gradient for x, no extra launch."""
+    norm and the residual add; the residual path's gradient goes into the LayerNorm backward kernel as its addend."""
 
     @staticmethod
     def forward(ctx, x, g, b):
@@ -521,79 +393,16 @@ class HipAttentionFn(torch.autograd.Function):
 
 
 # ---- a pre-LN residual branch as ONE autograd node ---------------------------------------------------------------------------
-# x + drop_path(attn(norm1(x))) and x + drop_path(mlp(norm2(x))) (timm_transformer/transformer.py:195-198).  Built from the ops above
-# these are 7 / 6 autograd nodes per branch with PyTorch glue between them - a bf16 cast in front of every Linear, addcmul for the
-# DropPath factor and its mul in the backward, a sum for every bias gradient, copies where a gradient is not contiguous: ~25 launches
-# of 3-5 us per branch and direction around kernels that run 5-15 us.  As one node the branch is the kernels and nothing else:
+# x + drop_path(attn(norm1(x))) and x + drop_path(mlp(norm2(x))) (timm_transformer/transformer.py:195-198):
 #   forward   LayerNorm -> bf16 rows | GEMM (+ x^T pack; fc1: + GELU -> bf16) | attention -> bf16 | GEMM with `x + factor * (.)` in its epilogue
-#   backward  prep (factor * dy -> bf16, bf16^T, bias partials) | GEMM pair (+ bias sum) | attention backward | prep (fc1: x GELU') | GEMM pair |
+#   backward  prep (factor * dy -> bf16, bf16^T, bias partials) | GEMM pair (+ bias sum) | attention backward | GELU' | prep | GEMM pair |
 #             LayerNorm backward with dy as its addend (the residual path)
 # The fp32 LayerNorm / attention / GELU outputs are never written: the Linear behind each takes bf16 operands and nothing else reads them.
-BLOCK_FUSED = bool(int(_os.environ.get("SYN_TRAIN_BLOCK_FUSED", "1")))
-GELU_FUSED = int(_os.environ.get("SYN_TRAIN_GELU_FUSED", "1"))         # bit 0: GELU in fc1's epilogue (-0.1 ms per step); bit 1: GELU' in the backward's
-                                                                       # operand pass (same-box A/B: no gain - erf + exp in the transposing pass cost what the launch did)
-
+# Batches of more than 64 clips run the blocks as these nodes; up to 64 the persistent `StackFn` below.
 
 def engine_has_xcd_groups(device) -> bool:
     """The tile-split kernels deal the workgroups of an XCD by hardware id: 256 CUs in 8 XCDs of 32 (MI355X)."""
     return torch.cuda.get_device_properties(device).multi_processor_count == 256
-
-
-def _fused_ok(M, *layers) -> bool:
-    """Every Linear of the branch has its step packs (W and W^T fragments) and the GEMM pair's shape constraints hold."""
-    if not (BLOCK_FUSED and M % 128 == 0):
-        return False
-    for l in layers:
-        pk, tr = _lookup_packs(l.weight)
-        if pk is None or tr is None or l.weight.shape[1] % 512 or l.weight.shape[0] % 128:
-            return False
-        if l.bias is not None and not (l.bias.dtype is torch.float32 and l.bias.is_contiguous()):
-            return False
-    return True
-
-
-def _lin_fwd(xb, w, b, res=None, scale=None, rows_per_scale=1, gelu_out=None):
-    """bf16 rows [M][K] -> fp32 [M][N] = x W^T + b, or res + scale[row // rows_per_scale] * (x W^T + b); also the x^T fragments the
-    weight-gradient GEMM will take (packed by the same launch while M <= 2048)."""
-    pk, wt = _lookup_packs(w)
-    M, K = xb.shape
-    N = w.shape[0]
-    y = torch.empty(M, N, dtype=torch.float32, device=xb.device)
-    xt = torch.empty(K * M * 2, dtype=torch.uint8, device=xb.device)
-    lib, st = _lib.load(), _lib.current_stream(xb.device)
-    if gelu_out is not None:                   # fc1: y stays fp32 for the backward, gelu_out receives bf16(GELU(y)) - fc2's operand
-        _lib.check(lib.syn_linear_gelu(xb.data_ptr(), pk.data_ptr(), _lib.ptr(b), M, N, K, y.data_ptr(), gelu_out.data_ptr(), xt.data_ptr(), st),
-                   "syn_linear_gelu")
-    elif res is not None:
-        _lib.check(lib.syn_linear_res(xb.data_ptr(), pk.data_ptr(), _lib.ptr(b), res.data_ptr(), _lib.ptr(scale), rows_per_scale, M, N, K,
-                                      y.data_ptr(), xt.data_ptr(), st), "syn_linear_res")
-    else:
-        _lib.check(lib.syn_linear_and_pack(xb.data_ptr(), pk.data_ptr(), _lib.ptr(b), M, N, K, y.data_ptr(), xt.data_ptr(), st), "syn_linear_and_pack")
-    return y, (xt, wt)          # what the backward takes: x^T and W^T fragments as of THIS forward (the step's pack cache may have moved on by then)
-
-
-def _lin_bwd(dy2, packs, w, has_bias, scale=None, rows_per_scale=1, gelu_pre=None, owners=(None, None)):
-    """fp32 dy [M][N] (contiguous) -> dx [M][K], dW [N][K], db [N] of y = x W^T + b; dy is first multiplied by its rows' factors
-    (scale) or by GELU'(gelu_pre) (dy taken behind a GELU of y).  packs: (x^T fragments, W^T fragments) from `_lin_fwd`."""
-    xt, wt = packs
-    M, N = dy2.shape
-    K = w.shape[1]
-    dev = dy2.device
-    lib, st = _lib.load(), _lib.current_stream(dev)
-    dyb = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    dybt = torch.empty(N, M, dtype=torch.bfloat16, device=dev)
-    part = torch.empty(M // 64, N, dtype=torch.float32, device=dev) if has_bias else None
-    _lib.check(lib.syn_linear_bwd_prep(dy2.data_ptr(), M, N, _lib.ptr(scale), rows_per_scale, _lib.ptr(gelu_pre), dyb.data_ptr(), dybt.data_ptr(), _lib.ptr(part),
-                                       None, None, st), "syn_linear_bwd_prep")
-    dx = torch.empty(M, K, dtype=torch.float32, device=dev)
-    dw = _grad_out(owners[0], (N, K)) if owners[0] is not None else torch.empty(N, K, dtype=torch.float32, device=dev)
-    in_pair = has_bias and M <= 2048
-    db = (_grad_out(owners[1], (N,)) if owners[1] is not None else torch.empty(N, dtype=torch.float32, device=dev)) if in_pair else None
-    _lib.check(lib.syn_linear_pair(dyb.data_ptr(), wt.data_ptr(), M, K, N, dx.data_ptr(), dybt.data_ptr(), xt.data_ptr(), N, K, M, dw.data_ptr(),
-                                   _lib.ptr(part) if in_pair else None, M // 64, N, _lib.ptr(db), st), "syn_linear_pair")
-    if has_bias and db is None:
-        db = part.sum(0)
-    return dx, dw, db
 
 
 def _ln_rows_bf16(hc, g, b):
@@ -617,7 +426,7 @@ def _ln_bwd_rows(dz, hc, g, mean, rstd, add, owners=(None, None)):
 
 
 class AttnBranchFn(torch.autograd.Function):
-    """h + factor * proj(attention(qkv(LayerNorm(h)))) for h (B, 32, 512); factor (B, 1, 1) or None."""
+    """h + factor * proj(attention(qkv(LayerNorm(h)))) for h (B, 32, 512), B % 4 == 0; factor (B, 1, 1) or None."""
 
     @staticmethod
     def forward(ctx, h, g, b, wqkv, bqkv, wproj, bproj, factor):
@@ -638,26 +447,19 @@ class AttnBranchFn(torch.autograd.Function):
     def backward(ctx, dout):
         hc, gc, mean, rstd, qkv, wqkv, wproj, factor = ctx.saved_tensors
         B, T, _ = hc.shape
-        dh, dg, db, dwq, dbq, dwp, dbp = _attn_branch_bwd(_f32c(dout).view(B * T, 512), hc, gc, mean, rstd, qkv, wqkv, wproj, factor, ctx.packs, ctx.bias,
-                                                          ctx.owners)
+        xt1, xt2 = ctx.packs
+        og, ob, owq, obq, owp, obp = ctx.owners
+        d = _f32c(dout).view(B * T, 512)
+        do, dwp, dbp = _lin_bwd(d, xt2, wproj, ctx.bias[1], factor, T, owners=(owp, obp))
+        dqkv = torch.empty_like(qkv)
+        _lib.check(_lib.load().syn_attn_bwd(qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), B, _lib.current_stream(d.device)), "syn_attn_bwd")
+        dz, dwq, dbq = _lin_bwd(dqkv.view(B * T, -1), xt1, wqkv, ctx.bias[0], owners=(owq, obq))
+        dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d, owners=(og, ob))
         return dh.view(B, T, 512), dg, db, dwq, dbq, dwp, dbp, None
 
 
-def _attn_branch_bwd(d, hc, gc, mean, rstd, qkv, wqkv, wproj, factor, packs, bias, owners):
-    """Backward of h + factor * proj(attention(qkv(LayerNorm(h)))) from d = the gradient at its output, (B * 32, 512) fp32 contiguous."""
-    xt1, xt2 = packs
-    B, T = hc.shape[0], hc.shape[1]
-    og, ob, owq, obq, owp, obp = owners
-    do, dwp, dbp = _lin_bwd(d, xt2, wproj, bias[1], factor, T, owners=(owp, obp))
-    dqkv = torch.empty_like(qkv)
-    _lib.check(_lib.load().syn_attn_bwd(qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), B, _lib.current_stream(d.device)), "syn_attn_bwd")
-    dz, dwq, dbq = _lin_bwd(dqkv.view(B * T, -1), xt1, wqkv, bias[0], owners=(owq, obq))
-    dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d, owners=(og, ob))
-    return dh, dg, db, dwq, dbq, dwp, dbp
-
-
 class MlpBranchFn(torch.autograd.Function):
-    """h + factor * fc2(GELU(fc1(LayerNorm(h))))."""
+    """h + factor * fc2(GELU(fc1(LayerNorm(h)))), GELU in fc1's epilogue."""
 
     @staticmethod
     def forward(ctx, h, g, b, w1, b1, w2, b2, factor):
@@ -665,11 +467,7 @@ class MlpBranchFn(torch.autograd.Function):
         B, T, _ = hc.shape
         zb, mean, rstd = _ln_rows_bf16(hc, gc, bc)
         ab = torch.empty(B * T, w1.shape[0], dtype=torch.bfloat16, device=hc.device)
-        if GELU_FUSED & 1:
-            pre, xt1 = _lin_fwd(zb, w1, b1, gelu_out=ab)                 # GELU in fc1's epilogue
-        else:
-            pre, xt1 = _lin_fwd(zb, w1, b1)
-            _lib.check(_lib.load().syn_gelu_fwd(pre.data_ptr(), None, ab.data_ptr(), pre.numel(), _lib.current_stream(hc.device)), "syn_gelu_fwd")
+        pre, xt1 = _lin_fwd(zb, w1, b1, gelu_out=ab)
         out, xt2 = _lin_fwd(ab, w2, b2, hc, factor, T)
         ctx.save_for_backward(hc, gc, mean, rstd, pre, w1, w2, factor)
         ctx.packs = (xt1, xt2)
@@ -681,46 +479,31 @@ class MlpBranchFn(torch.autograd.Function):
     def backward(ctx, dout):
         hc, gc, mean, rstd, pre, w1, w2, factor = ctx.saved_tensors
         B, T, _ = hc.shape
-        dh, dg, db, dw1, db1, dw2, db2 = _mlp_branch_bwd(_f32c(dout).view(B * T, 512), hc, gc, mean, rstd, pre, w1, w2, factor, ctx.packs, ctx.bias, ctx.owners)
+        xt1, xt2 = ctx.packs
+        og, ob, ow1, ob1, ow2, ob2 = ctx.owners
+        d = _f32c(dout).view(B * T, 512)
+        da, dw2, db2 = _lin_bwd(d, xt2, w2, ctx.bias[1], factor, T, owners=(ow2, ob2))
+        dpre = torch.empty_like(pre)
+        _lib.check(_lib.load().syn_gelu_bwd(pre.data_ptr(), da.data_ptr(), dpre.data_ptr(), pre.numel(), _lib.current_stream(d.device)), "syn_gelu_bwd")
+        dz, dw1, db1 = _lin_bwd(dpre, xt1, w1, ctx.bias[0], owners=(ow1, ob1))
+        dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d, owners=(og, ob))
         return dh.view(B, T, 512), dg, db, dw1, db1, dw2, db2, None
 
 
-def _mlp_branch_bwd(d, hc, gc, mean, rstd, pre, w1, w2, factor, packs, bias, owners):
-    """Backward of h + factor * fc2(GELU(fc1(LayerNorm(h)))) from d = the gradient at its output, (B * 32, 512) fp32 contiguous."""
-    xt1, xt2 = packs
-    T = hc.shape[1]
-    og, ob, ow1, ob1, ow2, ob2 = owners
-    da, dw2, db2 = _lin_bwd(d, xt2, w2, bias[1], factor, T, owners=(ow2, ob2))
-    if GELU_FUSED & 2:
-        dz, dw1, db1 = _lin_bwd(da, xt1, w1, bias[0], gelu_pre=pre, owners=(ow1, ob1))    # GELU' in the operand pass of fc1's backward
-    else:
-        dpre = torch.empty_like(pre)
-        _lib.check(_lib.load().syn_gelu_bwd(pre.data_ptr(), da.data_ptr(), dpre.data_ptr(), pre.numel(), _lib.current_stream(d.device)), "syn_gelu_bwd")
-        dz, dw1, db1 = _lin_bwd(dpre, xt1, w1, bias[0], owners=(ow1, ob1))
-    dh, dg, db = _ln_bwd_rows(dz, hc, gc, mean, rstd, d, owners=(og, ob))
-    return dh, dg, db, dw1, db1, dw2, db2
+def _blocks_ok(m) -> bool:
+    """The reference's block geometry (timm_transformer/transformer.py:154-198 as models/denoiser.py:94-98 builds it): what the fused nodes implement."""
+    for blk in m.mytimmblocks:
+        if blk.attn.qkv.bias is not None or blk.attn.proj.bias is None or blk.mlp.fc1.bias is None or blk.mlp.fc2.bias is None:
+            return False
+        if (tuple(blk.attn.qkv.weight.shape), tuple(blk.attn.proj.weight.shape), tuple(blk.mlp.fc1.weight.shape), tuple(blk.mlp.fc2.weight.shape)) != \
+                ((1536, 512), (512, 512), (1024, 512), (512, 1024)):
+            return False
+    return True
 
 
-# ---- the eight blocks' forward as ONE persistent launch (round 5) ------------------------------------------------------------------------------
-# `syn_train_stack_fwd` (csrc/syn_stack_train.inc): the sampling path's whole-step kernel in its tile-split mode, writing what the branch
-# backwards above take.  56 launches at their latency floor (0.55 ms at 32 clips) become one; the backward is the per-branch chain unchanged.
-PACK_BLOCKS_LATE = bool(int(_os.environ.get("SYN_TRAIN_PACK_BLOCKS_LATE", "1")))     # (A/B: 0 = all Linears packed at the top of the forward)
-STACK_FUSED = bool(int(_os.environ.get("SYN_TRAIN_STACK_FUSED", "1")))
-STACK_BWD_PIECES = int(_os.environ.get("SYN_TRAIN_STACK_BWD_PIECES", "1"))        # the backward chain in this many launches, the finished pieces' weight-gradient GEMMs on a
-                                                                                 # second stream.  Measured (one box, captured step): 1 -> 5.25 ms, 2 -> 5.28, 4 -> 5.27, 8 -> 5.42: the replayed
-                                                                                 # graph does not run the GEMMs beside the chain (as the side-stream weight gradients of round 4): default 1
-_side_streams = {}
-
-
-def _side_stream(device):
-    s = _side_streams.get(device)
-    if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device=device)
-    return s
-
-
-STACK_BWD_PREFETCH = bool(int(_os.environ.get("SYN_TRAIN_STACK_BWD_PREFETCH", "1")))
-STACK_BWD_FUSED = bool(int(_os.environ.get("SYN_TRAIN_STACK_BWD_FUSED", "1")))   # (A/B: 0 = the per-branch backward chain behind the persistent forward)       # (A/B: 0 = one autograd node per residual branch, `AttnBranchFn` / `MlpBranchFn`)
+# ---- the eight blocks as two persistent launches (csrc/syn_stack_train.inc) -----------------------------------------------------------------------
+# `syn_train_stack_fwd`: the sampling path's whole-step kernel in its tile-split mode, writing what the backward takes; `syn_train_stack_bwd`: the
+# data-gradient chain as one launch; `syn_train_stack_wgrad`: the 32 weight-gradient GEMMs four per launch.  4 | batch <= 64 clips on a 256-CU device.
 _stack_ws = {}
 
 
@@ -731,8 +514,29 @@ def _stack_workspace(device, n_seq):
     return ws
 
 
+def stack_sync_flag(device):
+    """The persistent block kernels' sticky error flag (int32 device tensor of one element), or None if they never ran on `device`.  Their XCD-local
+    barrier waits are bounded (`lat::group_wait`); a wait that ran out - CUs taken by another kernel - sets the flag and the kernel carries on with
+    whatever partial sums it found.  The loss kernel turns every loss into NaN while the flag is set (`MaskedSmoothL1Fn`), `check_stack_sync` raises."""
+    ws = _stack_ws.get(torch.device(device))
+    return None if ws is None else ws[0][256:257]
+
+
+def check_stack_sync(device=None):
+    """Host check of the persistent block kernels' barrier flag (a device read: call it once per N steps or after a graph replay, not per launch).
+    Raises SynHipError and clears the flag."""
+    for dev, ws in list(_stack_ws.items()):
+        if device is not None and torch.device(device) != dev:
+            continue
+        flag = int(ws[0][256].item())
+        if flag:
+            ws[0].zero_()
+            raise _lib.SynHipError(f"persistent block kernels on {dev}: an XCD-local barrier wait ran out (flag {flag}) - activations / gradients of the "
+                                   "steps since are wrong; is another kernel occupying CUs of this device?")
+
+
 class StackFn(torch.autograd.Function):
-    """mytimmblocks[0..7] on h (B, 32, 512), B <= 64; dp: DropPath factors (16, B, 1, 1) or None; params: per block norm1.weight, norm1.bias,
+    """mytimmblocks[0..7] on h (B, 32, 512), 4 | B <= 64; dp: DropPath factors (16, B, 1, 1) or None; params: per block norm1.weight, norm1.bias,
     attn.qkv.weight, attn.proj.weight, attn.proj.bias, norm2.weight, norm2.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias."""
 
     NP = 11
@@ -757,9 +561,7 @@ class StackFn(torch.autograd.Function):
         for l in range(len(params) // NP):
             g1, b1, wq, wp, bp, g2, b2, w1, bb1, w2, bb2 = params[l * NP:(l + 1) * NP]
             L = a.layer[l]
-            fr = [_lookup_packs(w) for w in (wq, wp, w1, w2)]
-            if any(f[0] is None or f[1] is None for f in fr):
-                raise _lib.SynHipError("StackFn: every Linear of the blocks needs its step packs (training.WeightPacks)")
+            fr = [_packs_of(w) for w in (wq, wp, w1, w2)]
             vecs = [_f32c(v) for v in (g1, b1, bp, g2, b2, bb1, bb2)]
             keep += vecs
             L.ln1_g, L.ln1_b, L.b_proj, L.ln2_g, L.ln2_b, L.b_fc1, L.b_fc2 = (v.data_ptr() for v in vecs)
@@ -771,12 +573,11 @@ class StackFn(torch.autograd.Function):
             saves.append(sv)
             packs.append(tuple(f[1] for f in fr))            # W^T fragment sets as of this forward (qkv, proj, fc1, fc2)
         _lib.check(lib.syn_train_stack_fwd(C.byref(a), _lib.current_stream(dev)), "syn_train_stack_fwd")
-        ctx.saves, ctx.packs, ctx.dp, ctx.params, ctx.keep, ctx.fwd = saves, packs, dpc, params, keep, a
+        ctx.saves, ctx.packs, ctx.params, ctx.keep, ctx.fwd = saves, packs, params, keep, a
         return out
 
     @staticmethod
-    def _backward_persistent(ctx, dout):
-        """The data-gradient chain as one launch (`syn_train_stack_bwd`), then the 32 weight-gradient GEMMs four per launch (`syn_train_stack_wgrad`)."""
+    def backward(ctx, dout):
         lib = _lib.load()
         params, NP = ctx.params, StackFn.NP
         d = _f32c(dout)
@@ -789,7 +590,8 @@ class StackFn(torch.autograd.Function):
         g.dh_out, g.dh_in, g.stash = d.data_ptr(), dh_in.data_ptr(), stash.data_ptr()
         bf = lambda n: torch.empty(n, M, dtype=torch.bfloat16, device=dev)
         keep, grads = [d, stash], [None] * len(params)
-        for l in range(len(params) // NP):
+        n_blk = len(params) // NP
+        for l in range(n_blk):
             g1, b1, wq, wp, bp, g2, b2, w1, bb1, w2, bb2 = params[l * NP:(l + 1) * NP]
             tq, tp_, t1, t2 = ctx.packs[l]
             L = g.layer_t[l]
@@ -808,150 +610,212 @@ class StackFn(torch.autograd.Function):
             keep += [gains, [ten[k] for k in ("dyt_fc2", "dyt_fc1", "dyt_proj", "dyt_qkv", "part")]]
             grads[l * NP:(l + 1) * NP] = [ten["d_ln1_g"], ten["d_ln1_b"], ten["dw_qkv"], ten["dw_proj"], ten["d_proj_b"], ten["d_ln2_g"], ten["d_ln2_b"],
                                           ten["dw_fc1"], ten["d_fc1_b"], ten["dw_fc2"], ten["d_fc2_b"]]
-        if STACK_BWD_PREFETCH and _packs_blocks is not None:
-            ctx_pf = _packs_blocks.prefetch(True)              # (the transposed sets were packed in front of the forward; 150 MB of saved tensors went by since)
-        # The chain occupies half the chip (32 sequences x 4 workgroups on 256 CUs) and the weight-gradient GEMMs of a block need nothing but that block's
-        # piece of it: the chain goes out in STACK_BWD_PIECES pieces on this stream, and the GEMMs of a finished piece on a second stream beside the next
-        # piece (a fork / join in the captured graph).
-        n_blk = len(params) // NP
-        pieces = max(1, min(STACK_BWD_PIECES, n_blk))
-        per = -(-n_blk // pieces)
-        main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if pieces > 1 else main
-        cur, hi = d, n_blk - 1
-        while hi >= 0:
-            lo = max(0, hi - per + 1)
-            nxt = dh_in if lo == 0 else torch.empty(B, T, 512, dtype=torch.float32, device=dev)
-            g.dh_out, g.dh_in, g.first_block, g.last_block = cur.data_ptr(), nxt.data_ptr(), hi, lo
-            _lib.check(lib.syn_train_stack_bwd(C.byref(g), main.cuda_stream), "syn_train_stack_bwd")
-            if side is not main:
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-            _lib.check(lib.syn_train_stack_wgrad(C.byref(g), side.cuda_stream), "syn_train_stack_wgrad")
-            keep.append(cur)
-            cur, hi = nxt, lo - 1
-        if side is not main:
-            main.wait_stream(side)
+        if _packs_blocks is not None:
+            _packs_blocks.prefetch(True)                   # (the transposed sets were packed in front of the forward; 150 MB of saved tensors went by since)
+        st = _lib.current_stream(dev)
+        g.first_block, g.last_block = n_blk - 1, 0
+        _lib.check(lib.syn_train_stack_bwd(C.byref(g), st), "syn_train_stack_bwd")
+        _lib.check(lib.syn_train_stack_wgrad(C.byref(g), st), "syn_train_stack_wgrad")
         del ten, keep                             # (stream-ordered allocator: the launches above are enqueued, later work on this stream comes after them)
         return (dh_in, None, *grads)
 
-    @staticmethod
-    def backward(ctx, dout):
-        if STACK_BWD_FUSED and dout.shape[0] % 4 == 0:
-            return StackFn._backward_persistent(ctx, dout)
-        params, NP = ctx.params, StackFn.NP
-        n = len(params) // NP
-        d = _f32c(dout)
-        B, T, _ = d.shape
-        d = d.view(B * T, 512)
-        grads = [None] * len(params)
-        for l in reversed(range(n)):
-            g1, b1, wq, wp, bp, g2, b2, w1, bb1, w2, bb2 = params[l * NP:(l + 1) * NP]
-            sv, (tq, tp_, t1, t2) = ctx.saves[l], ctx.packs[l]
-            fa = None if ctx.dp is None else ctx.dp[2 * l]
-            fm = None if ctx.dp is None else ctx.dp[2 * l + 1]
-            d, dg2, db2, dw1, dbb1, dw2, dbb2 = _mlp_branch_bwd(d, sv["h_mlp"], _f32c(g2), sv["mean_mlp"], sv["rstd_mlp"], sv["pre"], w1, w2, fm,
-                                                                  ((sv["xt_ln2"], t1), (sv["xt_gelu"], t2)), (True, True), (g2, b2, w1, bb1, w2, bb2))
-            d = d.view(B * T, 512)
-            d, dg1, db1, dwq, _, dwp, dbp = _attn_branch_bwd(d, sv["h_attn"], _f32c(g1), sv["mean_attn"], sv["rstd_attn"], sv["qkv"], wq, wp, fa,
-                                                             ((sv["xt_ln1"], tq), (sv["xt_attn"], tp_)), (False, True), (g1, b1, wq, None, wp, bp))
-            d = d.view(B * T, 512)
-            grads[l * NP:(l + 1) * NP] = [dg1, db1, dwq, dwp, dbp, dg2, db2, dw1, dbb1, dw2, dbb2]
-        return (d.view(B, T, 512), None, *grads)
+
+def _stack_ok(m, bs, T, device) -> bool:
+    return T == 32 and bs % 4 == 0 and 4 <= bs <= 64 and len(m.mytimmblocks) == 8 and engine_has_xcd_groups(device)
 
 
-def _stack_ok(m, bs, T) -> bool:
-    if not (STACK_FUSED and torch.is_grad_enabled() and T == 32 and 1 <= bs <= 64 and len(m.mytimmblocks) == 8):
-        return False
-    for blk in m.mytimmblocks:
-        if blk.attn.qkv.bias is not None or blk.attn.proj.bias is None or blk.mlp.fc1.bias is None or blk.mlp.fc2.bias is None:
-            return False
-        if not _fused_ok(bs * T, blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
-            return False
-        if (tuple(blk.attn.qkv.weight.shape), tuple(blk.mlp.fc1.weight.shape)) != ((1536, 512), (1024, 512)):
-            return False
-    return True
-
-
+# ---- the loss ------------------------------------------------------------------------------------------------------------------------------------
 class MaskedSmoothL1Fn(torch.autograd.Function):
-    """`masked_l2` of the reference's training_losses (gaussian_diffusion.py:202-215: SmoothL1 x mask, summed per sample, / (sum(mask) x C)) with its
-    gradient from the same launch (`syn_masked_smooth_l1`): (target, out (B, C, 1, T), mask (B, 1, 1, T) bool) -> (B,)."""
+    """`masked_l2` of the reference's training_losses (gaussian_diffusion.py:202-215: SmoothL1 x mask, summed per sample, / (sum(mask) x C)):
+    (target, out (B, C, 1, T), mask (B, 1, 1, T) bool) -> (B,).  `out` is read where the output Linear left it - as (B, C, 1, T), or as the
+    [B][T][C] rows that `train_forward`'s result is a permuted view of - and the gradient, with the incoming per-sample factors folded in, is
+    written the same way by one pass in the backward: neither direction materialises a permuted copy."""
 
     @staticmethod
     def forward(ctx, target, out, mask):
-        B = out.shape[0]
-        T = out.shape[-1]
-        tc, oc = _f32c(target), _f32c(out)
-        mk = mask.detach().reshape(B, T).to(torch.uint8).contiguous()
+        B, Cc, _, T = out.shape
+        rows = _is_rows_view(out)
+        oc = out.detach() if (rows or out.is_contiguous()) else out.detach().contiguous()
+        tc = _f32c(target)
+        mk = mask.detach().reshape(B, T).contiguous().view(torch.uint8)
         loss = torch.empty(B, dtype=torch.float32, device=out.device)
-        dout = torch.empty_like(oc)
-        _lib.check(_lib.load().syn_masked_smooth_l1(tc.data_ptr(), oc.data_ptr(), mk.data_ptr(), B, oc.numel() // B, T, loss.data_ptr(), dout.data_ptr(),
-                                                    _lib.current_stream(out.device)), "syn_masked_smooth_l1")
-        ctx.save_for_backward(dout)
+        part = torch.empty(B, Cc // 64, dtype=torch.float32, device=out.device)
+        flag = stack_sync_flag(out.device)                    # a block-kernel barrier that gave up poisons the loss (sticky until check_stack_sync)
+        _lib.check(_lib.load().syn_masked_smooth_l1(tc.data_ptr(), oc.data_ptr(), mk.data_ptr(), B, Cc, T, int(rows), part.data_ptr(), _lib.ptr(flag),
+                                                    loss.data_ptr(), _lib.current_stream(out.device)), "syn_masked_smooth_l1")
+        ctx.save_for_backward(tc, oc, mk)
+        ctx.rows = rows
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        (dout,) = ctx.saved_tensors
-        return None, dout * g.reshape(-1, *([1] * (dout.dim() - 1))), None
+        tc, oc, mk = ctx.saved_tensors
+        B, Cc, _, T = oc.shape
+        gc = _f32c(g)
+        if ctx.rows:
+            buf = torch.empty(B, T, Cc, dtype=torch.float32, device=oc.device)
+            dout = buf.permute(0, 2, 1).unsqueeze(2)
+        else:
+            buf = dout = torch.empty_like(oc)
+        _lib.check(_lib.load().syn_masked_smooth_l1_grad(tc.data_ptr(), oc.data_ptr(), mk.data_ptr(), B, Cc, T, int(ctx.rows), gc.data_ptr(), buf.data_ptr(),
+                                                         _lib.current_stream(oc.device)), "syn_masked_smooth_l1_grad")
+        return None, dout, None
 
 
-LOSS_FUSED = bool(int(_os.environ.get("SYN_TRAIN_LOSS_FUSED", "1")))
+def _is_rows_view(out) -> bool:
+    """`out` (B, C, 1, T) is a permuted view of contiguous [B][T][C] rows (what `train_forward` returns)."""
+    B, Cc, _, T = out.shape
+    return out.stride(1) == 1 and out.stride(3) == Cc and (B == 1 or out.stride(0) == T * Cc) and Cc > 1
 
 
 def masked_smooth_l1(target, out, mask):
     """The fused loss when it applies (device fp32 tensors, one mask row per sample, no gradient asked for the target), else None."""
-    if not (LOSS_FUSED and out.is_cuda and out.dim() == 4 and out.dtype is torch.float32 and target.shape == out.shape and not target.requires_grad
+    if not (out.is_cuda and out.dim() == 4 and out.shape[2] == 1 and out.dtype is torch.float32 and target.shape == out.shape and not target.requires_grad
             and target.is_cuda and target.device == out.device
             and torch.is_tensor(mask) and mask.is_cuda and mask.device == out.device and mask.dtype is torch.bool and tuple(mask.shape) == (out.shape[0], 1, 1, out.shape[-1])
-            and out.shape[-1] <= 64 and (out.numel() // out.shape[0]) % 4 == 0):
+            and out.shape[-1] <= 64 and out.shape[1] % 64 == 0):
         return None
     return MaskedSmoothL1Fn.apply(target, out, mask)
 
 
-class RotaryFn(torch.autograd.Function):
-    """The rotary embedding of the hidden state as one launch each way (`syn_rotary`); the backward is the transposed rotation."""
+# ---- rotary ----------------------------------------------------------------------------------------------------------------------------------------
+def _rotary_tables(m, T, device):
+    """(T, 32) tables cos / sin(position x inv_freq), fp32 like the reference's buffer (models/denoiser.py:324-343)."""
+    inv = m.rel_pos.inv_freq
+    key = (inv.data_ptr(), inv._version, inv.device, T)
+    tab = m.__dict__.get("_syn_rotary_tables")
+    if tab is None or tab[0] != key:
+        with torch.no_grad():
+            fr = torch.einsum("i,j->ij", torch.arange(T, device=device).type_as(inv), inv)
+            tab = m.__dict__["_syn_rotary_tables"] = (key, fr.cos().contiguous(), fr.sin().contiguous())
+    return tab[1], tab[2]
+
+
+def _rotary_launch(x, cs, sn, inverse):
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().syn_rotary(x.data_ptr(), cs.data_ptr(), sn.data_ptr(), x.numel() // (32 * 512), int(inverse), y.data_ptr(), _lib.current_stream(x.device)),
+               "syn_rotary")
+    return y
+
+
+# ---- the input stage as ONE autograd node ------------------------------------------------------------------------------------------------------------
+# models/denoiser.py:151-186 (denoiser_h3d.py:180-210) behind the audio encoder, rows in (clip, frame) order:
+#   w_feat = text_encoder_body(text_pre_encoder_body(word))                  embedding rows written as the Linear's bf16 operand (300 -> 384 columns)
+#   at     = avg_pool(mix_audio_text(cat[a_feat, w_feat]))                   the pool commutes with the Linear: the operand is cat[pool(a_feat), pool(w_feat)],
+#                                                                            a quarter of the rows through the GEMM and its backward
+#   x_     = poseEmbedding(x permuted to rows)                               transpose + bf16 rounding in one pass
+#   seq    = input_process2(cat[emb_seed + emb_t (per clip), x_, at])        one concat kernel writes the operand
+#   [seq   = input_process3(cat[seq, style (per clip)])]
+#   h      = rotary(seq)
+# Backward: every Linear is prep -> GEMM pair; the pieces of a cat's gradient are read in place as column slices of the data gradient (prep's ld /
+# row_div / scale), per-clip vectors get their rows summed, the audio features' gradient is the pool's backward of its slice.
+# 9 launches forward, ~20 backward, where the op-by-op composition took ~30 / ~70 (PyTorch casts, pads, cats, slice copies, reductions).
+def _concat_bf16(srcs, M, out_ld, device):
+    """srcs: (tensor, width, ld, row_div, pool, addend | None) -> bf16 [M][out_ld]."""
+    arr = (_lib.SynConcatSrc * len(srcs))()
+    for i, (t, width, ld, row_div, pool, t2) in enumerate(srcs):
+        arr[i].p, arr[i].p2, arr[i].width, arr[i].ld, arr[i].row_div, arr[i].pool = t.data_ptr(), _lib.ptr(t2), width, ld, row_div, pool
+    out = torch.empty(M, out_ld, dtype=torch.bfloat16, device=device)
+    _lib.check(_lib.load().syn_rows_concat_bf16(arr, len(srcs), M, out_ld, out.data_ptr(), _lib.current_stream(device)), "syn_rows_concat_bf16")
+    return out
+
+
+class InputStageFn(torch.autograd.Function):
+    """(a_rows (B, F, A) audio features, x (B, C, 1, T), emb_seed (B, D), emb_t (B, D), style (B, S) | None, word ids (B, F), rotary cos, sin,
+    embedding table, text_encoder_body w / b, mix_audio_text w / b, poseEmbedding w / b, input_process2 w / b, input_process3 w / b | None)
+    -> h (B, T, D) after the rotary embedding.  F = pool x T; 4 | B."""
 
     @staticmethod
-    def forward(ctx, h, cs, sn):
-        hc = _f32c(h)
-        y = torch.empty_like(hc)
-        _lib.check(_lib.load().syn_rotary(hc.data_ptr(), cs.data_ptr(), sn.data_ptr(), hc.shape[0], 0, y.data_ptr(), _lib.current_stream(hc.device)), "syn_rotary")
-        ctx.save_for_backward(cs, sn)
-        return y
+    def forward(ctx, a_rows, x, emb_seed, emb_t, style, ids, cs, sn, table, wt, bt, wm, bm, wp, bp, w2, b2, w3, b3):
+        lib = _lib.load()
+        dev = x.device
+        st = _lib.current_stream(dev)
+        B, Fr, A = a_rows.shape
+        Cx, T = x.shape[1], x.shape[-1]
+        pool = Fr // T
+        M, MF = B * T, B * Fr
+        D = w2.shape[0]
+        ac, xc, es, et = _f32c(a_rows), _f32c(x), _f32c(emb_seed), _f32c(emb_t)
+        idc = ids.detach().reshape(-1).to(torch.int64).contiguous()
+        V, DW = table.shape
+        DWp = _ceil_to(DW, 128)
+        E = torch.empty(MF, DWp, dtype=torch.bfloat16, device=dev)
+        _lib.check(lib.syn_embed_rows_bf16(idc.data_ptr(), table.detach().data_ptr(), V, DW, MF, DWp, E.data_ptr(), st), "syn_embed_rows_bf16")
+        w_feat, pk_t = _lin_fwd(E, wt, bt)                                                   # (B F, word_f)
+        WF = w_feat.shape[1]
+        P = _concat_bf16([(ac, A, A, 1, pool, None), (w_feat, WF, WF, 1, pool, None)], M, _ceil_to(A + WF, 128), dev)
+        at, pk_m = _lin_fwd(P, wm, bm)                                                        # (B T, audio_f) - pooled
+        AT = at.shape[1]
+        xt = torch.empty(M, Cx, dtype=torch.bfloat16, device=dev)
+        _lib.check(lib.syn_bct_to_rows_bf16(xc.data_ptr(), B, Cx, T, xt.data_ptr(), st), "syn_bct_to_rows_bf16")
+        x_, pk_p = _lin_fwd(xt, wp, bp)                                                       # (B T, D)
+        I = _concat_bf16([(es, D, D, T, 1, et), (x_, D, D, 1, 1, None), (at, AT, AT, 1, 1, None)], M, _ceil_to(2 * D + AT, 128), dev)
+        seq, pk_2 = _lin_fwd(I, w2, b2)
+        pk_3, S = None, 0
+        if w3 is not None:
+            sc = _f32c(style)
+            S = sc.shape[1]
+            I3 = _concat_bf16([(seq, D, D, 1, 1, None), (sc, S, S, T, 1, None)], M, _ceil_to(D + S, 128), dev)
+            seq, pk_3 = _lin_fwd(I3, w3, b3)
+        h = _rotary_launch(seq, cs, sn, False)
+        ctx.save_for_backward(idc, cs, sn, wt, wm, wp, w2, w3)
+        ctx.packs = (pk_t, pk_m, pk_p, pk_2, pk_3)
+        ctx.dims = (B, Fr, A, T, pool, D, AT, WF, S, V, DW, DWp)
+        ctx.owners = (table, wt, bt, wm, bm, wp, bp, w2, b2, w3, b3)
+        ctx.style_shape = None if style is None else style.shape
+        return h.view(B, T, D)
 
     @staticmethod
-    def backward(ctx, dy):
-        cs, sn = ctx.saved_tensors
-        d = _f32c(dy)
-        dx = torch.empty_like(d)
-        _lib.check(_lib.load().syn_rotary(d.data_ptr(), cs.data_ptr(), sn.data_ptr(), d.shape[0], 1, dx.data_ptr(), _lib.current_stream(d.device)), "syn_rotary")
-        return dx, None, None
-
-
-ROTARY_FUSED = bool(int(_os.environ.get("SYN_TRAIN_ROTARY_FUSED", "1")))
-
-
-def _rotary(m, h):
-    """models/denoiser.py:178-186,324-343 on (B, T, 512)."""
-    B, T, _ = h.shape
-    if ROTARY_FUSED and h.is_cuda and T == 32 and h.shape[2] == 512:
-        inv = m.rel_pos.inv_freq
-        key = (inv.data_ptr(), inv._version, inv.device)
-        tab = m.__dict__.get("_syn_rotary_tables")
-        if tab is None or tab[0] != key:                     # (T, 32) tables: cos / sin(position x inv_freq), fp32 like the reference's buffer
-            with torch.no_grad():
-                fr = torch.einsum("i,j->ij", torch.arange(T, device=h.device).type_as(inv), inv)
-                tab = m.__dict__["_syn_rotary_tables"] = (key, fr.cos().contiguous(), fr.sin().contiguous())
-        return RotaryFn.apply(h, tab[1], tab[2])
-    g = h.view(B, T, 8, -1).permute(0, 2, 1, 3).reshape(B * 8, T, -1)
-    pos = torch.arange(T, device=h.device).type_as(m.rel_pos.inv_freq)
-    fr = torch.einsum("i,j->ij", pos, m.rel_pos.inv_freq)
-    fr = torch.cat((fr, fr), dim=-1)
-    half = g.shape[-1] // 2
-    g = g * fr.cos() + torch.cat((-g[..., half:], g[..., :half]), dim=-1) * fr.sin()
-    return g.reshape(B, 8, T, -1).permute(0, 2, 1, 3).reshape(B, T, -1)
+    def backward(ctx, dh):
+        lib = _lib.load()
+        idc, cs, sn, wt, wm, wp, w2, w3 = ctx.saved_tensors
+        pk_t, pk_m, pk_p, pk_2, pk_3 = ctx.packs
+        B, Fr, A, T, pool, D, AT, WF, S, V, DW, DWp = ctx.dims
+        table, owt, obt, owm, obm, owp, obp, ow2, ob2, ow3, ob3 = ctx.owners
+        dev = dh.device
+        st = _lib.current_stream(dev)
+        M, MF = B * T, B * Fr
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        d = _rotary_launch(_f32c(dh).view(M, D), cs, sn, True)                                # gradient at the last Linear's output
+        src, ld = d.data_ptr(), D
+        d_style = dw3 = db3 = None
+        keep = [d]
+        if w3 is not None:
+            dI3, dw3, db3 = _lin_bwd(src, pk_3, w3, ob3 is not None, owners=(ow3, ob3), ld=ld, rows=M)
+            K3 = dI3.shape[1]
+            d_style = f32(B, S)
+            _lib.check(lib.syn_rows_group_sum(dI3.data_ptr() + 4 * D, K3, S, T, B, d_style.data_ptr(), st), "syn_rows_group_sum")
+            d_style = d_style.view(ctx.style_shape)
+            src, ld = dI3.data_ptr(), K3
+            keep.append(dI3)
+        dI, dw2, db2 = _lin_bwd(src, pk_2, w2, ob2 is not None, owners=(ow2, ob2), ld=ld, rows=M)   # [M][2 D + AT (+ padding)]
+        K2 = dI.shape[1]
+        d_emb = f32(B, D)
+        _lib.check(lib.syn_rows_group_sum(dI.data_ptr(), K2, D, T, B, d_emb.data_ptr(), st), "syn_rows_group_sum")
+        # poseEmbedding: the latent takes no gradient - weight and bias gradient only
+        _, dwp, dbp = _lin_bwd(dI.data_ptr() + 4 * D, pk_p, wp, obp is not None, owners=(owp, obp), ld=K2, rows=M, want_dx=False)
+        # mix_audio_text on the pooled rows
+        dP, dwm, dbm = _lin_bwd(dI.data_ptr() + 4 * 2 * D, pk_m, wm, obm is not None, owners=(owm, obm), ld=K2, rows=M)
+        KP = dP.shape[1]
+        d_a = f32(B, Fr, A)
+        _lib.check(lib.syn_rows_expand(dP.data_ptr(), KP, A, pool, 1.0 / pool, MF, d_a.data_ptr(), st), "syn_rows_expand")
+        # text_encoder_body: its output gradient = the pool's backward of dP's second slice, formed by the prep pass
+        dE, dwt, dbt = _lin_bwd(dP.data_ptr() + 4 * A, pk_t, wt, obt is not None, owners=(owt, obt), ld=KP, row_div=pool, cscale=1.0 / pool, rows=MF)
+        d_table = None
+        if ctx.needs_input_grad[8]:
+            d_table = _grad_out(table, (V, DW))
+            first = True
+            for lo in range(0, MF, 8192):                       # (the bench's 32 clips x 128 frames are one call)
+                n = min(8192, MF - lo)
+                tgt = d_table if first else torch.empty_like(d_table)
+                _lib.check(lib.syn_embedding_wgrad(idc[lo:].data_ptr(), dE[lo:].data_ptr(), DWp, n, V, DW, tgt.data_ptr(), st), "syn_embedding_wgrad")
+                if not first:
+                    d_table += tgt
+                first = False
+            del tgt                                             # (a second reference would make AccumulateGrad clone the 13 MB gradient instead of adopting it)
+        del keep
+        return (d_a, None, d_emb, d_emb.clone() if ctx.needs_input_grad[3] and ctx.needs_input_grad[2] else d_emb, d_style, None, None, None, d_table,
+                dwt, dbt, dwm, dbm, dwp, dbp, dw2, db2, dw3, db3)
 
 
 class ConvPacks:
@@ -999,12 +863,11 @@ class ConvPacks:
         return e[int(bool(transposed))]
 
 
-CONV_PACKS = bool(int(_os.environ.get("SYN_CONV_PACKS", "1")))        # (A/B: 0 = one pack launch per use)
 _conv_packs: "ConvPacks | None" = None
 
 
 def _lookup_conv_pack(w, transposed):
-    return _conv_packs.lookup(w, transposed) if (_conv_packs is not None and WEIGHT_PACKS and CONV_PACKS) else None
+    return _conv_packs.lookup(w, transposed) if _conv_packs is not None else None
 
 
 def _unsupported_conv(what, cin, stride, pad, cout):
@@ -1026,10 +889,16 @@ CONV_TERMS = _parse_conv_terms(_os.environ.get("SYN_CONV_TERMS", "3,3,1"))
 
 def _conv_terms(role: int):
     """Diagnostics only: with the default (3, 3, 1 = the library's own: both cross products forward and in the data gradient, one in the weight
-    gradient) the library's switch is never touched - the product path makes no `syn_debug_*` call.
-    An A/B run (SYN_CONV_TERMS set to something else) selects the role's mask in front of every convolution launch."""
+    gradient) the library's switch is never touched - the product path makes no `syn_debug_*` call.  An A/B run (SYN_CONV_TERMS set to something
+    else) selects the role's mask in front of a convolution launch; `_conv_terms_done` puts the library's own choice back behind it, so the
+    process-wide switch never outlives the launch it was set for."""
     if CONV_TERMS != (3, 3, 1):
         _lib.load().syn_debug_conv_terms(CONV_TERMS[role])
+
+
+def _conv_terms_done():
+    if CONV_TERMS != (3, 3, 1):
+        _lib.load().syn_debug_conv_terms(-1)
 
 
 class ConvSplitFn(torch.autograd.Function):
@@ -1071,6 +940,7 @@ class ConvSplitFn(torch.autograd.Function):
         _conv_terms(1 if transposed else 0)
         _lib.check(lib.syn_conv1d_train_fwd(xc.data_ptr(), n, l_in, cin, stride, pad, whi.data_ptr(), wlo.data_ptr(), None, cout,
                                                     y.data_ptr(), _lib.ptr(part), _lib.current_stream(x.device)), "syn_conv1d_train_fwd")
+        _conv_terms_done()
         if part is not None:
             y._syn_bn_part = part                                            # picked up by BnActFn.forward (same tensor object)
         return xc, y
@@ -1114,6 +984,7 @@ class ConvSplitFn(torch.autograd.Function):
                 _conv_terms(1)
                 _lib.check(lib.syn_conv1d_train_dgrad_strided(gy.data_ptr(), n, l_in, cin, stride, cout, whi.data_ptr(), wlo.data_ptr(),
                                                               gx.data_ptr(), _lib.current_stream(x.device)), "syn_conv1d_train_dgrad_strided")
+                _conv_terms_done()
             else:
                 raise _unsupported_conv("data gradient", cin, stride, pad, cout)
         if ctx.needs_input_grad[1]:
@@ -1128,6 +999,7 @@ class ConvSplitFn(torch.autograd.Function):
                 _conv_terms(2)
                 _lib.check(lib.syn_conv1d_train_wgrad(x.data_ptr(), gy.data_ptr(), n, l, cin, stride, pad, cout, ws.data_ptr(), gw.data_ptr(),
                                                       _lib.current_stream(x.device)), "syn_conv1d_train_wgrad")
+                _conv_terms_done()
                 gw = gw.to(w.dtype)
             else:
                 raise _unsupported_conv("weight gradient", cin, stride, pad, cout)
@@ -1351,17 +1223,17 @@ def _conv_bn_eval(conv, bn, x):
 #             recomputed pre-activation (`out` is neither saved nor read) | conv2 data gradient | conv2 weight gradient recomputing
 #             act(bn1(y1)) as it stages | bn1 backward | conv1 (and shortcut) gradients                 -> 19 tensor passes in block 0
 # Saved for the backward: x, y1, y2, y_sc and four small per-channel tables - not z1, not the normalised shortcut, not the output.
-WAV_BLOCK_FUSED = bool(int(_os.environ.get("SYN_TRAIN_WAV_BLOCK_FUSED", "1")))     # (A/B: 0 = the per-convolution nodes above)
-FIRST_PAIR = bool(int(_os.environ.get("SYN_TRAIN_FIRST_PAIR", "1")))               # block 0: conv1 + shortcut convolution as one launch (A/B: 0)
-FIRST_WGRAD_BN = bool(int(_os.environ.get("SYN_TRAIN_FIRST_WGRAD_BN", "1")))       # block 0: bn1's backward apply folded into conv1's weight gradient (A/B: 0)
 
 
 def _rows3(t):
-    """(N, C, 1, L) channels_last fp32 -> the same memory as (N, L, C) contiguous."""
+    """(N, C, 1, L) channels_last fp32 -> the same memory as (N, L, C) contiguous (a copy only if the memory is laid out otherwise)."""
     t = t.detach()
     if t.dtype is not torch.float32:
         t = t.float()
-    return t.contiguous(memory_format=torch.channels_last).permute(0, 3, 1, 2).reshape(t.shape[0], t.shape[3], t.shape[1])
+    n, c, _, l = t.shape
+    if t.stride(1) == 1 and t.stride(3) == c and (n == 1 or t.stride(0) == l * c):           # (the size-1 axis' stride is arbitrary)
+        return t.as_strided((n, l, c), (l * c, c, 1))
+    return t.contiguous(memory_format=torch.channels_last).permute(0, 3, 1, 2).reshape(n, l, c)
 
 
 def _as4(t3):
@@ -1395,6 +1267,7 @@ def _wb_conv_fwd(x3, conv, first, in_aff=None, in_act=0):
     else:
         _lib.check(lib.syn_conv1d_train_fwd_norm(x3.data_ptr(), n, l_in, cin, stride, pad, whi.data_ptr(), wlo.data_ptr(), cout, in_aff.data_ptr(),
                                                  int(in_act), y.data_ptr(), part.data_ptr(), st), "syn_conv1d_train_fwd_norm")
+    _conv_terms_done()
     return y, part, chunks
 
 
@@ -1447,6 +1320,7 @@ def _wb_dgrad(dy3, conv, l_in, dy3b=None, conv_b=None, residual=None):
     _lib.check(lib.syn_conv1d_train_dgrad_sum(dy3.data_ptr(), whi.data_ptr(), wlo.data_ptr(), _lib.ptr(dy3b), _lib.ptr(wb[0]), _lib.ptr(wb[1]),
                                               _lib.ptr(residual), n, l_in, cin, stride, pad, cout, dx.data_ptr(), _lib.current_stream(dev)),
                "syn_conv1d_train_dgrad_sum")
+    _conv_terms_done()
     return dx
 
 
@@ -1472,6 +1346,7 @@ def _wb_wgrad(x3, dy3, conv, first, in_aff=None, in_act=0):
     else:
         _lib.check(lib.syn_conv1d_train_wgrad_norm(x3.data_ptr(), dy3.data_ptr(), n, l_in, cin, stride, pad, cout, in_aff.data_ptr(), int(in_act),
                                                    ws.data_ptr(), gw.data_ptr(), st), "syn_conv1d_train_wgrad_norm")
+    _conv_terms_done()
     return gw
 
 
@@ -1488,7 +1363,7 @@ class WavBlockFn(torch.autograd.Function):
         n = x3.shape[0]
         ds = blk.downsample is not None
         ysc = sts = afs = None
-        if first and ds and FIRST_PAIR:
+        if first and ds:
             # conv1 and the shortcut convolution of block 0 read the same waveform window: one launch
             c0, c1m = blk.conv1, blk.downsample[0]
             l_in, cin = x3.shape[1], x3.shape[2]
@@ -1545,7 +1420,7 @@ class WavBlockFn(torch.autograd.Function):
         ws1 = torch.empty(2 * lib.syn_bn_chunks(rows) * c, device=dev, dtype=torch.float32)
         dgb1 = torch.empty(3, c, device=dev, dtype=torch.float32)
         g1, b1 = blk.bn1.weight.detach(), blk.bn1.bias.detach()
-        if first and FIRST_WGRAD_BN and blk.conv1.stride[0] == 5:
+        if first and blk.conv1.stride[0] == 5:
             # block 0: nothing but conv1's weight gradient reads dy1 (the waveform takes no gradient) - it forms dy1 itself from (dz1, y1)
             _lib.check(lib.syn_bn_bwd_stats(dz1.data_ptr(), None, y1.data_ptr(), st1.data_ptr(), g1.data_ptr(), b1.data_ptr(), rows, c, 1, ws1.data_ptr(),
                                             dgb1.data_ptr(), _lib.current_stream(dev)), "syn_bn_bwd_stats")
@@ -1579,7 +1454,7 @@ class WavBlockFn(torch.autograd.Function):
 
 
 def _wav_block_fused_ok(blk, x, first) -> bool:
-    if not (WAV_BLOCK_FUSED and blk.training and torch.is_grad_enabled() and x.is_cuda):
+    if not (blk.training and torch.is_grad_enabled() and x.is_cuda):
         return False
     bns = [blk.bn1, blk.bn2] + ([blk.downsample[1]] if blk.downsample is not None else [])
     if any(isinstance(b, nn.SyncBatchNorm) or not b.track_running_stats or b.momentum is None or b.weight is None for b in bns):
@@ -1594,8 +1469,20 @@ def _wav_block_fused_ok(blk, x, first) -> bool:
                 return False
         elif key not in ConvSplitFn.SUPPORTED or cv.padding[0] % cv.stride[0]:
             return False
-    c2 = blk.conv2
-    return c2.stride[0] == 1 and c2.padding[0] == 7 and c2.in_channels == c2.out_channels
+    c1, c2 = blk.conv1, blk.conv2
+    if not (c2.stride[0] == 1 and c2.padding[0] == 7 and c2.in_channels == c2.out_channels):
+        return False
+    if first:                                                  # block 0: conv1 and the shortcut convolution read one waveform window (`syn_conv1d_first_fwd2`)
+        if blk.downsample is None:
+            return True
+        sc = blk.downsample[0]
+        return (sc.stride[0], sc.padding[0], sc.out_channels, sc.in_channels) == (c1.stride[0], c1.padding[0], 64, c1.in_channels) and c1.stride[0] == 5
+    # what the backward's summed data gradient covers (`_wb_dgrad`): an identity block's stride-1 'same' conv1, or an unpadded strided conv1 + shortcut pair
+    if blk.downsample is None:
+        return c1.stride[0] == 1 and c1.padding[0] == 7 and (c1.out_channels, 1, c1.in_channels) in ConvSplitFn.SUPPORTED
+    sc = blk.downsample[0]
+    return (c1.padding[0] == 0 and (c1.out_channels, c1.stride[0]) in ((64, 6), (128, 6), (256, 3)) and (c1.stride[0] * c1.in_channels) % 128 == 0
+            and (sc.in_channels, sc.stride[0], sc.padding[0], sc.out_channels) == (c1.in_channels, c1.stride[0], c1.padding[0], c1.out_channels))
 
 
 def _wav_block_params(blk):
@@ -1625,39 +1512,46 @@ def _wav_block(blk, x):
     return F.leaky_relu(z + short, 0.01)
 
 
+
+def _step_packs(m, training: bool):
+    """Refresh the step's fragment sets: every Linear outside the blocks now (one launch), the audio encoder's convolutions (one launch); the blocks'
+    Linears are packed later, right in front of the blocks (`train_forward`)."""
+    global _packs, _packs_blocks, _conv_packs
+    pk = m.__dict__.get("_syn_weight_packs")
+    if pk is None or pk[0].owner() is not m or not (pk[0].valid() and pk[1].valid()):    # (a deep copy of the model brings the original's cache along)
+        in_blocks = {id(mod.weight) for blk in m.mytimmblocks for mod in blk.modules() if isinstance(mod, nn.Linear)}
+        lin_w = [mod.weight for mod in m.modules() if isinstance(mod, nn.Linear)]
+        pk = m.__dict__["_syn_weight_packs"] = (WeightPacks([w for w in lin_w if id(w) not in in_blocks]), WeightPacks([w for w in lin_w if id(w) in in_blocks]))
+        pk[0].owner = pk[1].owner = weakref.ref(m)
+    pk[0].refresh()
+    _packs, _packs_blocks = pk
+    cp = m.__dict__.get("_syn_conv_packs")
+    if training and (cp is None or cp.owner() is not m or not cp.valid()):
+        cp = m.__dict__["_syn_conv_packs"] = ConvPacks([mod for mod in m.WavEncoder.modules() if isinstance(mod, nn.Conv1d)])
+        cp.owner = weakref.ref(m)
+    if training and cp.lists:
+        cp.refresh()
+        _conv_packs = cp
+    else:
+        _conv_packs = None
+
+
 def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     """Differentiable MDM.forward, op-for-op with models/denoiser.py:132-196 (denoiser_h3d.py:148-221), with the
-    module's current train()/eval() semantics.  x (B,1536,1,T) -> (B,1536,1,T)."""
+    module's current train()/eval() semantics.  x (B,1536,1,T) -> (B,1536,1,T) (a permuted view of the output Linear's [B][T][C] rows)."""
     engine._require_cuda(x, "x")
-    bs, C, _, T = x.shape
+    if x.requires_grad and torch.is_grad_enabled():
+        raise _lib.SynHipError("the training path provides no gradient with respect to x_t (training_losses never asks for one, "
+                               "gaussian_diffusion.py:1236-1363): detach the latent")
+    bs, C_, _, T = x.shape
     training = m.training
-    global _packs
-    if WEIGHT_PACKS and torch.is_grad_enabled():
-        pk = m.__dict__.get("_syn_weight_packs")
-        if pk is None or pk[0].owner() is not m or not (pk[0].valid() and pk[1].valid()):    # (a deep copy of the model brings the original's cache along)
-            in_blocks = {id(mod.weight) for blk in m.mytimmblocks for mod in blk.modules() if isinstance(mod, nn.Linear)}
-            lin_w = [mod.weight for mod in m.modules() if isinstance(mod, nn.Linear)]
-            pk = m.__dict__["_syn_weight_packs"] = (WeightPacks([w for w in lin_w if id(w) not in in_blocks]), WeightPacks([w for w in lin_w if id(w) in in_blocks]))
-            pk[0].owner = pk[1].owner = __import__("weakref").ref(m)
-        pk[0].refresh()
-        global _packs_blocks
-        _packs, _packs_blocks = pk
-        if not PACK_BLOCKS_LATE:
-            _packs_blocks.refresh()
-        global _conv_packs
-        cp = m.__dict__.get("_syn_conv_packs")
-        if training and (cp is None or cp.owner() is not m or not cp.valid()):
-            cp = m.__dict__["_syn_conv_packs"] = ConvPacks([mod for mod in m.WavEncoder.modules() if isinstance(mod, nn.Conv1d)])
-            cp.owner = __import__("weakref").ref(m)
-        if training and cp.lists:
-            cp.refresh()
-            _conv_packs = cp
-        else:
-            _conv_packs = None
+    if torch.is_grad_enabled() and any(getattr(p, "_syn_grad_handed", False) for p in m.parameters()):
+        _reset_handed(m)                                       # a new step: every bound gradient buffer may be handed out again (`_grad_out`)
+    _step_packs(m, training)
     h3d = m.variant == "h3d"
     te = m.embed_timestep
     e = te.sequence_pos_encoder.pe[timesteps]                                   # (B,1,512)
-    emb_t = lin(F.silu(lin(e, te.time_embed[0])), te.time_embed[2]).permute(1, 0, 2)
+    emb_t = lin(F.silu(lin(e, te.time_embed[0])), te.time_embed[2]).reshape(bs, -1)
     emb_seed = lin(y["seed"].reshape(bs, -1), m.embed_text)
     audio, word = y["audio"], y["word"]
     if h3d and y.get("uncond_audio", False):
@@ -1674,376 +1568,64 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
         _tracked.clear()
     # From here on rows are (clip, frame), not the reference's (frame, clip) (denoiser.py:151-176): every op below is row-wise or acts along the
     # frame axis of one clip, so the order is free - and this one needs no transposing copy between the encoder, the blocks and the output.
-    a_feat = a.squeeze(2).transpose(1, 2)                  # (B, 128, 256): the channels_last output of the encoder as it lies in memory
-    w_feat = lin(_embed(m.text_pre_encoder_body, word), m.text_encoder_body)        # (B, 128, 256)
-    at = lin(torch.cat([a_feat, w_feat], dim=2), m.mix_audio_text)
+    n, ca, _, fr = a.shape
+    a_rows = a.permute(0, 3, 1, 2).reshape(n, fr, ca)        # (B, 128, 256): the channels_last output of the encoder as it lies in memory
     pool = getattr(m.args, "vqvae_squeeze_scale", 4) if not h3d else 4
-    if at.shape[1] % pool:
-        at = at[:, :at.shape[1] // pool * pool]              # (F.avg_pool1d drops the incomplete window)
-    at = at.reshape(bs, at.shape[1] // pool, pool, at.shape[2]).mean(dim=2)         # F.avg_pool1d over the frame axis (denoiser.py:157) -> (B, T, 256)
-    xt = torch.empty(bs, T, C, dtype=torch.bfloat16, device=x.device)
-    xt.copy_(x.detach().reshape(bs, C, T).transpose(1, 2))                          # (B, T, C) GEMM operand: transpose + bf16 rounding as one pass
-    x_ = lin(xt, m.input_process.poseEmbedding)
-    emb = (emb_seed + emb_t.reshape(bs, -1)).unsqueeze(1).expand(bs, T, emb_seed.shape[-1])
-    seq = lin(torch.cat((emb, x_, at), dim=2), m.input_process2)
+    if fr // pool != T:
+        raise _lib.SynHipError(f"{fr} audio frames pooled by {pool} do not give the latent's {T} frames (models/denoiser.py:157)")
+    if fr % pool:
+        a_rows = a_rows[:, :fr // pool * pool]               # (F.avg_pool1d drops the incomplete window)
+        word = word[:, :fr // pool * pool]
+    style = None
     if m.uses_style:
-        st = y["style_feature"]
+        style = y["style_feature"]
         force = bool(y.get("uncond", False))
-        null = m.uncon_text_embeddings.repeat(bs, 1) if h3d else torch.zeros_like(st)
+        null = m.uncon_text_embeddings.repeat(bs, 1) if h3d else torch.zeros_like(style)
         if force:
-            st = null
+            style = null
         elif training and m.cond_mask_prob > 0.:
-            mask = torch.bernoulli(torch.ones(bs, device=st.device) * m.cond_mask_prob).view(bs, 1)
-            st = st * (1. - mask) + null * mask
-        seq = lin(torch.cat((seq, st.unsqueeze(1).expand(bs, T, st.shape[-1])), dim=2), m.input_process3)
-    h = _rotary(m, seq)
+            mask = torch.bernoulli(torch.ones(bs, device=style.device) * m.cond_mask_prob).view(bs, 1)
+            style = style * (1. - mask) + null * mask
     # DropPath (timm_transformer/transformer.py:21-38: one Bernoulli(keep) / keep factor per sample and residual branch): all the
-    # step's factors from one draw, and x + branch * factor as one fused multiply-add instead of bernoulli, div, mul, add per branch
+    # step's factors from one draw, applied as x + branch * factor in the branch's last GEMM
     dp = None
     if training and drop_path > 0.:
         keep = 1. - drop_path
-        dp = h.new_empty(2 * len(m.mytimmblocks), bs, 1, 1).bernoulli_(keep).div_(keep)
-    if WEIGHT_PACKS and torch.is_grad_enabled() and PACK_BLOCKS_LATE and _packs_blocks is not None:
-        # The blocks' fragment sets are packed HERE, not at the top of the forward: the audio encoder in between moves ~1 GB through the memory-side cache,
-        # and the persistent block kernel below - latency-bound, every phase waits for its first weight fragments - then finds them in HBM
-        _packs_blocks.refresh()
-    stack = _stack_ok(m, bs, T) and engine_has_xcd_groups(h.device)
-    if stack:
+        dp = x.new_empty(2 * len(m.mytimmblocks), bs, 1, 1).bernoulli_(keep).div_(keep)
+    # The block kernels work on tiles of 4 clips: other batch sizes get empty clips appended here (zero rows, factor 1); their rows carry zero
+    # gradients back and are cut from the output.  (PyTorch ops: the odd-batch path is a convenience, not a tuned one.)
+    padn = (-bs) % 4
+    xin, word_in = x.detach(), word
+    if padn:
+        zr = lambda t: F.pad(t, (0, 0) * (t.dim() - 1) + (0, padn))
+        a_rows, xin, emb_seed, emb_t, word_in = zr(a_rows), zr(xin), zr(emb_seed), zr(emb_t), zr(word)
+        style = None if style is None else zr(style)
+        dp = None if dp is None else F.pad(dp, (0, 0, 0, 0, 0, padn), value=1.0)
+    B = bs + padn
+    cs, sn = _rotary_tables(m, T, x.device)
+    ip3 = getattr(m, "input_process3", None) if m.uses_style else None
+    tb, mx, pe_, ip2 = m.text_encoder_body, m.mix_audio_text, m.input_process.poseEmbedding, m.input_process2
+    h = InputStageFn.apply(a_rows, xin, emb_seed, emb_t, style, word_in, cs, sn, m.text_pre_encoder_body.weight, tb.weight, tb.bias, mx.weight, mx.bias,
+                           pe_.weight, pe_.bias, ip2.weight, ip2.bias, None if ip3 is None else ip3.weight, None if ip3 is None else ip3.bias)
+    if not _blocks_ok(m):
+        raise _lib.SynHipError("the block kernels implement the reference's Block (timm_transformer/transformer.py:154-198: 512 wide, 4 heads, qkv without "
+                               "bias, MLP 1024); this model's blocks differ")
+    # The blocks' fragment sets are packed HERE, not at the top of the forward: the audio encoder in between moves ~1 GB through the memory-side cache,
+    # and the persistent block kernel below - latency-bound, every phase waits for its first weight fragments - then finds them in HBM
+    _packs_blocks.refresh()
+    if _stack_ok(m, B, T, h.device):
         ps = []
         for blk in m.mytimmblocks:
             ps += [blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias,
                    blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias]
         h = StackFn.apply(h, dp, *ps)
-    for i, blk in enumerate(() if stack else m.mytimmblocks):
-        if torch.is_grad_enabled() and _fused_ok(bs * T, blk.attn.qkv, blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
+    else:
+        for i, blk in enumerate(m.mytimmblocks):
             h = AttnBranchFn.apply(h, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight,
                                    blk.attn.proj.bias, None if dp is None else dp[2 * i])
             h = MlpBranchFn.apply(h, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight,
                                   blk.mlp.fc2.bias, None if dp is None else dp[2 * i + 1])
-            continue
-        z, h = HipLnForkFn.apply(h, blk.norm1.weight, blk.norm1.bias)
-        o = HipAttentionFn.apply(lin(z, blk.attn.qkv))           # (B, T, 3 x 4 heads x 128) -> (B, T, 512)
-        br = lin(o, blk.attn.proj)
-        h = h + br if dp is None else torch.addcmul(h, br, dp[2 * i])
-        z, h = HipLnForkFn.apply(h, blk.norm2.weight, blk.norm2.bias)
-        br = lin(HipGeluFn.apply(lin(z, blk.mlp.fc1)), blk.mlp.fc2)
-        h = h + br if dp is None else torch.addcmul(h, br, dp[2 * i + 1])
-    out = lin(h, m.output_process.poseFinal)                # (B, T, C)
-    return out.permute(0, 2, 1).unsqueeze(2)                # (B, C, 1, T) as the reference returns it (a view: the loss kernel reads either layout)
-
-
-def unused_in_forward(model) -> tuple:
-    """Top-level parameter groups the training forward never reads: `embed_style` in both variants and the h3d
-    `uncon_audio_embeddings` (denoiser_h3d.py:63).  `uncon_text_embeddings` IS read by the h3d forward - the null prompt of its
-    cond-mask dropout (denoiser_h3d.py:119-122; `train_forward` above) - and is trained."""
-    m = getattr(model, "module", model)
-    return ("embed_style", "uncon_audio_embeddings") if getattr(m, "variant", "beatx") == "h3d" else ("embed_style",)
-
-
-DDP_AVG_HOOK = bool(int(_os.environ.get("SYN_DDP_AVG_HOOK", "1")))
-DIRECT_GRADS = bool(int(_os.environ.get("SYN_DDP_DIRECT_GRADS", "1")))     # captured DDP step: gradients written into the buckets (A/B: 0)
-DDP_BUCKET_MB = 32      # 118 MB of fp32 gradients -> 4 all-reduces (+ PyTorch's small first bucket, which starts the stream of collectives
-                        # as soon as the output projection's gradients exist).  xGMI is point-to-point, a ring all-reduce is per-link
-                        # bound (7 links x ~153 GB/s per GPU): at 8 GPUs a 32 MB bucket is ~0.4 ms on the wire, short enough to overlap
-                        # with a ~5 ms backward in four pieces, long enough that RCCL's launch latency (tens of us) stays below 10 %.
-                        # (round 2 used 64 MB = two buckets: the second all-reduce could only start when backward was nearly over.)
-
-
-def make_ddp(model, local_rank: int | None = None, sync_bn: bool = False, capturable: bool = False):
-    """One process per GPU, gradients all-reduced over RCCL (backend "nccl"); `embed_style` and the h3d
-    `uncon_audio_embeddings` never receive gradients (`unused_in_forward`), hence find_unused_parameters.
-    capturable=True prepares the wrapper for `GraphedTrainStep`: the unused-parameter search is a host-side walk plus
-    a blocking all-reduce in every backward, which cannot be captured, so those parameters are frozen instead and the
-    search is switched off (same gradients: they are None either way)."""
-    from torch.nn.parallel import DistributedDataParallel as DDP
-    if sync_bn:
-        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
-    if capturable:
-        frozen = unused_in_forward(model)
-        for n, p in model.named_parameters():
-            if n.split(".")[0] in frozen:
-                p.requires_grad_(False)
-    dev_ids = None if local_rank is None else [local_rank]
-    ddp = DDP(model, device_ids=dev_ids, broadcast_buffers=False, find_unused_parameters=not capturable,
-              gradient_as_bucket_view=True, bucket_cap_mb=DDP_BUCKET_MB)
-    if capturable and DDP_AVG_HOOK:
-        ddp.register_comm_hook(None, _avg_comm_hook)
-    return ddp
-
-
-def _avg_comm_hook(state, bucket):
-    """DDP communication hook of the captured step: ONE collective per bucket that also averages (RCCL's `ncclAvg`), so the reducer neither
-    divides a gradient as it copies it into the bucket nor - for a gradient that was written into the bucket directly (`_grad_out`) -
-    launches anything per parameter.  Backends without an averaging reduction (gloo, the CPU tests): torch's default hook (divide the
-    bucket, all-reduce)."""
-    import torch.distributed as dist
-    buf = bucket.buffer()
-    if dist.get_backend() == "nccl":
-        op = dist.ReduceOp.AVG if dist.get_world_size() > 1 else dist.ReduceOp.SUM      # (one rank: RCCL's in-place SUM launches nothing, AVG a pre-multiply kernel)
-        fut = dist.all_reduce(buf, op=op, async_op=True).get_future()
-        return fut.then(lambda f: f.value()[0])
-    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
-    return default_hooks.allreduce_hook(dist.group.WORLD, bucket)
-
-
-def ddp_bucket_sizes(ddp) -> list[int]:
-    """Bytes of gradient per all-reduce bucket of a DDP wrapper (tests, bench report).  Without the unused-parameter search DDP
-    runs its FIRST iteration on a single bucket and re-buckets by `bucket_cap_mb` in the order the gradients really arrived;
-    this returns the rebuilt plan once it exists (i.e. after the first backward)."""
-    try:
-        d = ddp._get_ddp_logging_data()
-        txt = d.get("rebuilt_bucket_sizes") or d.get("bucket_sizes", "")
-        return [int(b) for b in str(txt).split(",") if b.strip()]
-    except Exception:
-        return []
-
-
-class ClipAdam(torch.optim.Optimizer):
-    """`clip_grad_norm_(params, max_norm)` + `torch.optim.Adam(params, lr, betas, eps, weight_decay).step()` (the reference's
-    optimizer step, diffusion_rvqvae_trainer.py:351-356 with optimizers/optim_factory.py's Adam) as `2 + 2 n` launches for `64 n` tensors
-    (`syn_opt_sqnorm` / `syn_opt_scalars` / `syn_opt_adam`): the gradients are read twice and never rewritten - the clip factor is applied
-    inside the update - where PyTorch's foreach norm + multiply + fused Adam read them three times and write them once.
-    State layout and `state_dict()` are torch.optim.Adam's ("step" / "exp_avg" / "exp_avg_sq" per parameter; the step count is ONE device
-    tensor per group that every parameter's "step" aliases), so its checkpoints load here and the other way round.  The step count and,
-    when `lr` is a tensor, the learning rate live on the device: the step is capturable in a hipGraph.  `last_norm()` = the total gradient
-    norm of the latest step (what clip_grad_norm_ returns), a device tensor.
-    Differences from the two PyTorch calls: p.grad keeps the UNCLIPPED gradient after the step; amsgrad / maximize are not offered."""
-
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_norm=None):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self.max_norm = float(max_norm) if max_norm else 0.0
-        self._lists = {}            # (pointers of the tensors with gradients) -> prepared argument lists
-        self._scal = None
-
-    def last_norm(self):
-        return None if self._scal is None else self._scal[0][0, 3]
-
-    def _group_state(self, group, dev):
-        ps = [p for p in group["params"] if p.grad is not None]
-        for p in ps:
-            if p.dtype is not torch.float32 or not p.is_contiguous() or p.grad.dtype is not torch.float32 or not p.grad.is_contiguous() or p.grad.is_sparse:
-                raise _lib.SynHipError("ClipAdam takes contiguous fp32 parameters with dense contiguous fp32 gradients")
-        step = None
-        for p in group["params"]:
-            st = self.state.get(p)
-            if st and "step" in st:
-                step = st["step"] if step is None else step
-        if step is None or not torch.is_tensor(step) or step.device != dev or step.dtype is not torch.float32 or step.dim() != 0:
-            step = torch.tensor(float(step) if step is not None else 0.0, dtype=torch.float32, device=dev)
-        for p in ps:
-            st = self.state[p]
-            if "exp_avg" not in st:
-                st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format), torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["step"] = step                                           # (one count per group; a loaded state_dict's copies are re-aliased here)
-        return ps, step
-
-    def _prepare(self, ps):
-        # (every pointer a prepared list holds is part of its key: load_state_dict replaces the moment tensors, backward the gradients)
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in ps)
-        ent = self._lists.get(key)
-        if ent is None:
-            if len(self._lists) > 4:
-                self._lists.clear()
-            lib, lists, blocks = _lib.load(), [], []
-            for lo in range(0, len(ps), _lib.SYN_OPT_MAX):
-                L = _lib.SynOptList()
-                chunk = ps[lo:lo + _lib.SYN_OPT_MAX]
-                for i, p in enumerate(chunk):
-                    st = self.state[p]
-                    L.p[i], L.g[i], L.m[i], L.v[i], L.numel[i] = p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
-                L.n = len(chunk)
-                lists.append(L)
-                blocks.append(int(lib.syn_opt_blocks(C.byref(L))))
-            ent = self._lists[key] = (lists, blocks)
-        return ent
-
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
-        groups = []
-        for group in self.param_groups:
-            first = next((p for p in group["params"] if p.grad is not None), None)
-            if first is None:
-                continue
-            engine._require_cuda(first, "parameter")
-            ps, step = self._group_state(group, first.device)
-            groups.append((group, ps, step) + self._prepare(ps))
-        if not groups:
-            return loss
-        dev = groups[0][1][0].device
-        lib, st = _lib.load(), _lib.current_stream(dev)
-        total = sum(sum(b) for *_, b in groups)
-        if self._scal is None or self._scal[0].device != dev or self._scal[1].numel() < total or len(self._scal[0]) < len(groups):
-            self._scal = (torch.zeros(max(len(groups), 1), 4, device=dev), torch.empty(max(total, 1), device=dev))
-        scal, partials = self._scal
-        if self.max_norm > 0:                                           # the norm is over ALL parameters, whatever their group
-            off = 0
-            for _, _, _, lists, blocks in groups:
-                for L, b in zip(lists, blocks):
-                    _lib.check(lib.syn_opt_sqnorm(C.byref(L), partials[off:].data_ptr(), st), "syn_opt_sqnorm")
-                    off += b
-        for gi, (group, ps, step, lists, blocks) in enumerate(groups):
-            lr, (b1, b2) = group["lr"], group["betas"]
-            lr_dev = lr if torch.is_tensor(lr) else None
-            if lr_dev is not None and (lr_dev.device != dev or lr_dev.dtype is not torch.float32):
-                raise _lib.SynHipError("ClipAdam: a tensor learning rate must be an fp32 tensor on the parameters' device")
-            _lib.check(lib.syn_opt_scalars(partials.data_ptr(), total if self.max_norm > 0 else 0, self.max_norm, _lib.ptr(lr_dev),
-                                           0.0 if lr_dev is not None else float(lr), b1, b2, step.data_ptr(), scal[gi].data_ptr(), st), "syn_opt_scalars")
-            for L in lists:
-                _lib.check(lib.syn_opt_adam(C.byref(L), scal[gi].data_ptr(), b1, b2, group["eps"], group["weight_decay"], st), "syn_opt_adam")
-        return loss
-
-
-def _check_clip(optimizer, grad_norm):
-    """A ClipAdam clips inside its step with ITS max_norm; a `grad_norm` argument that says something else must not pass silently."""
-    if isinstance(optimizer, ClipAdam) and abs(float(grad_norm or 0.0) - optimizer.max_norm) > 1e-12:
-        raise ValueError(f"grad_norm={grad_norm} but the ClipAdam optimizer was built with max_norm={optimizer.max_norm or None}: "
-                         "construct it with max_norm=grad_norm (the clip is part of its step), or pass grad_norm=optimizer.max_norm")
-
-
-def train_step(model, diffusion, sampler, optimizer, x0, model_kwargs, grad_norm: float = 0.99):
-    """The body of the reference's hot training loop (diffusion_rvqvae_trainer.py:339-356, 555-560)."""
-    _check_clip(optimizer, grad_norm)
-    t, _ = sampler.sample(x0.shape[0], x0.device)
-    optimizer.zero_grad(set_to_none=True)
-    loss = diffusion.training_losses(model, x0, t, model_kwargs=model_kwargs)["loss"].mean()
-    loss.backward()
-    if grad_norm and not isinstance(optimizer, ClipAdam):           # (ClipAdam carries its max_norm: the clip is part of its step)
-        torch.nn.utils.clip_grad_norm_(model.parameters(), grad_norm)
-    optimizer.step()
-    return loss.detach()
-
-
-
-class GraphedTrainStep:
-    """`train_step` captured once in a hipGraph and replayed.  The step is ~1 000 kernel launches long and host-bound
-    when issued from Python (device time 15 ms, wall 17-21 ms at 32 clips); a replay costs the device time (15.5 ms).
-    Static shapes: every call must bring tensors of the shapes seen at construction.  The optimizer must be constructed
-    with ``capturable=True``.  With DDP: wrap with ``make_ddp(..., capturable=True)`` inside ``torch.cuda.stream(s)``,
-    pass ``stream=s`` and ``warmup=11`` (DDP needs that many eager iterations before a capture), and set
-    ``TORCH_NCCL_ASYNC_ERROR_HANDLING=0`` before ``init_process_group`` - the bucketed all-reduces are then nodes of the
-    graph (`scripts/bench_train_ddp.py`; checked with one rank over RCCL: 22.6 ms eager -> 18.0 ms replayed).
-
-        step = GraphedTrainStep(model, diffusion, optimizer, x0, {"y": y})
-        loss = step(x0, t, {"y": y})          # t from the schedule sampler (host RNG, as in the reference)
-
-    Replays are stream-ordered like any launch; nothing waits for them.  (Round 1 synchronised after every replay because
-    back-to-back replays aborted in the HIP runtime with an HSA memory-aperture violation.  Root cause, found in round 2: the
-    word-embedding gradient - PyTorch-ROCm's embedding_dense_backward, a chain of ~15 sort / scan / segment kernels - does not
-    survive being replayed at the bench size; with `EmbeddingFn` in its place 300 un-synchronised replays run clean, and so do the
-    launch variants that used to trip the same abort.  SYN_TORCH_EMBEDDING_GRAD=1 brings the op back to reproduce it.)
-    Call `close()` (or let the object die) before interpreter shutdown."""
-
-    def __init__(self, model, diffusion, optimizer, x0, model_kwargs, grad_norm: float = 0.99, warmup: int = 3, stream=None,
-                 keep_warmup_updates: bool = False, noise=None):
-        engine._require_cuda(x0, "x0")
-        _check_clip(optimizer, grad_norm)
-        self.model, self.opt, self.grad_norm, self.diffusion = model, optimizer, grad_norm, diffusion
-        self.sync = bool(_os.environ.get("SYN_TRAIN_GRAPH_SYNC"))   # wait for every replay (not needed: see the class docstring)
-        self.wrapped = diffusion._wrap_model(model)          # its timestep map is uploaded once, outside the capture
-        self.x0 = x0.detach().clone()
-        self.t = torch.zeros(x0.shape[0], dtype=torch.long, device=x0.device)
-        # `noise` (a tensor like x0): the step takes its q_sample noise from a static buffer the caller fills per call (`__call__(..., noise=)`,
-        # the `noise=` argument of training_losses - parity tests with injected noise) instead of drawing it inside the graph
-        self.noise = None if noise is None else noise.detach().clone()
-        self.y = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in model_kwargs["y"].items()}
-        side = stream if stream is not None else torch.cuda.Stream(device=x0.device)   # DDP: the stream the wrapper was built on
-        side.wait_stream(torch.cuda.current_stream(x0.device))
-        with torch.cuda.stream(side):                         # warm-up: lazy state, Adam state, DDP's bucket rebuild
-            # The warm-up iterations are real optimizer steps on the construction batch at t = 0.  They must not count as training:
-            # parameters, buffers (BatchNorm statistics) and the optimizer's state are put back IN PLACE afterwards (the capture
-            # holds their addresses), so the first replay is update number 1 of the run - or number n + 1 after a resume.
-            snap = None if keep_warmup_updates else self._snapshot()
-            self.bound = 0
-            for i in range(warmup):
-                self._body()
-                if i == 2 and hasattr(model, "reducer") and DIRECT_GRADS and DDP_AVG_HOOK:
-                    # DDP has rebuilt its buckets by now and every parameter's .grad is a view of one: from here on the backward kernels
-                    # write weight gradients straight into those views (the remaining warm-up iterations already run that way)
-                    self.bound = bind_grad_buffers(model)
-        torch.cuda.current_stream(x0.device).wait_stream(side)
-        mode = "global"
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            # A process group's watchdog thread polls the events of the warm-up's collectives (hipEventQuery, then their release).  Let it
-            # retire them before the capture starts - the device is drained, the thread sweeps every ~100 ms - and keep other threads'
-            # runtime calls out of this capture's error domain (thread-local mode: launches on the capturing stream are captured whichever
-            # thread issues them - the autograd engine's do - but a foreign thread's query cannot invalidate the capture).
-            # Deterministic part of the drain: every rank has issued its warm-up collectives (barrier) and the device has finished them
-            # (synchronize).  What is left is the watchdog thread's sweep, which PyTorch does not expose: it polls every ~100 ms, so the wait
-            # is three periods by default (SYN_GRAPH_WATCHDOG_DRAIN_S to change it, 0 to skip).
-            if torch.distributed.get_world_size() > 1:
-                torch.distributed.barrier()
-            torch.cuda.synchronize(x0.device)
-            drain = float(_os.environ.get("SYN_GRAPH_WATCHDOG_DRAIN_S", "0.3"))
-            if drain > 0:
-                __import__("time").sleep(drain)
-            mode = "thread_local"
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=side, capture_error_mode=mode):
-            self.loss = self._body()
-        if snap is not None:
-            with torch.cuda.stream(side):
-                self._restore(snap)
-            torch.cuda.current_stream(x0.device).wait_stream(side)
-
-    def _snapshot(self):
-        tensors = [p for p in self.model.parameters()] + list(self.model.buffers())
-        state = {}
-        for group in self.opt.param_groups:
-            for p in group["params"]:
-                st = self.opt.state.get(p)
-                if st:
-                    state[p] = {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)}
-        return [(t, t.detach().clone()) for t in tensors], state
-
-    @torch.no_grad()
-    def _restore(self, snap):
-        for t, saved in snap[0]:
-            t.copy_(saved)
-        for group in self.opt.param_groups:
-            for p in group["params"]:
-                for k, v in self.opt.state.get(p, {}).items():
-                    if torch.is_tensor(v):               # state born during the warm-up goes back to its initial value: zero
-                        v.copy_(snap[1][p][k]) if p in snap[1] and k in snap[1][p] else v.zero_()
-
-    def _body(self):
-        self.opt.zero_grad(set_to_none=True)
-        if self.bound:
-            _reset_handed(self.model)
-        loss = self.diffusion.training_losses(self.wrapped, self.x0, self.t, model_kwargs={"y": self.y}, noise=self.noise)["loss"].mean()
-        loss.backward()
-        if self.grad_norm and not isinstance(self.opt, ClipAdam):
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.grad_norm)
-        self.opt.step()
-        return loss.detach()
-
-    def __call__(self, x0, t, model_kwargs, noise=None):
-        self.x0.copy_(x0)
-        self.t.copy_(t)
-        if (noise is None) != (self.noise is None):
-            raise ValueError("GraphedTrainStep: pass `noise` to every call if and only if the step was constructed with a noise buffer")
-        if noise is not None:
-            self.noise.copy_(noise)
-        for k, v in model_kwargs["y"].items():
-            if torch.is_tensor(v):
-                self.y[k].copy_(v)
-        self.graph.replay()
-        if self.sync:
-            torch.cuda.current_stream(self.x0.device).synchronize()
-        return self.loss.clone()        # (stream-ordered copy: the static tensor is overwritten by the next replay)
-
-    def close(self):
-        if getattr(self, "graph", None) is not None:
-            torch.cuda.synchronize()
-            self.graph, self.loss = None, None
-            if getattr(self, "bound", 0):
-                unbind_grad_buffers(self.model)
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+    out = lin(h, m.output_process.poseFinal)                # (B, T, C) rows
+    if padn:
+        out = out[:bs]
+    return out.permute(0, 2, 1).unsqueeze(2)                # (B, C, 1, T) as the reference returns it: a view - `MaskedSmoothL1Fn` reads the rows in place

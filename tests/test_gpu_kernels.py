@@ -104,28 +104,36 @@ def test_linear_epilogues_residual_droppath_and_gelu(lib, m, n, k, rps):
 
 
 def test_linear_backward_operand_pass_and_pair_bias_sum(lib):
-    """syn_linear_bwd_prep (bf16 copy, bf16 transpose, per-64-row column sums of factor * dy or GELU'(pre) * dy) and the bias-gradient sum riding
-    syn_linear_pair, against torch."""
+    """syn_linear_bwd_prep (bf16 copy, bf16 transpose, per-64-row column sums of factor * dy; dy read in place as a column slice of a wider
+    tensor, or as the backward of an average pool over 4 rows) and the bias-gradient sum riding syn_linear_pair, against torch."""
     from syntalker_amd import engine, training
     g = torch.Generator().manual_seed(9)
     M, N, K = 256, 1024, 512
-    dy, pre = torch.randn(M, N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda() * 2
+    wide = torch.randn(M, N + 256, generator=g).cuda()               # dy = columns 128 .. 128 + N of a wider gradient (one piece of a torch.cat's backward)
+    pooled = torch.randn(M // 4, N, generator=g).cuda()              # dy = the backward of an average pool over 4 consecutive rows
     fac = (torch.rand(M // 32, generator=g) < 0.7).float().div(0.7).cuda()
     L, st = lib.load(), lib.current_stream()
-    for scale, gp in ((fac, None), (None, pre), (None, None)):
-        eff = dy.clone()
-        if scale is not None:
-            eff = eff * scale.repeat_interleave(32)[:, None]
-        if gp is not None:
-            x = gp.double()
-            eff = (eff.double() * (0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5)).float()
+    for case in ("factors", "slice", "pool", "plain"):
+        scale, ld, row_div, cs = None, N, 1, 1.0
+        if case == "slice":
+            src, ld = wide[:, 128:128 + N], N + 256
+            eff = src.clone()
+        elif case == "pool":
+            src, row_div, cs = pooled, 4, 0.25
+            eff = pooled.repeat_interleave(4, 0) * 0.25
+        else:
+            src = wide[:, :N].contiguous()
+            eff = src.clone()
+            if case == "factors":
+                scale = fac
+                eff = eff * scale.repeat_interleave(32)[:, None]
         dyb, dybt = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), torch.empty(N, M, dtype=torch.bfloat16, device="cuda")
         part = torch.empty(M // 64, N, device="cuda")
-        lib.check(L.syn_linear_bwd_prep(dy.data_ptr(), M, N, lib.ptr(scale), 32, lib.ptr(gp), dyb.data_ptr(), dybt.data_ptr(), part.data_ptr(), None, None, st),
+        lib.check(L.syn_linear_bwd_prep(src.data_ptr(), ld, row_div, cs, M, N, lib.ptr(scale), 32, dyb.data_ptr(), dybt.data_ptr(), part.data_ptr(), st),
                   "syn_linear_bwd_prep")
         torch.cuda.synchronize()
-        assert rel_l2(dyb.float().cpu(), eff.cpu()) < 3e-3 and torch.equal(dybt, dyb.t().contiguous())
-        assert rel_l2(part.sum(0).cpu(), eff.sum(0).cpu()) < 2e-5
+        assert rel_l2(dyb.float().cpu(), eff.cpu()) < 3e-3 and torch.equal(dybt, dyb.t().contiguous()), case
+        assert rel_l2(part.sum(0).cpu(), eff.sum(0).cpu()) < 2e-5, case
         # the pair launch: dx = dy . W, dW = dy^T . x, db = the sum of the partials
         xb = _bf(torch.randn(M, K, generator=g)).cuda().contiguous()
         w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
@@ -136,6 +144,34 @@ def test_linear_backward_operand_pass_and_pair_bias_sum(lib):
         torch.cuda.synchronize()
         assert rel_l2(db.cpu(), part.sum(0).cpu()) < 1e-6
         assert rel_l2(dx.cpu(), (dyb.float() @ _bf(w).float()).cpu()) < 2e-6 and rel_l2(dw.cpu(), (dyb.float().T @ xb.float()).cpu()) < 2e-6
+        db2 = torch.empty(N, device="cuda")
+        lib.check(L.syn_colsum_parts(part.data_ptr(), M // 64, N, db2.data_ptr(), st), "syn_colsum_parts")
+        assert torch.equal(db2, db)
+
+
+def test_linear_pair_on_128_column_shapes(lib):
+    """syn_linear_pair where an output width is a multiple of 128 but not of 512 (input_process2: 1280 input features; mix_audio_text: 256 outputs):
+    the pair runs on the 128-column tiles, and equals two syn_linear launches bitwise."""
+    from syntalker_amd import training
+    g = torch.Generator().manual_seed(19)
+    L, st = lib.load(), lib.current_stream()
+    for M, N, K in ((1024, 512, 1280), (1024, 256, 512), (4096, 256, 384)):
+        dyb = _bf(torch.randn(M, N, generator=g)).cuda().contiguous()
+        dybt = dyb.t().contiguous()
+        xb = _bf(torch.randn(M, K, generator=g)).cuda().contiguous()
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+        wt, xt = training._pack_t(w, K, N), training._pack_t(xb, K, M)
+        part = torch.randn(M // 64, N, generator=g).cuda()
+        dx, dw, db = torch.empty(M, K, device="cuda"), torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda")
+        lib.check(L.syn_linear_pair(dyb.data_ptr(), wt.data_ptr(), M, K, N, dx.data_ptr(), dybt.data_ptr(), xt.data_ptr(), N, K, M, dw.data_ptr(),
+                                    part.data_ptr(), M // 64, N, db.data_ptr(), st), "syn_linear_pair")
+        dx1, dw1 = torch.empty_like(dx), torch.empty_like(dw)
+        lib.check(L.syn_linear(dyb.data_ptr(), wt.data_ptr(), None, M, K, N, dx1.data_ptr(), st), "syn_linear")
+        lib.check(L.syn_linear(dybt.data_ptr(), xt.data_ptr(), None, N, K, M, dw1.data_ptr(), st), "syn_linear")
+        torch.cuda.synchronize()
+        assert torch.equal(dx, dx1) and torch.equal(dw, dw1), (M, N, K)
+        assert rel_l2(db.cpu(), part.sum(0).cpu()) < 1e-6
+        assert rel_l2(dx.cpu(), (dyb.float() @ _bf(w).float()).cpu()) < 2e-6 and rel_l2(dw.cpu(), (dyb.float().T @ xb.float()).cpu()) < 3e-6
 
 
 def test_gemm_tile_sizes_agree_bitwise(lib):
@@ -318,7 +354,6 @@ def test_fused_residual_branches_equal_the_op_by_op_composition():
         packs.refresh()
         training._packs = packs
         try:
-            assert training._fused_ok(B * 32, *layers)
             h0 = torch.randn(B, 32, 512, device=dev)
             up = torch.randn(B, 32, 512, device=dev)
             for factors in (None, torch.empty(2, B, 1, 1, device=dev).bernoulli_(0.7).div_(0.7)):
@@ -554,87 +589,116 @@ def test_training_conv_forward_on_split_operands_vs_fp32(cin, stride, cout, pad,
         lib.syn_debug_conv_terms(-1)
 
 
-def test_embedding_gradient_vs_torch():
-    """syn_embedding_wgrad (training.EmbeddingFn: the word-embedding table's gradient, one deterministic launch) against
-    torch.nn.functional.embedding's autograd: repeated ids, untouched rows exactly zero, a vocabulary that is not a multiple of the
-    block's 16 rows, bitwise run-to-run."""
-    from syntalker_amd import training
+def test_embedding_gradient_vs_torch(lib):
+    """syn_embedding_wgrad (the word-embedding table's gradient: a memset node + one deterministic launch) against
+    torch.nn.functional.embedding's autograd: repeated ids, untouched rows exactly zero, dy read as a column slice of a wider tensor (pitch 384:
+    text_encoder_body's padded data gradient), bitwise run-to-run; and syn_embed_rows_bf16 = bf16(table[ids]) with zero padding."""
     DEV = "cuda"
     g = torch.Generator().manual_seed(11)
-    V, D = 11195, 300
-    w = torch.randn(V, D, generator=g).to(DEV).requires_grad_(True)
+    V, D, LD = 11195, 300, 384
+    w = torch.randn(V, D, generator=g).to(DEV)
     ids = torch.randint(0, V, (32, 128), generator=g)
     ids[:, :40] = torch.randint(0, 50, (32, 40), generator=g)         # heavy repeats
     ids[0, 0], ids[0, 1] = 0, V - 1
-    ids = ids.to(DEV)
-    dy = torch.randn(32, 128, D, generator=g).to(DEV)
+    ids = ids.to(DEV).reshape(-1).contiguous()
+    n = ids.numel()
+    dyw = torch.randn(n, LD, generator=g).to(DEV)
+    L, st = lib.load(), lib.current_stream()
     outs = []
     for _ in range(2):
-        w.grad = None
-        y = training.EmbeddingFn.apply(ids, w)
-        assert torch.equal(y, w.detach()[ids])
-        y.backward(dy)
-        outs.append(w.grad.clone())
+        dw = torch.full((V, D), float("nan"), device=DEV)
+        lib.check(L.syn_embedding_wgrad(ids.data_ptr(), dyw.data_ptr(), LD, n, V, D, dw.data_ptr(), st), "syn_embedding_wgrad")
+        outs.append(dw)
     assert torch.equal(*outs)
-    w2 = w.detach().clone().requires_grad_(True)
-    torch.nn.functional.embedding(ids, w2).backward(dy)
+    w2 = w.clone().requires_grad_(True)
+    torch.nn.functional.embedding(ids, w2).backward(dyw[:, :D].contiguous())
     assert rel_l2(outs[0].cpu(), w2.grad.cpu()) < 1e-6
-    untouched = torch.ones(V, dtype=torch.bool); untouched[ids.cpu().reshape(-1)] = False
+    untouched = torch.ones(V, dtype=torch.bool); untouched[ids.cpu()] = False
     assert float(outs[0].cpu()[untouched].abs().max()) == 0.0
+    E = torch.full((n, LD), 7.0, dtype=torch.bfloat16, device=DEV)
+    lib.check(L.syn_embed_rows_bf16(ids.data_ptr(), w.data_ptr(), V, D, n, LD, E.data_ptr(), st), "syn_embed_rows_bf16")
+    assert torch.equal(E[:, :D], w[ids].bfloat16()) and float(E[:, D:].float().abs().max()) == 0.0
 
 
-def test_step_weight_packs_and_in_launch_bias_gradient(monkeypatch):
-    """syn_pack_weights (every Linear weight and its transpose as bf16 fragments, one launch) against the per-use packers,
-    bitwise; a weight updated in place falls out of the cache until the next refresh; and syn_linear_bwd_prep's bias gradient
-    from the same launch (arrival counter, last block adds the partial sums) against dy.sum(0), twice in a row (the counters
-    reset themselves) and bitwise run-to-run."""
+def test_glue_kernels_vs_torch(lib):
+    """csrc/syn_glue.inc against the PyTorch ops they stand for: the concatenated bf16 operand (per-clip vectors repeated over the frames, a sum of two,
+    an average pool over 4 rows, zero padding), the (B, C, 1, T) -> rows transpose, group sums, the pool's backward."""
+    DEV = "cuda"
+    g = torch.Generator().manual_seed(23)
+    L, st = lib.load(), lib.current_stream()
+    B, T, D, A = 8, 32, 512, 256
+    M = B * T
+    es, et = torch.randn(B, D, generator=g).to(DEV), torch.randn(B, D, generator=g).to(DEV)
+    x_ = torch.randn(M, D, generator=g).to(DEV)
+    at4 = torch.randn(M * 4, A, generator=g).to(DEV)
+    arr = (lib.SynConcatSrc * 3)()
+    for i, (t, t2, width, ld, div, pool) in enumerate(((es, et, D, D, T, 1), (x_, None, D, D, 1, 1), (at4, None, A, A, 1, 4))):
+        arr[i].p, arr[i].p2, arr[i].width, arr[i].ld, arr[i].row_div, arr[i].pool = t.data_ptr(), lib.ptr(t2), width, ld, div, pool
+    out_ld = 1408                                                     # 1280 columns + padding
+    out = torch.full((M, out_ld), 7.0, dtype=torch.bfloat16, device=DEV)
+    lib.check(L.syn_rows_concat_bf16(arr, 3, M, out_ld, out.data_ptr(), st), "syn_rows_concat_bf16")
+    want = torch.cat([(es + et).repeat_interleave(T, 0), x_, at4.view(M, 4, A).mean(1)], 1)
+    assert rel_l2(out[:, :1280].float().cpu(), want.bfloat16().float().cpu()) < 1e-3 and float(out[:, 1280:].float().abs().max()) == 0.0
+    assert torch.equal(out[:, :1024], want[:, :1024].bfloat16())       # (no arithmetic but one add: exact)
+    x = torch.randn(B, 1536, 1, T, generator=g).to(DEV)
+    xr = torch.empty(M, 1536, dtype=torch.bfloat16, device=DEV)
+    lib.check(L.syn_bct_to_rows_bf16(x.data_ptr(), B, 1536, T, xr.data_ptr(), st), "syn_bct_to_rows_bf16")
+    assert torch.equal(xr.view(B, T, 1536), x.reshape(B, 1536, T).transpose(1, 2).bfloat16())
+    wide = torch.randn(M, 1280, generator=g).to(DEV)
+    gs = torch.empty(B, D, device=DEV)
+    lib.check(L.syn_rows_group_sum(wide.data_ptr() + 4 * 512, 1280, D, T, B, gs.data_ptr(), st), "syn_rows_group_sum")
+    assert rel_l2(gs.cpu(), wide[:, 512:1024].reshape(B, T, D).sum(1).cpu()) < 1e-6
+    ex = torch.empty(M * 4, A, device=DEV)
+    lib.check(L.syn_rows_expand(wide.data_ptr() + 4 * 1024, 1280, A, 4, 0.25, M * 4, ex.data_ptr(), st), "syn_rows_expand")
+    assert torch.equal(ex, wide[:, 1024:1280].repeat_interleave(4, 0) * 0.25)
+    lib.check(L.syn_touch(wide.data_ptr(), wide.numel() * 4, st), "syn_touch")
+    torch.cuda.synchronize()
+
+
+def test_step_weight_packs_and_linear_node():
+    """syn_pack_weights (every Linear weight and its transpose as bf16 fragments, one launch; an input width that is not a multiple of 128 zero-padded)
+    against the per-use packers, bitwise; a weight updated in place falls out of the cache until the next refresh; `HipLinearFn` on those packs and on
+    packs made on the spot: the same bits, run-to-run identical, against torch on the bf16-rounded operands - at the shapes of the step (1024 rows),
+    of input_process2 (1280 inputs), of text_encoder_body (300 inputs, 4096 rows), and at a row count that is not a multiple of 128."""
     from syntalker_amd import training, engine
+    import torch.nn.functional as F
     DEV = "cuda"
     g = torch.Generator().manual_seed(5)
-    ws = [torch.randn(n, k, generator=g).to(DEV) for n, k in ((512, 512), (1536, 512), (512, 2048), (1024, 512), (256, 300))]
+    ws = [torch.randn(n, k, generator=g).to(DEV) for n, k in ((512, 512), (1536, 512), (512, 2048), (1024, 512), (256, 300), (512, 1280))]
     pk = training.WeightPacks(ws)
     pk.refresh()
-    for w in ws[:4]:
+    for w in ws:
         N, K = w.shape
+        Kp = (K + 127) // 128 * 128
+        wpad = F.pad(w, (0, Kp - K)).contiguous()
         fwd, tr = pk.lookup(w)
-        assert fwd is not None and torch.equal(fwd, engine.pack_weight(w).view(torch.uint8).reshape(-1))
-        if K % 512 == 0 and N % 128 == 0:
-            assert torch.equal(tr, training._pack_t(w, K, N))
-    assert pk.lookup(ws[4]) == (None, None)                        # (256, 300): not a shape the GEMM takes unpadded
+        assert torch.equal(fwd, engine.pack_weight(wpad).view(torch.uint8).reshape(-1)), (N, K)
+        assert torch.equal(tr, training._pack_t(wpad, Kp, N)), (N, K)
     ws[0].add_(1.0)
     assert pk.lookup(ws[0]) == (None, None)                        # stale until the next refresh
     pk.refresh()
     assert torch.equal(pk.lookup(ws[0])[0], engine.pack_weight(ws[0]).view(torch.uint8).reshape(-1))
-    training._packs = pk
-    monkeypatch.setattr(training, "LINEAR_BWD_PREP", 3)
-    for M, N, K in ((1024, 512, 512), (128, 1536, 512), (1024, 512, 2048)):
+    for M, N, K in ((1024, 512, 512), (128, 1536, 512), (1024, 512, 2048), (1024, 512, 1280), (4096, 256, 300), (160, 512, 512)):
         w = next(t for t in ws if t.shape == (N, K)).requires_grad_(True)
         b = torch.randn(N, generator=g).to(DEV).requires_grad_(True)
         x = torch.randn(M, K, generator=g).to(DEV).requires_grad_(True)
         dy = torch.randn(M, N, generator=g).to(DEV)
         grads = []
-        for _ in range(2):
-            w.grad = b.grad = x.grad = None
-            training.HipLinearFn.apply(x, w, b).backward(dy)
-            grads.append((b.grad.clone(), x.grad.clone(), w.grad.clone()))
-        assert all(torch.equal(p, q) for p, q in zip(*grads))
-        monkeypatch.setattr(training, "LINEAR_BWD_PAIR", False)       # the two backward GEMMs as two launches: the same bits
-        w.grad = b.grad = x.grad = None
-        training.HipLinearFn.apply(x, w, b).backward(dy)
-        assert torch.equal(x.grad, grads[0][1]) and torch.equal(w.grad, grads[0][2])
-        monkeypatch.setattr(training, "LINEAR_BWD_PAIR", True)
-        monkeypatch.setattr(training, "LINEAR_FWD_PACK", False)      # x^T packed by its own launch in the backward: the same bits
-        w.grad = b.grad = x.grad = None
-        y2 = training.HipLinearFn.apply(x, w, b)
-        y2.backward(dy)
-        assert torch.equal(x.grad, grads[0][1]) and torch.equal(w.grad, grads[0][2])
-        monkeypatch.setattr(training, "LINEAR_FWD_PACK", True)
-        assert torch.equal(y2, training.HipLinearFn.apply(x, w, b))
-        assert rel_l2(grads[0][0].cpu(), dy.sum(0).cpu()) < 1e-6
+        for cached in (True, True, False):
+            training._packs = pk if cached else None
+            try:
+                w.grad = b.grad = x.grad = None
+                y = training.HipLinearFn.apply(x, w, b)
+                y.backward(dy)
+                grads.append((y.detach().clone(), b.grad.clone(), x.grad.clone(), w.grad.clone()))
+            finally:
+                training._packs = None
+        assert all(torch.equal(p, q) for p, q in zip(grads[0], grads[1])) and all(torch.equal(p, q) for p, q in zip(grads[0], grads[2])), (M, N, K)
         xb, wb, dyb = x.detach().bfloat16().float(), w.detach().bfloat16().float(), dy.bfloat16().float()
-        assert rel_l2(grads[0][1].cpu(), (dyb @ wb).cpu()) < 1e-5 and rel_l2(grads[0][2].cpu(), (dyb.t() @ xb).cpu()) < 1e-5
+        assert rel_l2(grads[0][0].cpu(), (xb @ wb.t() + b.detach()).cpu()) < 1e-5
+        assert rel_l2(grads[0][1].cpu(), dy.sum(0).cpu()) < 1e-5
+        assert rel_l2(grads[0][2].cpu(), (dyb @ wb).cpu()) < 1e-5 and rel_l2(grads[0][3].cpu(), (dyb.t() @ xb).cpu()) < 1e-5, (M, N, K)
         w.requires_grad_(False)
-    training._packs = None
 
 
 @pytest.mark.parametrize("cin,stride,pad,L", [(1, 5, 1700, 6001), (2, 5, 1700, 12345), (2, 5, 0, 644), (1, 3, 4, 77)])
@@ -753,68 +817,78 @@ def test_sync_batchnorm_over_two_emulated_ranks_vs_torch_autograd(C, L, short, a
     assert rel_l2(dg.cpu(), g2.grad.cpu()) < 1e-4 and rel_l2(db.cpu(), b2.grad.cpu()) < 1e-4
 
 
-def test_fused_rotary_equals_the_op_by_op_chain(monkeypatch):
-    """`syn_rotary` (training.RotaryFn) against the reference's own chain of views / cat / mul / add on the hidden state
-    (models/denoiser.py:178-186, 324-343), forward and gradient."""
+def test_fused_rotary_equals_the_op_by_op_chain():
+    """`syn_rotary` against the reference's own chain of views / cat / mul / add on the hidden state (models/denoiser.py:178-186, 324-343), forward,
+    and its inverse launch against that chain's autograd gradient."""
     from syntalker_amd import synth, training
     from syntalker_amd.denoiser import MDM
     m = MDM(synth.default_args()).cuda()
     g = torch.Generator().manual_seed(3)
     h = torch.randn(5, 32, 512, generator=g).cuda().requires_grad_(True)
     w = torch.randn(5, 32, 512, generator=g).cuda()
-    outs = []
-    for fused in (False, True):
-        monkeypatch.setattr(training, "ROTARY_FUSED", fused)
-        h.grad = None
-        y = training._rotary(m, h)
-        (y * w).sum().backward()
-        outs.append((y.detach().clone(), h.grad.clone()))
-    assert float((outs[0][0] - outs[1][0]).abs().max()) < 2e-6 and float((outs[0][1] - outs[1][1]).abs().max()) < 2e-6
-    assert float((outs[1][0].norm(dim=-1) - h.detach().norm(dim=-1)).abs().max()) < 1e-3          # a rotation
+    B, T, _ = h.shape
+    gq = h.view(B, T, 8, -1).permute(0, 2, 1, 3).reshape(B * 8, T, -1)
+    pos = torch.arange(T, device=h.device).type_as(m.rel_pos.inv_freq)
+    fr = torch.einsum("i,j->ij", pos, m.rel_pos.inv_freq)
+    fr = torch.cat((fr, fr), dim=-1)
+    half = gq.shape[-1] // 2
+    gq = gq * fr.cos() + torch.cat((-gq[..., half:], gq[..., :half]), dim=-1) * fr.sin()
+    want = gq.reshape(B, 8, T, -1).permute(0, 2, 1, 3).reshape(B, T, -1)
+    (want * w).sum().backward()
+    cs, sn = training._rotary_tables(m, T, h.device)
+    y = training._rotary_launch(h.detach().contiguous(), cs, sn, False)
+    dh = training._rotary_launch(w.contiguous(), cs, sn, True)
+    assert float((y - want.detach()).abs().max()) < 2e-6 and float((dh - h.grad).abs().max()) < 2e-6
+    assert float((y.norm(dim=-1) - h.detach().norm(dim=-1)).abs().max()) < 1e-3          # a rotation
 
 
-def test_small_row_linear_gradients_vs_torch(monkeypatch):
+def test_small_row_linear_gradients_vs_torch():
     """`syn_linear_wgrad_rows` through HipLinearFn (the timestep MLP / embed_text case: one row per clip) against fp32 autograd on the same
-    bf16-rounded input, and against the GEMM path it replaces."""
+    bf16-rounded input."""
     from syntalker_amd import training
     g = torch.Generator().manual_seed(4)
-    for M, K, N in ((32, 512, 512), (4, 6144, 512), (64, 512, 1536)):
+    for M, K, N in ((32, 512, 512), (4, 6144, 512), (64, 512, 1536), (3, 512, 512)):
         x = torch.randn(M, K, generator=g).cuda().requires_grad_(True)
         w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda().requires_grad_(True)
         b = torch.randn(N, generator=g).cuda().requires_grad_(True)
         dy = torch.randn(M, N, generator=g).cuda()
-        got = {}
-        for small in (True, False):
-            monkeypatch.setattr(training, "SMALL_M_WGRAD", small)
-            for t in (x, w, b):
-                t.grad = None
-            training.HipLinearFn.apply(x, w, b).backward(dy)
-            got[small] = (x.grad.clone(), w.grad.clone(), b.grad.clone())
-        xr = _bf(x.detach()).float()
-        want_w, want_b = dy.t() @ xr, dy.sum(0)
-        assert rel_l2(got[True][1], want_w) < 1e-6 and rel_l2(got[True][2], want_b) < 1e-6          # fp32 FMAs on the operand the forward took
-        assert rel_l2(got[False][1], want_w) < 1e-2                                                 # (the MFMA path rounds dy to bf16 as well)
-        assert rel_l2(got[True][0], got[False][0]) < 1e-6                                           # the data gradient is the same launch either way
+        y = training.HipLinearFn.apply(x, w, b)
+        y.backward(dy)
+        xr, wr = _bf(x.detach()).float(), _bf(w.detach()).float()
+        assert rel_l2(y.detach(), xr @ wr.t() + b.detach()) < 1e-5
+        assert rel_l2(w.grad, dy.t() @ xr) < 1e-6 and rel_l2(b.grad, dy.sum(0)) < 1e-6            # fp32 FMAs on the operand the forward took
+        assert rel_l2(x.grad, _bf(dy).float() @ wr) < 1e-5
 
 
-def test_fused_masked_smooth_l1_vs_torch(monkeypatch):
-    """`syn_masked_smooth_l1` (loss + gradient in one launch) against the reference's masked_l2 composition (gaussian_diffusion.py:202-215)."""
+def test_fused_masked_smooth_l1_vs_torch():
+    """`syn_masked_smooth_l1` / `_grad` against the reference's masked_l2 composition (gaussian_diffusion.py:202-215): `out` as a (B, C, 1, T) tensor
+    and as the permuted view of [B][T][C] rows that the training forward returns (read and differentiated in place, no permuted copy)."""
     from syntalker_amd import training
     from syntalker_amd.process import create_gaussian_diffusion
     d = create_gaussian_diffusion()
     g = torch.Generator().manual_seed(5)
     a = torch.randn(6, 1536, 1, 32, generator=g).cuda()
-    b = (a + 1.5 * torch.randn(6, 1536, 1, 32, generator=g).cuda()).requires_grad_(True)          # both branches of the SmoothL1
+    b0 = a + 1.5 * torch.randn(6, 1536, 1, 32, generator=g).cuda()                                 # both branches of the SmoothL1
     mask = (torch.rand(6, 1, 1, 32, generator=g) < 0.8).cuda()
     wgt = torch.rand(6, generator=g).cuda()
-    res = {}
-    for fused in (True, False):
-        monkeypatch.setattr(training, "LOSS_FUSED", fused)
-        b.grad = None
-        loss = d.masked_l2(a, b, mask)
+    b = b0.clone().requires_grad_(True)
+    ref = torch.nn.functional.smooth_l1_loss(a, b, reduction="none") * mask.float()
+    ref = ref.sum(dim=[1, 2, 3]) / (mask.sum(dim=[1, 2, 3]) * 1536)
+    (ref * wgt).sum().backward()
+    want = (ref.detach().clone(), b.grad.clone())
+    for rows in (False, True):
+        if rows:
+            base = b0.reshape(6, 1536, 32).transpose(1, 2).contiguous().requires_grad_(True)      # [B][T][C]
+            out = base.permute(0, 2, 1).unsqueeze(2)
+            assert training._is_rows_view(out)
+        else:
+            base = out = b0.clone().requires_grad_(True)
+        loss = d.masked_l2(a, out, mask)
         (loss * wgt).sum().backward()
-        res[fused] = (loss.detach().clone(), b.grad.clone())
-    assert res[True][0].shape == (6,) and rel_l2(res[True][0], res[False][0]) < 1e-6 and rel_l2(res[True][1], res[False][1]) < 1e-6
+        grad = base.grad.permute(0, 2, 1).unsqueeze(2) if rows else base.grad
+        assert loss.shape == (6,) and rel_l2(loss.detach(), want[0]) < 1e-6 and rel_l2(grad, want[1]) < 1e-6, rows
+        if rows:
+            assert base.grad.is_contiguous()
 
 
 @pytest.mark.parametrize("B,drop", [(4, False), (12, True), (32, True)])

@@ -515,8 +515,8 @@ def test_train_mode_loss_gradients_and_bn_buffers_vs_golden(golden):
 def test_fused_wav_block_equals_the_per_convolution_nodes():
     """training.WavBlockFn (round 5: a BasicBlock of the audio encoder as one autograd node - bn1 + LeakyReLU applied by conv2 as it stages its
     tile, the shortcut's BatchNorm inside the block's one elementwise pass, one statistics + one apply pass for both BatchNorms in the backward,
-    no z1 / shortcut / output saved) against the per-convolution nodes it replaces (`_conv_bn_act`: the path the train-mode golden was first
-    pinned on): same loss, every parameter gradient, the BatchNorm buffers.  Differences are fp32 reassociation (a(v) = v * scale + shift
+    no z1 / shortcut / output saved) against the per-convolution nodes (`_conv_bn_act`: the path SyncBatchNorm takes, and the one the train-mode
+    golden was first pinned on): same loss, every parameter gradient, the BatchNorm buffers.  Differences are fp32 reassociation (a(v) = v * scale + shift
     against (v - mean) * rstd * gamma + beta) on top of the split-operand convolutions."""
     from syntalker_amd import training
     from syntalker_amd.process import create_gaussian_diffusion
@@ -525,18 +525,16 @@ def test_fused_wav_block_equals_the_per_convolution_nodes():
     t4 = torch.tensor([0, 17, 500, 999], device=DEV)
     d = create_gaussian_diffusion()
     res = {}
-    keep = training.WAV_BLOCK_FUSED
-    try:
-        for fused in (False, True):
-            training.WAV_BLOCK_FUSED = fused
-            m = _model("beatx").train()
-            m.drop_path = 0.0
-            loss = d.training_losses(m, x0, t4, model_kwargs={"y": y}, noise=eps)["loss"]
-            loss.mean().backward()
-            res[fused] = (loss.detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None},
-                          {k: v.detach().cpu() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k})
-    finally:
-        training.WAV_BLOCK_FUSED = keep
+    for fused in (False, True):
+        m = _model("beatx").train()
+        if not fused:                                   # SyncBatchNorm (train.py:90; one rank here) takes the per-convolution nodes
+            m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
+            assert not training._wav_block_fused_ok(m.WavEncoder.feat_extractor[1], torch.zeros(1, device=DEV), False)
+        m.drop_path = 0.0
+        loss = d.training_losses(m, x0, t4, model_kwargs={"y": y}, noise=eps)["loss"]
+        loss.mean().backward()
+        res[fused] = (loss.detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None},
+                      {k: v.detach().cpu() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k})
     (l0, g0, b0), (l1, g1, b1) = res[False], res[True]
     assert torch.allclose(l0, l1, rtol=5e-4), (l0, l1)      # (bf16 operands downstream: an fp32-rounding difference in the conditioning flips bf16 roundings)
     assert g0.keys() == g1.keys()
@@ -557,9 +555,9 @@ def test_fused_wav_block_equals_the_per_convolution_nodes():
         assert torch.allclose(b0[k].double(), b1[k].double(), rtol=1e-5, atol=1e-6), k
 
 
-def test_persistent_stack_forward_equals_the_per_branch_nodes():
-    """training.StackFn (round 5: the eight blocks' training forward as ONE persistent launch, `syn_train_stack_fwd` = the sampling path's whole-step
-    kernel in its tile-split mode + DropPath + the tensors the backward takes) against the per-branch nodes it replaces (`AttnBranchFn` /
+def test_persistent_stack_forward_equals_the_per_branch_nodes(monkeypatch):
+    """training.StackFn (round 5: the eight blocks' training forward and backward as persistent launches, `syn_train_stack_fwd` = the sampling path's
+    whole-step kernel in its tile-split mode + DropPath + the tensors the backward takes) against the per-branch nodes larger batches run (`AttnBranchFn` /
     `MlpBranchFn`): loss and every parameter gradient, with DropPath factors drawn from the same generator state.  The two forwards differ where
     the sampling kernels do: q / k / v and the softmax numerators are rounded to bf16 for the attention's MFMAs (fp32 in `syn_attn_fwd`)."""
     from syntalker_amd import training
@@ -569,18 +567,17 @@ def test_persistent_stack_forward_equals_the_per_branch_nodes():
     t5 = torch.tensor([0, 17, 500, 999, 250, 3, 750, 100], device=DEV)      # (8 clips: the fused paths take row counts that are multiples of 128)
     d = create_gaussian_diffusion()
     res = {}
-    keep = training.STACK_FUSED
-    try:
-        for fused in (False, True):
-            training.STACK_FUSED = fused
-            m = _model("beatx").train()
-            m.drop_path = 0.25
-            torch.manual_seed(1234)
-            loss = d.training_losses(m, x0, t5, model_kwargs={"y": y}, noise=eps)["loss"]
-            loss.mean().backward()
-            res[fused] = (loss.detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None})
-    finally:
-        training.STACK_FUSED = keep
+    for fused in (False, True):
+        if not fused:
+            monkeypatch.setattr(training, "_stack_ok", lambda *a: False)       # the path batches of more than 64 clips take
+        else:
+            monkeypatch.undo()
+        m = _model("beatx").train()
+        m.drop_path = 0.25
+        torch.manual_seed(1234)
+        loss = d.training_losses(m, x0, t5, model_kwargs={"y": y}, noise=eps)["loss"]
+        loss.mean().backward()
+        res[fused] = (loss.detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None})
     (l0, g0), (l1, g1) = res[False], res[True]
     print("persistent stack vs per-branch nodes, loss ratio:", (l1 / l0).numpy())
     assert torch.allclose(l0, l1, rtol=1e-2), (l0, l1)
@@ -594,47 +591,6 @@ def test_persistent_stack_forward_equals_the_per_branch_nodes():
         worst = max(worst, (n, e), key=lambda v: v[1])
         assert e < 3e-2, (n, e)
     print(f"persistent stack vs per-branch nodes: worst gradient rel-L2 {worst[1]:.2e} ({worst[0]})")
-
-
-def test_persistent_stack_backward_equals_the_per_branch_chain():
-    """`syn_train_stack_bwd` + `syn_train_stack_wgrad` (round 5: the blocks' data-gradient chain as one persistent launch - MFMA attention backward, GELU',
-    LayerNorm backward, DropPath - and the 32 weight-gradient GEMMs four per launch) against the per-branch backward chain (`_mlp_branch_bwd` /
-    `_attn_branch_bwd`: `syn_linear_bwd_prep` + `syn_linear_pair` + `syn_attn_bwd` + `syn_ln_bwd`) behind the SAME persistent forward: the forward is
-    bit-identical in both runs, so every difference is the backward's (bf16 attention operands where `syn_attn_bwd` is fp32)."""
-    from syntalker_amd import training
-    from syntalker_amd.process import create_gaussian_diffusion
-    y = synth.to_device(synth.synth_clip_inputs(8, seed=5, mask_batch=8), DEV)
-    x0, eps = synth.synth_latent(8, seed=5, name="x0").to(DEV), synth.synth_latent(8, seed=6, name="eps").to(DEV)
-    t8 = torch.tensor([0, 17, 500, 999, 250, 3, 750, 100], device=DEV)
-    d = create_gaussian_diffusion()
-    res = {}
-    keep = training.STACK_BWD_FUSED
-    try:
-        for fused in (False, True):
-            training.STACK_BWD_FUSED = fused
-            m = _model("beatx").train()
-            m.drop_path = 0.25
-            torch.manual_seed(1234)
-            loss = d.training_losses(m, x0, t8, model_kwargs={"y": y}, noise=eps)["loss"]
-            loss.mean().backward()
-            res[fused] = (loss.detach().cpu(), {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None})
-    finally:
-        training.STACK_BWD_FUSED = keep
-    (l0, g0), (l1, g1) = res[False], res[True]
-    assert torch.equal(l0, l1)
-    assert g0.keys() == g1.keys()
-    worst = ("", 0.0)
-    for n in g0:
-        if float(g0[n].norm()) < 1e-6:
-            assert float(g1[n].norm()) < 1e-6, n
-            continue
-        e = rel_l2(g1[n], g0[n])
-        worst = max(worst, (n, e), key=lambda v: v[1])
-        assert e < 2e-2, (n, e)
-    print(f"persistent backward vs per-branch chain: worst gradient rel-L2 {worst[1]:.2e} ({worst[0]})")
-    for n in ("mytimmblocks.7.mlp.fc2.bias", "mytimmblocks.7.mlp.fc2.weight", "mytimmblocks.7.norm2.weight", "mytimmblocks.7.mlp.fc1.weight", "mytimmblocks.7.attn.proj.weight",
-              "mytimmblocks.7.attn.qkv.weight", "mytimmblocks.7.norm1.weight", "mytimmblocks.0.attn.qkv.weight", "input_process2.weight"):
-        print(f"   {n}: {rel_l2(g1[n], g0[n]):.2e}")
 
 
 def test_sync_batchnorm_model_on_the_native_path(golden):
@@ -857,7 +813,6 @@ def test_captured_train_step_at_the_bench_size_replays_back_to_back(beatx):
     embedding_dense_backward, replaced by training.EmbeddingFn.  Loss finite and falling on a fixed batch."""
     from syntalker_amd import training
     from syntalker_amd.process import create_gaussian_diffusion
-    assert training.LINEAR_BWD_PREP >= 2
     B = 32
     m = _model("beatx").train()
     d = create_gaussian_diffusion()
@@ -867,7 +822,6 @@ def test_captured_train_step_at_the_bench_size_replays_back_to_back(beatx):
     x0 = synth.synth_latent(B, seed=62, name="x0").to(DEV)
     t = (torch.arange(B, device=DEV) * 31) % 1000
     step = training.GraphedTrainStep(m, d, opt, x0, {"y": y})
-    assert not step.sync
     losses = [step(x0, t, {"y": y}).clone() for _ in range(40)]          # (clones are stream-ordered copies of the static loss)
     torch.cuda.synchronize()
     step.close()
