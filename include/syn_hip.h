@@ -94,7 +94,9 @@ typedef struct syn_step {
     const float*   cond;    /* [V*B*32][512] per-clip term: cbias + c_frame + seed/style term    */
     const int32_t* t_model; /* [V*B] ORIGINAL timestep -> row of syn_model.te                    */
     const float*   cfg_w;   /* [3][V] weights of the variants for output channels 0:512, 512:1024,
-                               1024:1536; NULL iff V == 1                                        */
+                               1024:1536; NULL iff V == 1.  With cfg_w_clip_stride = 3 V (below):
+                               [B][3][V], one table per clip - the reference's per-sample guidance
+                               scales, y['scale'].view(-1, 1, 1, 1) (diffusion/cfg_sampler.py:28,54,167) */
     /* state, token-major */
     const float*   x_t;       /* [B*32][1536] fp32                                               */
     const void*    x_t_bf16;  /* [B*32][1536] bf16 copy of x_t (GEMM operand)                    */
@@ -127,7 +129,7 @@ typedef struct syn_step {
                           wave-per-sequence kernel's fragment order (syn_x_to_fragment), and that kernel runs the step
                           (n_variants <= 4, syn_model.tape non-NULL; of the workspaces only cfg_w is used).  syn_prefers_fragment_order() says when the
                           library would like a caller to keep its latent that way.                                   */
-    int32_t reserved2;
+    int32_t cfg_w_clip_stride; /* (ABI 8) floats between the cfg_w tables of consecutive clips: 0 = one table for the batch, 3 * n_variants = one per clip */
 } syn_step;
 
 /* 1 when a step over n_clips x n_variants is best run by the wave-per-sequence kernel, i.e. the caller should keep the
@@ -432,8 +434,9 @@ int syn_opt_scalars(const float* partials, int32_t n_partials, float max_norm, c
                     float* scal4, void* stream);
 int syn_opt_adam(const syn_opt_list* l, const float* scal4, float beta1, float beta2, float eps, float weight_decay, void* stream);
 /* Gradient of an nn.Embedding table (models/denoiser.py:72, the word embedding in front of text_encoder_body): dw [vocab][dim] =
- * sum over the positions p with ids[p] == v of dy[p][:], added in increasing p (no atomics on the result; a memset node zeroes dw first).
- * ids int64 [n_pos] (n_pos <= 8192 per call), dy fp32 rows of pitch ld >= dim (ABI 8: a column slice of the next Linear's data gradient), dim <= 512. */
+ * sum over the positions p with ids[p] == v of dy[p][:], added in increasing p (no atomics on the result; every row written by the one launch).
+ * ids int64 [n_pos] (n_pos <= 8192 per call), dy fp32 rows of pitch ld >= dim (ABI 8: a column slice of the next Linear's data gradient), dim <= 512,
+ * vocab <= 65536. */
 int syn_embedding_wgrad(const int64_t* ids, const float* dy, int32_t ld, int32_t n_pos, int32_t vocab, int32_t dim, float* dw, void* stream);
 /* Backward of an nn.Linear, the operand preparation in one pass over its output gradient [m_rows][n] fp32: the bf16 copy (data-gradient GEMM),
  * the bf16 transpose [n][m_rows] (weight-gradient GEMM) and colsum_part [m_rows / 64][n] = column sums of every 64-row block

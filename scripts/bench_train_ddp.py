@@ -42,6 +42,7 @@ def run(capturable):
     torch.cuda.synchronize(); dist.barrier(); dt = (time.perf_counter() - t0) / n
     torch.cuda.synchronize()
     check = float(sum(p.detach().double().abs().sum() for p in m.parameters()))
+    params = {k: v.detach().clone() for k, v in m.named_parameters()}
     note = ""
     if capturable:
         # gradients written straight into DDP's buckets (training.bind_grad_buffers): every bound parameter's .grad IS its bucket view
@@ -53,11 +54,11 @@ def run(capturable):
         print(f"{'graph-replayed' if capturable else 'eager'} DDP step, {world} rank(s) x {B} clips: {dt*1e3:.2f} ms "
               f"({world*B/dt:.0f} samples/s){note}, parameter checksum {check:.6f}, loss {float(loss):.4f}", flush=True)
     if capturable: g.close()
-    return check
+    return check, params
 
 
 run(False)
-c0 = run(True)
-c1 = run(True)
-assert c0 == c1, (c0, c1)            # two captured runs from the same seeds: the same parameters bit for bit (every reduction in a fixed order)
+c0, p0 = run(True)
+c1, p1 = run(True)
+assert c0 == c1, (c0, c1, [(k, float((p0[k] - p1[k]).abs().max())) for k in p0 if not torch.equal(p0[k], p1[k])][:12])            # two captured runs from the same seeds: the same parameters bit for bit (every reduction in a fixed order)
 dist.barrier(); dist.destroy_process_group()

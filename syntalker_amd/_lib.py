@@ -70,7 +70,7 @@ class SynStep(C.Structure):
                 ("x_next", vp), ("x_next_bf16", vp), ("pred_x0", vp),
                 ("ws_h", vp), ("ws_xn", vp), ("ws_q", vp), ("ws_k", vp), ("ws_vt", vp), ("ws_o", vp),
                 ("ws_hid", vp), ("ws_hc", vp), ("ws_sync", vp), ("ws_x0v", vp), ("ws_xch", vp),
-                ("x_fragment_order", i32), ("reserved2", i32)]
+                ("x_fragment_order", i32), ("cfg_w_clip_stride", i32)]
 
 
 SYN_OPT_MAX = 64

@@ -1616,7 +1616,7 @@ __global__ __launch_bounds__(kThreads) void k_stack(const SArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Guidance combine: hc[c][m][:] = sum_v w[c][v] * H[v*Mb + m][:]  -> bf16 (operand of the output GEMM)
-__global__ void k_combine(const float* __restrict__ H, const float* __restrict__ w, int V, int Mb,
+__global__ void k_combine(const float* __restrict__ H, const float* __restrict__ w, int w_stride, int V, int Mb,
                           __bf16* __restrict__ hc) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 each
     const size_t per = (size_t)Mb * kNT / 4;
@@ -1624,14 +1624,15 @@ __global__ void k_combine(const float* __restrict__ H, const float* __restrict__
     const int c = (int)(i / per);
     const size_t e = (i % per) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int v = 0; v < V; ++v) s = s + *reinterpret_cast<const f32x4*>(H + (size_t)v * Mb * kNT + e) * w[c * V + v];
+    const float* wc = w + (e / ((size_t)SYN_T * kNT)) * w_stride + c * V;                 // (row e / 512 belongs to clip row / 32)
+    for (int v = 0; v < V; ++v) s = s + *reinterpret_cast<const f32x4*>(H + (size_t)v * Mb * kNT + e) * wc[v];
     *reinterpret_cast<bf16x4*>(hc + (size_t)c * Mb * kNT + e) = to_bf16x4(s);
 }
 
 // Guided small batches (k_lat with per-sequence groups): x0 = sum_v w[blk][v] * x0_v, then the same posterior /
 // DDIM update and noise as the fused epilogues.  One float4 per thread.
 struct UArgs {
-    const float* X0v; const float* w; int V, B;
+    const float* X0v; const float* w; int w_stride; int V, B;
     const float* Xt; const float* noise; const unsigned long long* rng; const float* coef; const int* t_coef;
     float* Xn; __bf16* Xnb; float* X0;
 };
@@ -1644,7 +1645,7 @@ __global__ void k_guided_update(const UArgs a) {
     const int blk = (int)((off % SYN_C) / kNT);
     f32x4 x0 = {0.f, 0.f, 0.f, 0.f};
     for (int v = 0; v < a.V; ++v)
-        x0 = x0 + *reinterpret_cast<const f32x4*>(a.X0v + (size_t)v * a.B * SYN_T * SYN_C + off) * a.w[blk * a.V + v];
+        x0 = x0 + *reinterpret_cast<const f32x4*>(a.X0v + (size_t)v * a.B * SYN_T * SYN_C + off) * a.w[(size_t)clip * a.w_stride + blk * a.V + v];
     const int tc = a.t_coef[clip];
     const f32x4 cf = *reinterpret_cast<const f32x4*>(a.coef + (size_t)tc * 4);
     f32x4 xn = x0 * cf[0] + *reinterpret_cast<const f32x4*>(a.Xt + off) * cf[1];
@@ -3021,13 +3022,11 @@ int syn_opt_adam(const syn_opt_list* l, const float* scal4, float beta1, float b
 }
 
 int syn_embedding_wgrad(const int64_t* ids, const float* dy, int32_t ld, int32_t n_pos, int32_t vocab, int32_t dim, float* dw, void* stream) {
-    if (!ids || !dy || !dw || n_pos <= 0 || n_pos > glu::kEmbMaxPos || vocab <= 0 || dim <= 0 || dim > glu::kEmbMaxD || ld < dim)
-        return fail_msg("syn_embedding_wgrad: bad arguments (at most 8192 positions per call, dim <= 512, ld >= dim)");
-    hipError_t e = hipMemsetAsync(dw, 0, (size_t)vocab * dim * sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return fail("syn_embedding_wgrad memset", e);
+    if (!ids || !dy || !dw || n_pos <= 0 || n_pos > glu::kEmbMaxPos || vocab <= 0 || vocab > glu::kEmbMaxV || dim <= 0 || dim > glu::kEmbMaxD || ld < dim)
+        return fail_msg("syn_embedding_wgrad: bad arguments (at most 8192 positions per call, vocab <= 65536, dim <= 512, ld >= dim)");
     hipLaunchKernelGGL(glu::k_embedding_wgrad, dim3((n_pos + glu::kEmbWaves - 1) / glu::kEmbWaves), dim3(glu::kEmbWaves * 64), 0, (hipStream_t)stream,
                        reinterpret_cast<const long*>(ids), dy, ld, n_pos, vocab, dim, dw);
-    e = hipGetLastError();
+    hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_embedding_wgrad launch", e);
 }
 
@@ -3566,6 +3565,7 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     const int B = st->n_clips, V = st->n_variants;
     if (B <= 0 || V <= 0) return fail_msg("syn_denoise_step: n_clips and n_variants must be positive");
     if (V > 1 && (!st->cfg_w || (!st->ws_hc && !st->x_fragment_order))) return fail_msg("syn_denoise_step: n_variants > 1 needs cfg_w and ws_hc");
+    if (st->cfg_w_clip_stride != 0 && st->cfg_w_clip_stride != 3 * V) return fail_msg("syn_denoise_step: cfg_w_clip_stride is 0 (one weight table) or 3 * n_variants (one per clip)");
     if (!st->cond || !st->t_model || !st->x_t || !st->x_t_bf16 || !st->coef || !st->t_coef || !st->x_next ||
         !st->x_next_bf16 || !st->ws_h || !st->ws_xn || !st->ws_q || !st->ws_k || !st->ws_vt || !st->ws_o || !st->ws_hid)
         return fail_msg("syn_denoise_step: null state/workspace pointer");
@@ -3587,7 +3587,7 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
         q.te = md->te; q.rcos = md->rot_cos; q.rsin = md->rot_sin; q.cond = st->cond; q.t_model = st->t_model;
         q.xt = st->x_t; q.xb = (const uint4*)st->x_t_bf16; q.noise = st->noise; q.rng = (const unsigned long long*)st->rng;
         q.coef = st->coef; q.t_coef = st->t_coef; q.xn = st->x_next; q.xnb = (uint4*)st->x_next_bf16; q.x0 = st->pred_x0;
-        q.R = B; q.V = V; q.cfg_w = st->cfg_w; q.dbg = g_dbg_mlp;
+        q.R = B; q.V = V; q.cfg_w = st->cfg_w; q.cfg_stride = st->cfg_w_clip_stride; q.dbg = g_dbg_mlp;
         // The persistent step loop wants all its workgroups resident at once (one per CU).  A larger batch goes out as
         // CU-filling slices, each carried through ALL the steps by its own launch (slices are independent: a sequence never
         // leaves its wave); run as one launch, a round of workgroups would finish all its steps before the next one starts
@@ -3644,7 +3644,7 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
         for (int l = 0; l < SYN_LAYERS; ++l) la.layer[l] = md->layer[l];
         la.w_out = (const uint4*)md->w_out; la.b_out = md->b_out;
         la.B = B; la.V = V;
-        la.cond = st->cond; la.t_model = st->t_model; la.cfg_w = st->cfg_w;
+        la.cond = st->cond; la.t_model = st->t_model; la.cfg_w = st->cfg_w; la.cfg_stride = st->cfg_w_clip_stride;
         la.xb = (const __bf16*)st->x_t_bf16; la.xt = st->x_t; la.noise = st->noise;
         la.rng = (const unsigned long long*)st->rng; la.coef = st->coef; la.t_coef = st->t_coef;
         la.xn = st->x_next; la.xnb = (__bf16*)st->x_next_bf16; la.x0 = st->pred_x0;
@@ -3655,7 +3655,7 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
         mark(ST_FC2);
         if (by_seq) {
             UArgs u;
-            u.X0v = st->ws_x0v; u.w = st->cfg_w; u.V = V; u.B = B; u.Xt = st->x_t; u.noise = st->noise;
+            u.X0v = st->ws_x0v; u.w = st->cfg_w; u.w_stride = st->cfg_w_clip_stride; u.V = V; u.B = B; u.Xt = st->x_t; u.noise = st->noise;
             u.rng = (const unsigned long long*)st->rng; u.coef = st->coef; u.t_coef = st->t_coef;
             u.Xn = st->x_next; u.Xnb = (__bf16*)st->x_next_bf16; u.X0 = st->pred_x0;
             const size_t n4 = (size_t)B * SYN_T * SYN_C / 4;
@@ -3760,7 +3760,7 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     if (!fuse_out) {
         if (V > 1) {
             const size_t n4 = (size_t)3 * Mb * kNT / 4;
-            hipLaunchKernelGGL(k_combine, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, st->ws_h, st->cfg_w, V, Mb,
+            hipLaunchKernelGGL(k_combine, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, st->ws_h, st->cfg_w, st->cfg_w_clip_stride, V, Mb,
                                (__bf16*)st->ws_hc);
             mark(ST_COMBINE);
             aout.X = (const __bf16*)st->ws_hc; aout.x_chunk_stride = (long)Mb * kNT;
