@@ -126,7 +126,7 @@ class StepBuffers:
         self.cond = e(R, D)
         self.t_model = torch.zeros(V * B, dtype=torch.int32, device=device)
         self.t_coef = torch.zeros(B, dtype=torch.int32, device=device)
-        self.cfg_w = e(3, V) if V > 1 else None
+        self.cfg_w = e(B, 3, V) if V > 1 else None      # one weight table per clip (`copy_` broadcasts a (3, V) table over the clips)
         self.h = e(R, D)
         self.xn, self.q, self.k, self.o = e(R, D, dt=bf), e(R, D, dt=bf), e(R, D, dt=bf), e(R, D, dt=bf)
         self.vt, self.hid = e(R * D, dt=bf), e(R, FF, dt=bf)
@@ -152,6 +152,7 @@ class StepBuffers:
         self.xch = e(V * B + 1, 8, 32 * D) if 8 < V * B <= 256 else None      # (129..256 sequences: 64-row tiles split in two, the same bytes per sequence)
         s.ws_xch = _lib.ptr(self.xch)
         s.x_fragment_order = int(self.fragment)
+        s.cfg_w_clip_stride = 3 * V if V > 1 else 0
         self.c = s
 
     # layout ------------------------------------------------------------------------------------

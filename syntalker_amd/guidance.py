@@ -22,15 +22,22 @@ PART_BLOCK = {"upper_mask": 0, "hands_mask": 1, "lower_mask": 2}      # cfg_samp
 
 
 def _scalar(v, what):
+    """A guidance scale as the reference's wrappers take it - `y['scale'].view(-1, 1, 1, 1)`, one value for the batch or one per clip
+    (cfg_sampler.py:28,54,167) - as a python float when it is one value, else as a 1-d fp32 tensor of per-clip scales."""
     if torch.is_tensor(v):
-        if v.numel() != 1 and bool((v != v.flatten()[0]).any()):
-            raise NotImplementedError(f"per-sample {what} is not supported by the fused guidance path")
-        return float(v.flatten()[0])
+        if v.numel() == 1 or not bool((v != v.flatten()[0]).any()):
+            return float(v.flatten()[0])
+        return v.detach().reshape(-1).float()
     return float(v)
 
 
+def _is_zero(w) -> bool:
+    return (not torch.is_tensor(w)) and w == 0.0
+
+
 class _Plan:
-    """variants: list of (uncond, uncond_audio, style_override|None); weights: (3, V) python lists."""
+    """variants: list of (uncond, uncond_audio, style_override|None); weights: (3, V) lists of python floats or, for per-clip guidance scales,
+    1-d tensors of one weight per clip."""
 
     def __init__(self, null_style_on_uncond: bool = True):
         # MDM replaces the style vector by its null row when `uncond` is set (denoiser_h3d.py:116-124), so a
@@ -39,7 +46,7 @@ class _Plan:
         self.merge = null_style_on_uncond
 
     def add(self, uncond, uncond_audio, style, w3):
-        if not any(w3):            # a zero-weight evaluation cannot change the result: skip it
+        if all(_is_zero(w) for w in w3):            # a zero-weight evaluation cannot change the result: skip it
             return
         drop = uncond and self.merge
         key = (bool(uncond), bool(uncond_audio), None if (style is None or drop) else id(style))
@@ -53,7 +60,20 @@ class _Plan:
             self.weights[c][v] += w3[c]
 
     def tensor(self, device):
-        return torch.tensor(self.weights, dtype=torch.float32, device=device)
+        """(3, V) weights, or (B, 3, V) when a scale came per clip."""
+        flat = [w for row in self.weights for w in row]
+        if not any(torch.is_tensor(w) for w in flat):
+            return torch.tensor(self.weights, dtype=torch.float32, device=device)
+        B = max(w.numel() for w in flat if torch.is_tensor(w))
+        cols = []
+        for w in flat:
+            if torch.is_tensor(w):
+                if w.numel() != B:
+                    raise ValueError(f"per-clip guidance scales of different lengths ({w.numel()} and {B})")
+                cols.append(w.to(device=device, dtype=torch.float32))
+            else:
+                cols.append(torch.full((B,), float(w), dtype=torch.float32, device=device))
+        return torch.stack(cols, 1).view(B, 3, len(self.variants))
 
 
 def _run(model, x, timesteps, y, plan: _Plan):
@@ -71,7 +91,8 @@ def _run(model, x, timesteps, y, plan: _Plan):
         if style is not None:
             yy["style_feature"] = style
         o = model(x, timesteps, yy)
-        w = W[:, v].repeat_interleave(o.shape[1] // 3).view(1, -1, 1, 1)
+        w = (W[:, v].repeat_interleave(o.shape[1] // 3).view(1, -1, 1, 1) if W.dim() == 2
+             else W[:, :, v].repeat_interleave(o.shape[1] // 3, dim=1).view(W.shape[0], -1, 1, 1))
         out = o * w if out is None else out + o * w
     return out
 

@@ -55,7 +55,7 @@ class CpuStepBuffers:
         self.cond = torch.zeros(V * B * T, D)
         self.t_model = torch.zeros(V * B, dtype=torch.int32)
         self.t_coef = torch.zeros(B, dtype=torch.int32)
-        self.cfg_w = torch.zeros(3, V) if V > 1 else None
+        self.cfg_w = torch.zeros(B, 3, V) if V > 1 else None
         self.rng = torch.zeros(2, dtype=torch.int64)
 
     def load_x(self, x_bct):
@@ -121,7 +121,7 @@ class CpuStepGraph:
         else:                                               # the guidance combination, one weight row per 512-channel block
             x0 = torch.zeros_like(outs[0])
             for v in range(V):
-                x0 = x0 + outs[v] * sb.cfg_w[:, v].repeat_interleave(CH // 3).view(1, CH, 1, 1)
+                x0 = x0 + outs[v] * sb.cfg_w[:, :, v].repeat_interleave(CH // 3, dim=1).view(-1, CH, 1, 1)
         x0 = x0.reshape(B, CH, T).transpose(1, 2).reshape(B * T, CH)
         c = self.coef[sb.t_coef.long()].repeat_interleave(T, 0)                  # (B*T, 4)
         nxt = c[:, 0:1] * x0 + c[:, 1:2] * sb.x

@@ -343,8 +343,34 @@ def main_surface():
         print(f"{k:36s} {tuple(v.shape)} {float(np.abs(v).mean()):.5f}")
 
 
+def main_per_sample_scales():
+    """Per-sample guidance scales: the reference combines with y['scale'].view(-1, 1, 1, 1) - one scale per clip (diffusion/cfg_sampler.py:28,54) - on
+    the text-prompt denoiser, three clips with three different scales: ClassifierFreeSampleModel, TwoClassifierFreeSampleModel (single evaluations) and a
+    guided DDIM-50 loop -> per_sample_scales_outputs.npz."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    _, RefMDMH3D, make_diff, cfgmod, data_path = import_reference()
+    mh = synth.synth_fill_(RefMDMH3D(synth.default_args(data_path=data_path)).eval(), seed=0)
+    yh, xh, th = synth.synth_clip_inputs(3, seed=51, style_dim=256, style_zero=False), synth.synth_latent(3, seed=51), torch.tensor([10, 700, 333])
+    out = {}
+    with torch.no_grad():
+        out["cfg"] = f32(cfgmod.ClassifierFreeSampleModel(mh)(xh, th, dict(yh, scale=torch.tensor([1.5, 2.5, 0.0]))))
+        out["twocfg"] = f32(cfgmod.TwoClassifierFreeSampleModel(mh)(xh, th, dict(yh, scale_audio=torch.tensor([0.5, 1.0, 1.0]),
+                                                                              scale_prompt=torch.tensor([4.0, 2.0, 0.0]))))
+        sn = synth.synth_step_noise(50, 3, seed=52)
+        with InjectNoise(list(sn)):
+            out["cfg.ddim50.sample"] = f32(make_diff(use_ddim=True).ddim_sample_loop(
+                cfgmod.ClassifierFreeSampleModel(mh), (3, 1536, 1, 32), noise=xh.clone(), clip_denoised=False,
+                model_kwargs={"y": dict(yh, scale=torch.tensor([1.5, 2.5, 4.0]))}))
+    np.savez_compressed(os.path.join(HERE, "per_sample_scales_outputs.npz"), **out)
+    for k, v in out.items():
+        print(f"{k:36s} {tuple(v.shape)} {float(np.abs(v).mean()):.5f}")
+
+
 if __name__ == "__main__":
-    if "loop_kwargs" in sys.argv[1:]:
+    if "per_sample_scales" in sys.argv[1:]:
+        main_per_sample_scales()
+    elif "loop_kwargs" in sys.argv[1:]:
         main_loop_kwargs()
     elif "surface" in sys.argv[1:]:
         main_surface()

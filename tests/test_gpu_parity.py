@@ -213,6 +213,32 @@ def test_h3d_guidance_vs_golden(h3d, golden, kernel):
         assert e < FWD_TOL * 4, e
 
 
+def test_per_clip_guidance_scales_vs_reference(h3d, kernel):
+    """One guidance scale per clip (the reference's y['scale'].view(-1, 1, 1, 1), diffusion/cfg_sampler.py:28,54): three clips, three scales, on each of
+    the step kernels - a per-clip weight table [B][3][V] in the output stage's combination - against the reference's own wrappers
+    (tests/golden/per_sample_scales_outputs.npz), single evaluations and a guided DDIM-50 loop with injected noise."""
+    import os
+    from syntalker_amd import guidance as G
+    from syntalker_amd.process import create_gaussian_diffusion
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "per_sample_scales_outputs.npz"))
+    y = synth.to_device(synth.synth_clip_inputs(3, seed=51, style_dim=256, style_zero=False), DEV)
+    x, t = synth.synth_latent(3, seed=51).to(DEV), torch.tensor([10, 700, 333], device=DEV)
+    with torch.no_grad():
+        yc = dict(y, scale=torch.tensor([1.5, 2.5, 0.0], device=DEV))
+        e = rel_l2(G.ClassifierFreeSampleModel(h3d)(x, t, yc).cpu(), fx["cfg"])
+        assert e < FWD_TOL * 2, e
+        yc = dict(y, scale_audio=torch.tensor([0.5, 1.0, 1.0], device=DEV), scale_prompt=torch.tensor([4.0, 2.0, 0.0], device=DEV))
+        e = rel_l2(G.TwoClassifierFreeSampleModel(h3d)(x, t, yc).cpu(), fx["twocfg"])
+        assert e < FWD_TOL * 4, e
+        sn = synth.synth_step_noise(50, 3, seed=52).to(DEV)
+        s = create_gaussian_diffusion(use_ddim=True).ddim_sample_loop(
+            G.ClassifierFreeSampleModel(h3d), (3, 1536, 1, 32), noise=x.clone(), clip_denoised=False,
+            model_kwargs={"y": dict(y, scale=torch.tensor([1.5, 2.5, 4.0], device=DEV))}, step_noise=sn)
+        e = rel_l2(s.cpu(), fx["cfg.ddim50.sample"])
+        print(f"guided DDIM-50 with per-clip scales (kernel {kernel}): rel-L2 {e:.3e}")
+        assert e < LOOP_TOL, e
+
+
 def test_h3d_guidance_vs_golden_in_a_split_tile_batch(h3d, golden):
     """The guided golden case (2 clips) tiled 6 times: 12 clips x 2 / 3 variants = 24 / 36 sequences, the range in which the
     whole-step kernel splits every tile over 4 workgroups; every copy must reproduce the reference's guided outputs."""

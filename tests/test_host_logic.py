@@ -122,9 +122,29 @@ def test_guidance_plans_and_generic_path_equal_oracle():
     yb = dict(y, style_feature=parts, scale=torch.ones(1) * 2.5)
     assert rel_l2(w2(x, t, dict(yb)), gr.cfg_bodypart(fn, x, t, dict(yb))) < 1e-6
     assert np.allclose(np.array(w2.plan(yb).weights).sum(1), 1.0)
-    with pytest.raises(NotImplementedError):                      # per-sample scales are not fused
-        guidance.ClassifierFreeSampleModel(toy).plan(dict(y, scale=torch.tensor([1.0, 2.0])))
     assert guidance.resolve(toy) == (None, None)
+
+
+def test_per_clip_guidance_scales_plan_and_generic_path_equal_oracle():
+    """The reference combines with y['scale'].view(-1, 1, 1, 1): one scale per clip (cfg_sampler.py:28,54).  The planner carries such scales as
+    per-clip weight tables (B, 3, V); the generic path (any wrapped module) applies them per clip; both equal the oracle's restatement."""
+    toy = ToyModel()
+    fn = lambda a, b, c: toy(a, b, c)
+    x, t = torch.randn(3, 1536, 1, 4), torch.tensor([17, 400, 3])
+    y = {"style_feature": torch.randn(3, 256), "seed": torch.zeros(3, 4, 1536)}
+    sc = torch.tensor([1.5, 2.5, 0.0])
+    w = guidance.ClassifierFreeSampleModel(toy)
+    assert rel_l2(w(x, t, dict(y, scale=sc)), gr.cfg(fn, x, t, dict(y, scale=sc))) < 1e-6
+    W = w.plan(dict(y, scale=sc)).tensor("cpu")
+    assert W.shape == (3, 3, 2) and torch.allclose(W.sum(2), torch.ones(3, 3)) and torch.allclose(W[:, 0, 0], sc)
+    assert w.plan(dict(y, scale=torch.ones(3) * 2.5)).tensor("cpu").shape == (3, 2)          # equal per-clip scales stay one table
+    yy = dict(y, scale_audio=torch.tensor([0.5, 1.0, 1.0]), scale_prompt=torch.tensor([4.0, 2.0, 0.0]))
+    w2 = guidance.TwoClassifierFreeSampleModel(toy)
+    assert rel_l2(w2(x, t, dict(yy)), gr.two_cfg(fn, x, t, dict(yy))) < 1e-6
+    W2 = w2.plan(dict(yy)).tensor("cpu")
+    assert W2.shape == (3, 3, 3) and torch.allclose(W2.sum(2), torch.ones(3, 3))
+    with pytest.raises((ValueError, RuntimeError)):                  # scales of different lengths
+        w2.plan(dict(y, scale_audio=torch.tensor([0.5, 1.0, 1.0]), scale_prompt=torch.tensor([4.0, 2.0]))).tensor("cpu")
 
 
 @pytest.mark.parametrize("variant", ["beatx", "h3d"])

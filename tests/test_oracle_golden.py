@@ -125,6 +125,28 @@ def test_h3d_flags_and_guidance(golden):
         assert rel_l2(o, golden["h3d.twocfg"]) < 5e-6
 
 
+def test_per_clip_guidance_scales_vs_reference():
+    """tests/golden/per_sample_scales_outputs.npz (make_golden.py per_sample_scales: the reference's wrappers with one scale per clip): the oracle's
+    restatement, and the product's wrappers on their generic path around the oracle's model function."""
+    from syntalker_amd import guidance as G
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "per_sample_scales_outputs.npz"))
+    sd = synth_state_dict("h3d")
+    fn = _model_fn(sd, "h3d")
+    y = synth.synth_clip_inputs(3, seed=51, style_dim=256, style_zero=False)
+    x, t = synth.synth_latent(3, seed=51), torch.tensor([10, 700, 333])
+
+    class Wrapped(torch.nn.Module):
+        def forward(self, a, b, c):
+            return fn(a, b, c)
+    with torch.no_grad():
+        yc = dict(y, scale=torch.tensor([1.5, 2.5, 0.0]))
+        assert rel_l2(gr.cfg(fn, x, t, dict(yc)), fx["cfg"]) < 5e-6
+        assert rel_l2(G.ClassifierFreeSampleModel(Wrapped())(x, t, dict(yc)), fx["cfg"]) < 5e-6
+        yc = dict(y, scale_audio=torch.tensor([0.5, 1.0, 1.0]), scale_prompt=torch.tensor([4.0, 2.0, 0.0]))
+        assert rel_l2(gr.two_cfg(fn, x, t, dict(yc)), fx["twocfg"]) < 5e-6
+        assert rel_l2(G.TwoClassifierFreeSampleModel(Wrapped())(x, t, dict(yc)), fx["twocfg"]) < 5e-6
+
+
 def _bodypart_case():
     y = synth.synth_clip_inputs(1, seed=8, style_dim=256, style_zero=False)
     g = synth._gen("part_prompts", 8)
