@@ -96,6 +96,92 @@ def test_native_host_calls_the_c_abi_without_python(tmp_path):
     assert abs(vals["randn_sq"] / 4096 - 1.0) < 0.1                                    # a standard normal sample
 
 
+def test_native_host_runs_the_denoising_hot_path_through_the_c_abi(tmp_path):
+    """tests/native/denoise_host.cpp - C++, no Python or torch in its process - packs the synthetic model's fp32 weights itself (`syn_pack_weight`), fills
+    `syn_model` / `syn_step`, and runs (1) one model evaluation through `syn_denoise_step` on token-major latents and (2) ten DDPM steps as one persistent
+    `syn_denoise_steps` launch on fragment-order latents with the noise drawn in the kernel's epilogue - the functions INTEGRATION.md 3 documents for a
+    non-Python host.  Both results equal the same calls made from this process through ctypes BIT FOR BIT, and the CPU oracle (the second one fed the
+    regenerated noise) within the bf16 tolerance."""
+    import shutil
+    import numpy as np
+    import torch
+    from oracle import denoiser_ref as dr
+    from oracle.process_ref import RefProcess
+    from syntalker_amd import _lib, conditioning, engine, synth
+    from syntalker_amd import tape as _tape
+    from syntalker_amd.denoiser import MDM
+    from syntalker_amd.process import create_gaussian_diffusion
+    from tests.conftest import rel_l2
+    from tests.refmodel import synth_state_dict
+    from tests.test_gpu_parity import _regenerated_step_noise
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    DEV = "cuda"
+    B, K, seed, t_eval = 2, 10, 4242, 500
+    m = MDM(synth.default_args()).eval()
+    m.load_state_dict(synth_state_dict("beatx"), strict=False)
+    m = m.to(DEV)
+    y, xT = synth.synth_clip_inputs(B, seed=81), synth.synth_latent(B, seed=81)
+    d = create_gaussian_diffusion()
+    pm = m.packed()
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        cond = m.variant_conds(synth.to_device(y, DEV), [(False, False, None)])[0].contiguous()          # (B, 32, 512)
+    coef = engine.posterior_coefs(d.tables(), DEV)
+    x_in = (torch.tensor(float(np.float32(d.tables()["sqrt_one_minus_alphas_cumprod"][K - 1])), dtype=torch.float32) * xT).contiguous()   # q_sample(0, K - 1, x_T)
+    rc, rs = conditioning.rotary_tables(sd["rel_pos.inv_freq"].float(), 32)
+    tp, tb = _tape.build_tape(sd, pm.folded["A"])
+    f32 = lambda t: t.detach().float().contiguous().cpu().numpy().tobytes()
+    secs = [np.array([B, K, seed, pm.te.shape[0], coef.shape[0], _tape.TAPE_FRAGS // _tape.CHUNK_FRAGS, t_eval, 0], dtype=np.int64).tobytes(),
+            f32(pm.folded["A"]), f32(pm.te), f32(rc), f32(rs)]
+    for i in range(8):
+        p = f"mytimmblocks.{i}."
+        secs += [f32(sd[p + k]) for k in ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias",
+                                          "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")]
+    secs += [f32(sd["output_process.poseFinal.weight"]), f32(sd["output_process.poseFinal.bias"]),
+             tp.contiguous().view(torch.uint8).cpu().numpy().tobytes(), f32(tb), f32(cond), f32(x_in), f32(coef)]
+    blob, outp = tmp_path / "in.blob", tmp_path / "out.bin"
+    with open(blob, "wb") as f:
+        for sec in secs:
+            f.write(np.int64(len(sec)).tobytes()); f.write(sec)
+    exe = str(tmp_path / "denoise_host")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    b = subprocess.run([hipcc, "--offload-arch=gfx950", "-w", "-I", os.path.join(REPO, "include"), os.path.join(REPO, "tests", "native", "denoise_host.cpp"),
+                        "-L", libdir, "-lsyn_hip", f"-Wl,-rpath,{libdir}", "-o", exe], capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-3000:]
+    r = subprocess.run([exe, str(blob), str(outp)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "n_clips" in r.stdout.splitlines()[1]                    # the error path: status + text
+    got = torch.from_numpy(np.fromfile(outp, dtype=np.float32).copy()).view(2, B, 1536, 1, 32)
+    # the same calls through ctypes
+    with torch.no_grad():
+        sb = engine.StepBuffers(B, 1, DEV)
+        assert not sb.fragment
+        sb.cond.copy_(cond.reshape(-1, 512)); sb.load_x(x_in.to(DEV)); sb.t_model.fill_(t_eval); sb.t_coef.zero_()
+        engine.run_step(pm, sb, engine.identity_coefs(DEV), use_noise=False)
+        mine_eval = sb.read(sb.x).cpu()
+        sq = engine.StepBuffers(B, 1, DEV, layer_mode=5)
+        assert sq.fragment
+        sq.cond.copy_(cond.reshape(-1, 512)); sq.load_x(x_in.to(DEV)); sq.set_rng(seed, 0)
+        rows = torch.arange(K - 1, -1, -1, dtype=torch.int32, device=DEV).view(K, 1).repeat(1, B).contiguous()
+        sq.c.t_model, sq.c.t_coef = rows.data_ptr(), rows.data_ptr()
+        engine.run_step(pm, sq, coef, use_noise=True, fused_rng=True, steps=K)
+        mine_loop = sq.read(sq.x).cpu()
+    assert torch.equal(got[0], mine_eval) and torch.equal(got[1], mine_loop)
+    # the oracle
+    fw = dr.fold_weights(sd_cpu := synth_state_dict("beatx"))
+    with torch.no_grad():
+        oc, te = dr.clip_conditioning(sd_cpu, y, fw), dr.time_table(sd_cpu, fw)
+        want_eval = dr.mdm_forward_folded(sd_cpu, fw, oc, te, x_in, torch.full((B,), t_eval))
+        model_fn = lambda a, b_, c: dr.mdm_forward_folded(sd_cpu, fw, oc, te, a, b_)
+        want_loop = RefProcess(False).p_sample_loop(model_fn, (B, 1536, 1, 32), y, noise=xT.clone(),
+                                                    step_noise=_regenerated_step_noise(B, range(K - 1, -1, -1), seed), skip_timesteps=1000 - K)
+    e1, e2 = rel_l2(got[0], want_eval), rel_l2(got[1], want_loop)
+    print(f"native host: one evaluation rel-L2 {e1:.3e}, {K} DDPM steps on the wave-per-sequence kernel {e2:.3e} vs the oracle; {r.stdout.splitlines()[0]}")
+    assert e1 < 2e-2 and e2 < 2e-2
+
+
 def test_two_data_parallel_ranks_on_one_gpu_equal_the_full_batch():
     """scripts/check_ddp_two_ranks_one_gpu.py: two processes on this box's one GPU over gloo - SyncBatchNorm statistics reduced over the ranks,
     DDP-averaged gradients of two 4-clip half-batches - against the 8-clip batch in one process, every parameter gradient.  (SURVEY 8e on
