@@ -23,12 +23,17 @@ buffers = ("running_mean", "running_var", "num_batches_tracked", ".pe", "inv_fre
 sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(buffers)) for k, v in synth_state_dict("beatx").items()}
 RefProcess(False).training_losses(lambda a, b, c: dr.mdm_forward(sd, a, b, c, train_bn=True), x0, t4, y, eps)["loss"].mean().backward()
 print("SYN_CONV_TERMS =", training.CONV_TERMS)
-worst = 0.0
+worst, rows = 0.0, []
 for n, p in m.named_parameters():
     if p.grad is None or sd[n].grad is None or float(sd[n].grad.norm()) < 1e-5:
         continue
     e = rel(p.grad.cpu(), sd[n].grad)
     worst = max(worst, e)
+    rows.append((n, e))
     if n.startswith("WavEncoder") and n.endswith("weight") and "bn" not in n and "downsample.1" not in n:
         print(f"  {n:48s} {e:.3e}")
+rows.sort(key=lambda v: -v[1])
+print("ten largest over ALL parameter tensors:")
+for n, e in rows[:10]:
+    print(f"  {n:48s} {e:.3e}")
 print(f"worst over all tensors: {worst:.3e}")

@@ -13,7 +13,8 @@ with 100 + k in front of the schedule sampler's draw, and `th.randn_like(x_start
 replaced by a seeded draw the tests regenerate.  Stored: OUTPUTS only - the K losses, the sampled timesteps, the total gradient norm
 `clip_grad_norm_` returned at every step, and for a few named parameters the norm of (parameter after K steps - initial) and that
 difference's first 4096 elements.
-    python tests/golden/make_train_golden.py
+    python tests/golden/make_train_golden.py            (5 steps -> train_trajectory.npz)
+    python tests/golden/make_train_golden.py 50         (50 steps -> train_trajectory_k50.npz: does the arithmetic drift? VERDICT r5 item 3)
 """
 import os
 import sys
@@ -30,17 +31,17 @@ from make_golden import InjectNoise, import_reference  # noqa: E402  (also puts 
 from make_longform_golden import lift_methods  # noqa: E402
 from syntalker_amd import synth  # noqa: E402
 
-K_STEPS, BATCH = 5, 4
+K_STEPS, BATCH = (int(sys.argv[1]) if __name__ == "__main__" and len(sys.argv) > 1 else 5), 4
 WATCH = ["mytimmblocks.0.attn.qkv.weight", "mytimmblocks.7.mlp.fc2.weight", "mytimmblocks.3.norm1.weight", "input_process2.weight",
          "output_process.poseFinal.bias", "embed_timestep.time_embed.0.weight", "WavEncoder.feat_extractor.0.conv2.weight",
          "WavEncoder.feat_extractor.0.bn1.weight", "WavEncoder.feat_extractor.5.conv1.weight", "text_encoder_body.weight"]
 
 
-def trajectory_inputs():
+def trajectory_inputs(steps=None):
     """The data batch and the per-step noise, from seeds alone (the tests regenerate them)."""
     y = synth.synth_clip_inputs(BATCH, seed=41)
     x0 = synth.synth_latent(BATCH, seed=41, name="x0")                          # (B, 1536, 1, 32)
-    eps = [synth.synth_latent(BATCH, seed=60 + k, name="eps") for k in range(K_STEPS)]
+    eps = [synth.synth_latent(BATCH, seed=60 + k, name="eps") for k in range(K_STEPS if steps is None else steps)]
     return y, x0, eps
 
 
@@ -101,8 +102,12 @@ def main():
     for n in ("WavEncoder.feat_extractor.0.bn1.running_mean", "WavEncoder.feat_extractor.5.bn2.running_var", "WavEncoder.feat_extractor.0.bn1.num_batches_tracked"):
         out[f"buffer.{n}"] = sd[n].double().numpy()
     del out["x0_with_seed"]                                                     # (regenerated by the tests: trajectory_inputs + the seed rows)
-    np.savez_compressed(os.path.join(HERE, "train_trajectory.npz"), **out)
-    print("wrote train_trajectory.npz", sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB")
+    for n, v in sd.items():                                                     # every BatchNorm running statistic of the encoder after K steps
+        if "running_" in n:
+            out[f"buffer.{n}"] = v.double().numpy()
+    name = "train_trajectory.npz" if K_STEPS == 5 else f"train_trajectory_k{K_STEPS}.npz"
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name, sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB")
 
 
 if __name__ == "__main__":

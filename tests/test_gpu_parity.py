@@ -832,6 +832,49 @@ def test_five_step_training_trajectory_vs_the_reference_loop():
         assert np.allclose(sd[n].double().cpu().numpy(), g[f"buffer.{n}"], rtol=5e-3, atol=5e-4), n
 
 
+def test_fifty_step_training_trajectory_does_not_drift_from_the_reference_loop():
+    """Fifty updates of the reference's own training loop (`_g_training` + its Adam + clip_grad_norm_(0.99) on one 4-clip batch, fresh timesteps and noise
+    every step: tests/golden/make_train_golden.py 50 -> train_trajectory_k50.npz) against `GraphedTrainStep` + `ClipAdam`.  Every step's loss depends on all
+    the updates before it, so an arithmetic difference that compounded - bf16 GEMM operands, the two-product convolution weight gradients, bf16 attention
+    operands in the block kernels - would show as a loss curve walking away from the reference's.  Asserted: every loss within 2e-2, every clipped gradient
+    norm within 4e-2, the mean loss of the last ten steps within 1 %, and the audio encoder's BatchNorm running statistics after fifty training forwards."""
+    import os
+    from syntalker_amd import training
+    from syntalker_amd.process import create_gaussian_diffusion
+    from tests.test_oracle_golden import trajectory_case
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_trajectory_k50.npz"))
+    K = int(g["steps"])
+    y, x0, eps = trajectory_case(K)
+    m = _model("beatx").train()
+    m.drop_path = 0.0
+    d = create_gaussian_diffusion()
+    opt = training.ClipAdam(m.parameters(), lr=5e-5, betas=(0.5, 0.999), max_norm=0.99)
+    yd = synth.to_device(y, DEV)
+    step = training.GraphedTrainStep(m, d, opt, x0.to(DEV), {"y": yd}, grad_norm=0.99, noise=eps[0].to(DEV))
+    losses, norms = [], []
+    for k in range(K):
+        losses.append(step(x0.to(DEV), torch.from_numpy(g["t"][k]).to(DEV), {"y": yd}, noise=eps[k].to(DEV)))
+        norms.append(opt.last_norm().clone())
+    training.check_stack_sync(DEV)
+    step.close()
+    losses, norms = np.array([float(v) for v in losses]), np.array([float(v) for v in norms])
+    rl, rn = losses / g["loss"], norms / g["grad_norm"]
+    print(f"50-step trajectory: loss ratio min {rl.min():.4f} max {rl.max():.4f}, first five {np.round(rl[:5], 4)}, last five {np.round(rl[-5:], 4)}; "
+          f"gradient-norm ratio min {rn.min():.4f} max {rn.max():.4f}; reference loss {g['loss'][0]:.3f} -> {g['loss'][-1]:.3f}")
+    assert np.allclose(losses, g["loss"], rtol=2e-2), (rl.min(), rl.max())
+    assert np.allclose(norms, g["grad_norm"], rtol=4e-2), (rn.min(), rn.max())
+    assert abs(losses[-10:].mean() / g["loss"][-10:].mean() - 1) < 1e-2
+    sd = m.state_dict()
+    worst = ("", 0.0)
+    for key in g.files:
+        if key.startswith("buffer.") and "running_" in key:
+            # (statistics of activations behind fifty sign-like Adam updates of the layers in front: compared per tensor, not per element)
+            e = rel_l2(torch.from_numpy(sd[key[7:]].double().cpu().numpy()), torch.from_numpy(g[key]))
+            worst = max(worst, (key[7:], e), key=lambda v: v[1])
+            assert e < 2e-2, (key, e)
+    print(f"50-step trajectory: worst BatchNorm running statistic rel-L2 {worst[1]:.2e} ({worst[0]})")
+
+
 def test_captured_train_step_at_the_bench_size_replays_back_to_back(beatx):
     """The whole training step of BASELINE config 3 (32 clips, 68 266 audio samples x 2 channels) captured in one hipGraph and
     replayed 40 times with NOTHING waiting between the replays.  Round 1 had to synchronise after every replay (HSA

@@ -263,7 +263,7 @@ def test_h3d_training_loss_and_gradient_norms_match_reference():
     assert np.allclose(got, fx["h3d.train.gradnorm"], rtol=2e-4), got / fx["h3d.train.gradnorm"]
 
 
-def trajectory_case():
+def trajectory_case(steps=5):
     """Inputs of tests/golden/make_train_golden.py, from seeds alone: one 4-clip batch (the seed rows written into x0 as
     `_g_training` reads them back, diffusion_rvqvae_trainer.py:346-349) and the per-step noise."""
     y = synth.synth_clip_inputs(4, seed=41)
@@ -272,7 +272,7 @@ def trajectory_case():
     lat[:, :4] = y["seed"]
     x0 = lat.permute(0, 2, 1).unsqueeze(2).contiguous()
     y = dict(y, seed=lat[:, :4].clone())
-    eps = [synth.synth_latent(4, seed=60 + k, name="eps") for k in range(5)]
+    eps = [synth.synth_latent(4, seed=60 + k, name="eps") for k in range(steps)]
     return y, x0, eps
 
 
