@@ -310,6 +310,29 @@ def dry_run(args, rank, world, dist):
                  "ms_per_step": round(dt / K * 1e3, 4), "dry_run": True, "mode": args.mode, "clips_per_gpu": B}, **extra) if rank == 0 else None
 
 
+def capture_or_fallback(build, world, dist, sync, dev, force=False):
+    """The capture of a step with RCCL collectives inside has run on hardware with ONE rank only (this pool has no multi-GPU node): if `build()`
+    raises on some rank of a larger job, EVERY rank drops to the eager step (same arithmetic, host-bound) and the line says so (`graph_fallback`)
+    instead of the whole bench aborting; the ranks agree through a MIN all-reduce of their capture status.  With one rank the exception propagates
+    (unless `force`, the test hook).  -> (captured step | None, reason | None)"""
+    g, reason = None, None
+    try:
+        g = build()
+    except Exception as e:                                       # noqa: BLE001 - anything the capture throws is reported, not swallowed
+        if world == 1 and not force:
+            raise
+        reason = f"{type(e).__name__}: {e}"[:300]
+    if world > 1:
+        sync()
+        ok = torch.tensor([0 if reason else 1], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok) == 0:
+            if g is not None:
+                g.close()
+            g, reason = None, reason or "the capture failed on another rank"
+    return g, reason
+
+
 F_TRAIN = 3 * 5.90e9               # algorithmic FLOPs per training sample: fwd + bwd through the as-written model (SURVEY.md 8d)
 
 
@@ -344,25 +367,14 @@ def run_train(args, rank, local, world, dev, dist):
         opt = torch.optim.Adam(net.parameters(), lr=5e-5, betas=(0.5, 0.999), capturable=graph, fused=True)
     else:
         opt = training.ClipAdam(net.parameters(), lr=5e-5, betas=(0.5, 0.999), max_norm=0.99)
-    fallback = None
+    fallback, g = None, None
     if graph:
-        # The capture of a step with RCCL collectives inside has run on hardware with ONE rank only (this pool has no multi-GPU node): if it
-        # raises on some rank of a larger job, every rank drops to the eager step (same arithmetic, host-bound) and the line says so,
-        # instead of the whole bench aborting.
-        try:
-            g = training.GraphedTrainStep(net, diff, opt, x0, {"y": y}, warmup=11 if ddp else 3, stream=side)
-        except Exception as e:                                   # noqa: BLE001 - anything the capture throws is reported, not swallowed
-            if world == 1:
-                raise
-            g, fallback = None, f"{type(e).__name__}: {e}"[:300]
-        if world > 1:
-            torch.cuda.synchronize(dev)
-            ok = torch.tensor([0 if fallback else 1], device=dev, dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok) == 0:
-                if g is not None:
-                    g.close()
-                g, graph, fallback = None, False, fallback or "the capture failed on another rank"
+        def build():
+            if args.inject_capture_failure:
+                raise RuntimeError("injected by --inject-capture-failure")
+            return training.GraphedTrainStep(net, diff, opt, x0, {"y": y}, warmup=11 if ddp else 3, stream=side)
+        g, fallback = capture_or_fallback(build, world, dist, lambda: torch.cuda.synchronize(dev), dev, force=args.inject_capture_failure)
+        graph = g is not None
     if graph:
         last = {}
         def step():
@@ -597,6 +609,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="sample mode: skip the train_step / guided sub-objects (BASELINE configs[2]-[4]) the default 1-GPU line carries")
     ap.add_argument("--torch-adam", action="store_true", help="train mode: torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(fused) instead of training.ClipAdam (A/B)")
+    ap.add_argument("--inject-capture-failure", action="store_true", help="train mode, test hook: the step's hipGraph capture raises, the run falls back to the eager step")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: exercises rank start-up, rendezvous (gloo), the barrier / max-over-ranks timing and the JSON line on CPU")
     ap.add_argument("--layer-mode", type=int, default=0, help="0 library's choice (whole-step kernel at the bench batch), 4 / 3 pin the whole-step / small-batch kernel, "

@@ -41,6 +41,59 @@ def test_bench_starts_its_own_ranks(mode):
             assert all(abs(sum(row) - 1.0) < 1e-6 for row in plan["weights"])          # a guidance formula's weights sum to 1 per block
 
 
+@pytest.mark.parametrize("mode", ["sample", "train", "guided"])
+def test_bench_dry_run_with_eight_ranks(mode):
+    """What the driver launches on an 8-GPU node (`--gpus 8`, one rank per GPU) has never run on hardware: its launch path - eight ranks, rendezvous,
+    barriers, the model and its DDP wrapper in train mode, ONE JSON line from rank 0 - must at least not fail for a trivial reason."""
+    r, lines = _run("--gpus", "8", "--mode", mode)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["gloo_ranks"] == 8 and out["dry_run"] is True and out["mode"] == mode
+    if mode == "train":
+        assert out["graph_replayed"] is True and out["ddp"]["find_unused_parameters"] is False and out["clips_per_gpu"] == 32
+
+
+def test_capture_failure_on_any_rank_sends_every_rank_to_the_eager_step():
+    """bench.capture_or_fallback: a capture that raises on one rank of a multi-rank job (or on none, while another rank's did) leaves EVERY rank
+    without a captured step and with a reason for the JSON line's `graph_fallback`; with one rank the exception propagates."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class Dist:                                             # the MIN all-reduce of a 2-rank job whose other rank reports `other`
+        class ReduceOp:
+            MIN = "min"
+
+        def __init__(self, other):
+            self.other = other
+
+        def all_reduce(self, t, op=None):
+            t.fill_(min(int(t), self.other))
+
+    class Step:
+        closed = False
+
+        def close(self):
+            self.closed = True
+
+    def boom():
+        raise RuntimeError("hipErrorStreamCaptureInvalidated")
+    g, why = bench.capture_or_fallback(boom, 2, Dist(1), lambda: None, "cpu")
+    assert g is None and "hipErrorStreamCaptureInvalidated" in why
+    mine = Step()
+    g, why = bench.capture_or_fallback(lambda: mine, 2, Dist(0), lambda: None, "cpu")            # this rank captured, the other did not
+    assert g is None and mine.closed and "another rank" in why
+    g, why = bench.capture_or_fallback(lambda: mine, 2, Dist(1), lambda: None, "cpu")
+    assert g is mine and why is None
+    with pytest.raises(RuntimeError):
+        bench.capture_or_fallback(boom, 1, None, lambda: None, "cpu")
+    g, why = bench.capture_or_fallback(boom, 1, None, lambda: None, "cpu", force=True)
+    assert g is None and why.startswith("RuntimeError")
+
+
 def test_bench_train_dry_run_with_the_eager_step_wiring():
     """--no-train-graph with several ranks: the eager step, the wrapper searches for unused parameters (nothing frozen)."""
     r, lines = _run("--gpus", "2", "--mode", "train", "--no-train-graph")

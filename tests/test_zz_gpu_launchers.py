@@ -64,6 +64,20 @@ def test_h3d_training_loop_under_the_captured_ddp_step(tmp_path):
     assert rep["frozen"] == ["embed_style.bias", "embed_style.weight", "uncon_audio_embeddings"]
 
 
+def test_bench_train_line_when_the_capture_fails():
+    """`bench.py --mode train --inject-capture-failure`: the hipGraph capture of the step raises; the run drops to the eager step and still prints a valid
+    JSON line that says so (`graph_fallback`, `graph_replayed` false) - what an N-GPU run does if the capture with RCCL collectives inside fails on a rank."""
+    import json
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--mode", "train", "--steps", "3", "--warmup", "1", "--batch", "4", "--inject-capture-failure"],
+                       capture_output=True, text=True, timeout=600, env=e)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(next(l for l in r.stdout.splitlines() if l.startswith("{")))
+    assert out["config"]["graph_replayed"] is False and "injected" in out["config"]["graph_fallback"] and out["value"] > 0 and out["ms_per_step"] > 0
+
+
 def test_native_host_calls_the_c_abi_without_python(tmp_path):
     """tests/native/abi_host.cpp - a C++ program that includes include/syn_hip.h and links libsyn_hip.so, no Python or torch in its process -
     gets the same bits from `syn_randn` and the pose-format kernels as this process does through ctypes, and sees errors as status + text."""
