@@ -71,14 +71,6 @@ _BLOCK = 2 * 32 * 512 * 1536 + _ATT + 2 * 32 * 512 * 512 + 2 * 2 * 32 * 512 * 10
 STAGE_INFO_STACK = {
     "fc2_gemm": ("k_stack<MT>", 2 * 32 * 1536 * 512 + 8 * _BLOCK + 2 * 32 * 512 * 1536),
 }
-# fused layer kernels report under the qkv / fc2 stage slots of syn_denoise_step_profile
-STAGE_INFO_FUSED = {
-    "in_gemm": ("k_gemm<MT,EPI_IN>", 2 * 32 * 1536 * 512),
-    "qkv_gemm": ("k_attn_block<MT>", 2 * 32 * 512 * 1536 + _ATT),
-    "fc2_gemm": ("k_mlp_block<MT>", 2 * 32 * 512 * 512 + 2 * 2 * 32 * 512 * 1024),
-    "out_gemm": ("k_gemm<MT,EPI_OUT>", 2 * 32 * 512 * 1536),
-}
-
 
 def cpu_baseline(budget_s: float):
     """Reference forward as written (no hoisting / folding), fp32, torch CPU, B=1 - SURVEY.md §8d protocol.
@@ -88,8 +80,9 @@ def cpu_baseline(budget_s: float):
     was re-sized four times in front of the sample) also times the runner-up and keeps the better one, and the line says so."""
     from oracle import denoiser_ref as dr
     from syntalker_amd import synth
-    from tests.refmodel import synth_state_dict
-    sd = synth_state_dict("beatx")
+    from syntalker_amd.denoiser import MDM
+    # the oracle runs on the reference's state_dict: the product module carries the same entries, filled by the same name-keyed initialiser
+    sd = {k: v.detach().clone() for k, v in synth.synth_fill_(MDM(synth.default_args()).eval(), 0).state_dict().items()}
     y, x = synth.synth_clip_inputs(1, seed=1), synth.synth_latent(1, seed=1)
     all_cores = torch.get_num_threads()
 
@@ -613,7 +606,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: exercises rank start-up, rendezvous (gloo), the barrier / max-over-ranks timing and the JSON line on CPU")
     ap.add_argument("--layer-mode", type=int, default=0, help="0 library's choice (whole-step kernel at the bench batch), 4 / 3 pin the whole-step / small-batch kernel, "
-                         "2 two kernels/block, 1 five kernels/block (A/B)")
+                         "5 the wave-per-sequence kernel, 1 five kernels per block (the restatement the whole-step kernel is checked against)", choices=[0, 1, 3, 4, 5])
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -754,7 +747,7 @@ def run_sample(args, rank, local, world, dev, dist):
     model = synth.synth_fill_(MDM(synth.default_args()).eval(), seed=0).to(dev)
     model.m_tile = args.m_tile
     model.layer_mode = args.layer_mode
-    STAGE_INFO = {0: STAGE_INFO_STACK, 4: STAGE_INFO_STACK, 3: STAGE_INFO_STACK, 1: STAGE_INFO_LEGACY, 2: STAGE_INFO_FUSED}[args.layer_mode]
+    STAGE_INFO = {0: STAGE_INFO_STACK, 4: STAGE_INFO_STACK, 3: STAGE_INFO_STACK, 5: STAGE_INFO_STACK, 1: STAGE_INFO_LEGACY}[args.layer_mode]
     diff = create_gaussian_diffusion()
     pm = model.packed()
 
@@ -789,7 +782,7 @@ def run_sample(args, rank, local, world, dev, dist):
         ms = (C.c_float * 8)()
         cnt = (C.c_int32 * 8)()
         tot, launches = [0.0] * 8, [0] * 8
-        reps = 5 if args.layer_mode in (1, 2) else 1     # single-kernel steps are timed by the replay brackets; one eager launch
+        reps = 5 if args.layer_mode == 1 else 1     # single-kernel steps are timed by the replay brackets; one eager launch
                                                          # only names the kernel (keeps the rocprofv3 average = the replay average)
         frag = bool(getattr(sb, "fragment", False))   # the step runs on the wave-per-sequence kernel (latent in fragment order):
         if frag:                                      # every k_seq launch of this command is one CH-step replay (no eager launch
@@ -801,8 +794,7 @@ def run_sample(args, rank, local, world, dev, dist):
                        "syn_denoise_step_profile")
             for c in range(8):
                 tot[c] += ms[c]; launches[c] += cnt[c]
-        rename = {0: {"fc2_gemm": "step_kernel"}, 4: {"fc2_gemm": "step_kernel"}, 3: {"fc2_gemm": "step_kernel"}, 1: {},
-                  2: {"qkv_gemm": "attn_block", "fc2_gemm": "mlp_block"}}[args.layer_mode]
+        rename = {} if args.layer_mode == 1 else {"fc2_gemm": "step_kernel"}
         stage_ms = {STAGES[c]: tot[c] / max(reps, 1) for c in range(8) if launches[c]}
         # group by kernel symbol (proj and fc2 share one)
         by_kernel = {}
@@ -828,7 +820,7 @@ def run_sample(args, rank, local, world, dev, dist):
             dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
             d = by_kernel[dom]
             avg_s = d["ms"] * 1e-3 / d["launches"]
-            if args.layer_mode in (0, 3, 4):       # the step IS one kernel: use the hipEvent brackets of the K timed replays
+            if args.layer_mode in (0, 3, 4, 5):      # the step IS one kernel: use the hipEvent brackets of the K timed replays
                 avg_s = replay_ms * 1e-3
         achieved = d["flops"] / d["launches"] / avg_s
         # HBM/fabric bytes per launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this

@@ -87,7 +87,7 @@ typedef struct syn_step {
     int32_t m_tile;         /* rows per workgroup: 0 = auto, else 32 / 64 / 128                  */
     int32_t reserved;       /* kernel selection: 0 = auto (small-batch kernel up to 8 sequences when ws_sync != NULL, the whole-step
                                kernel with split tiles at 9..128 sequences when ws_xch != NULL, else the whole-step kernel); 4 = whole-step kernel always;
-                               3 = small-batch kernel always; 1 / 2 = five / two kernels per block (A/B);
+                               3 = small-batch kernel always; 1 = five kernels per block (the plain restatement the whole-step kernel is checked against bit for bit);
                                5 = wave-per-sequence kernel always (needs x_fragment_order = 1);
                                +8 = never split a tile over several workgroups (see ws_xch)               */
     /* conditioning, row (v*B + b)*32 + frame */
@@ -215,7 +215,7 @@ int syn_conv1d_first_fwd_stats(const float* x, int32_t n_clips, int32_t l_in, in
 
 /* The two fragment sets syn_conv1d_train_fwd takes, from the module's weight w [cout][cin][15] (fp32) in one launch; each
  * output holds syn_conv1d_pack_bytes(...) bytes.  transposed = 1: the matrix of the DATA GRADIENT (stride 1; for a strided
- * convolution the form syn_conv1d_train_dgrad_strided takes)
+ * convolution the form syn_conv1d_train_dgrad_sum takes: a stride-1 convolution over dy whose output rows are `stride` consecutive positions x cin channels)
  * of that convolution (taps reversed, channel roles swapped: N = cin, C = cout) - the gradient then is
  * syn_conv1d_train_fwd(dy, ..., cin = cout, stride 1, pad 7, ..., cout = cin). */
 int syn_conv1d_pack_split(const float* w, int32_t cout, int32_t cin, int32_t stride, int32_t transposed, void* out_hi, void* out_lo,
@@ -227,11 +227,6 @@ typedef struct syn_conv_pack_req { const float* w; void* out_hi; void* out_lo; i
 int syn_conv1d_pack_split_many(const syn_conv_pack_req* reqs, int32_t n_reqs, void* stream);
 /* Bytes of each of syn_conv1d_pack_split's two outputs. */
 int64_t syn_conv1d_pack_bytes(int32_t cout, int32_t cin, int32_t stride, int32_t transposed);
-/* Data gradient of a STRIDED, unpadded Conv1d(k = 15) of the encoder ((cout, stride) = (64, 6), (128, 6), (256, 3)): dx fp32
- * channels-last [n_clips][l_in][cin] from dy [n_clips][l_out][cout]; w_hi / w_lo = syn_conv1d_pack_split(w, ..., stride,
- * transposed = 1).  A stride-1 convolution over dy whose output rows are `stride` consecutive positions x cin channels. */
-int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t cout,
-                                   const void* w_hi, const void* w_lo, float* dx, void* stream);
 /* (ABI 7) The data gradient that reaches a BasicBlock's input, written once: dx [n_clips][l_in][cin] = conv^T dy [+ conv2^T dy2] [+ residual].
  * Strided, unpadded layers (a down-sampling block: conv1 and the shortcut convolution share input and geometry): dy / dy2 [n_clips][l_out][cout] with their
  * transposed fragment sets, both accumulated in one launch instead of two tensors and an add; residual must be NULL.  Stride 1, padding 7 (a block with an

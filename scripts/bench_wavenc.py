@@ -3,6 +3,7 @@ Usage: python scripts/bench_wavenc.py [B=64]"""
 import sys, torch
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from syntalker_amd import conditioning, synth
+from tests import refmodel
 from syntalker_amd.denoiser import MDM
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 m = synth.synth_fill_(MDM(synth.default_args()).eval(), 0)
@@ -19,7 +20,7 @@ def timed(fn, n):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 t_hip = timed(lambda: enc(wav), 10)
-t_ref = timed(lambda: conditioning.wav_features(cu, wav), 3)
+t_ref = timed(lambda: refmodel.wav_features(cu, wav), 3)
 gf = 2 * 2.31e9 * B
 print(f"B={B}: HIP {t_hip:.3f} ms ({t_hip / B * 1e3:.1f} us/clip, {gf / t_hip / 1e9:.0f} TFLOP/s)   "
       f"PyTorch-ROCm/MIOpen {t_ref:.3f} ms ({t_ref / B * 1e3:.1f} us/clip)   speed-up {t_ref / t_hip:.1f}x")

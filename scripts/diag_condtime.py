@@ -1,6 +1,7 @@
 import sys, time, torch, torch.nn.functional as F
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from syntalker_amd import synth, conditioning
+from tests import refmodel
 from tests.refmodel import synth_state_dict
 sd = {k: v.cuda() for k, v in synth_state_dict('beatx').items()}
 blocks = conditioning.fold_wav_encoder(sd)
@@ -10,9 +11,9 @@ def timeit(fn, n=3):
     fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-print("baseline fp32 conv1d:        %.2f ms per %d clips" % (timeit(lambda: conditioning.wav_features(blocks, wav)), B))
+print("baseline fp32 conv1d:        %.2f ms per %d clips" % (timeit(lambda: refmodel.wav_features(blocks, wav)), B))
 torch.backends.cudnn.benchmark = True
-print("cudnn.benchmark=True:        %.2f ms" % timeit(lambda: conditioning.wav_features(blocks, wav)))
+print("cudnn.benchmark=True:        %.2f ms" % timeit(lambda: refmodel.wav_features(blocks, wav)))
 torch.backends.cudnn.benchmark = False
 # per-layer timing
 x = wav.transpose(1, 2)

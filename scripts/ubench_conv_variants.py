@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Device time of the training-mode WavEncoder convolutions (forward with BatchNorm partial sums, data gradient) at the bench
 shapes, per layer class, with a check against torch's fp32 convolution.  GPU box: python scripts/ubench_train_conv.py [clips]
-(SYN_CV selects the kernels' decomposition per layer class - see conv_variant in csrc/syn_kernels.hip)."""
+"""
 import os
 import sys
 
@@ -38,7 +38,7 @@ def rel(a, b):
     return float((a.float() - b.float()).norm() / b.float().norm())
 
 
-print(f"SYN_CV={os.environ.get('SYN_CV', '')} clips={N}")
+print(f"clips={N}")
 tot = 0.0
 for name, cin, cout, stride, pad, l_in in LAYERS:
     x = torch.randn(N, cin, 1, l_in, device=dev).contiguous(memory_format=torch.channels_last)
@@ -63,8 +63,8 @@ for name, cin, cout, stride, pad, l_in in LAYERS:
         gx = torch.empty(N, cin, 1, l_in, device=dev, dtype=torch.float32).contiguous(memory_format=torch.channels_last)
 
         def run_d():
-            _lib.check(lib.syn_conv1d_train_dgrad_strided(gy.data_ptr(), N, l_in, cin, stride, cout, whi.data_ptr(), wlo.data_ptr(), gx.data_ptr(),
-                                                          _lib.current_stream(dev)), "dgrad")
+            _lib.check(lib.syn_conv1d_train_dgrad_sum(gy.data_ptr(), whi.data_ptr(), wlo.data_ptr(), None, None, None, None, N, l_in, cin, stride, 0, cout, gx.data_ptr(),
+                                                      _lib.current_stream(dev)), "dgrad")
             return gx
     e_d = rel(run_d(), gref)
     t_d = timed(run_d)

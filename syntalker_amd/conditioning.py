@@ -49,18 +49,6 @@ def fold_wav_encoder(sd, prefix="WavEncoder.feat_extractor."):
     return blocks
 
 
-def wav_features(blocks, wav):
-    """wav (B, L, 2) or (B, L) -> (B, 128, 256)."""
-    x = wav.unsqueeze(1) if wav.dim() == 2 else wav.transpose(1, 2)
-    for blk in blocks:
-        z = F.leaky_relu(F.conv1d(x, *blk["c1"], stride=blk["stride"], padding=blk["pad"]), 0.01)
-        z = F.conv1d(z, *blk["c2"], padding=7)
-        if blk["sc"] is not None:
-            x = F.conv1d(x, *blk["sc"], stride=blk["stride"], padding=blk["pad"])
-        x = F.leaky_relu(z + x, 0.01)
-    return x.transpose(1, 2)
-
-
 def wav_gemm_weight(w, stride: int):
     """BN-folded Conv1d weight (cout, cin, 15) -> the GEMM matrix W'[cout][tap][cin'] of the HIP encoder
     (syn_wavenc.inc): K index = tap*cin + ci; a stride-s conv is a stride-1 conv over s-row groups, i.e. the same

@@ -772,288 +772,8 @@ __global__ __launch_bounds__(256) void k_attn(const __bf16* __restrict__ Q, cons
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Fused attention half of a block:  O = softmax(q k^T / sqrt(128)) v,  [q|k|v] = xn . Wqkv^T.
-// One workgroup owns MT rows (MT/32 whole sequences) and walks the 4 heads; q, k, v of one head live
-// only in LDS (bf16) and the attention itself only in registers, so nothing but xn (read) and O
-// (write) touches HBM.  Per head every wave computes one 16-column fragment of q, one of k and one of
-// v for all MT rows (so the three accumulator slots have compile-time roles); v uses the swapped MFMA
-// orientation so it lands transposed ([d][token]) as the PV product wants it.
-//   LDS: [0, 2*MT*128)  activation K-tiles (double buffer)
-//        Qs  MT x 256 B   row = token, 16-B slots XOR-swizzled by (row & 15)
-//        Ks  MT x 256 B   same
-//        Vts MT/32 x 128 x 72 B   [sequence][d][token], rows padded 64 -> 72 B
-struct AArgs {
-    long long* dbg;       // diagnostics: per-workgroup phase timestamps (null in production)
-    const __bf16* X;      // [M][512] LN1 output
-    const uint4* W;       // packed qkv weight (1536 x 512)
-    __bf16* O;            // [M][512]
-    int M;
-};
-
 __device__ __forceinline__ void stamp(long long* dbg, int slot) {
     if (dbg != nullptr && threadIdx.x == 0) dbg[(size_t)blockIdx.x * 32 + slot] = (long long)__builtin_readcyclecounter();
-}
-
-template <int MT>
-__global__ __launch_bounds__(kThreads) void k_attn_block(const AArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MF = MT / 16;
-    constexpr int BUF = MT * 128;
-    constexpr int KS = SYN_D / 32;
-    char* const Qs = smem + 2 * BUF;
-    char* const Ks = Qs + MT * 256;
-    char* const Vts = Ks + MT * 256;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lr = lane & 15;
-    const int m0 = blockIdx.x * MT;
-
-    stamp(a.dbg, 0);
-    for (int head = 0; head < SYN_HEADS; ++head) {
-        // ---- qkv GEMM for this head: 3 fragments per wave (q, k, v), K = 512 -------------------------
-        f32x4 acc[3][MF];
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl)
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf) acc[sl][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // fragment of slot sl: n-frag sl*32 + head*8 + wave; slot 2 (v) uses the swapped orientation
-        gemm_mainloop<MT, 3, 32, 0x4>(acc, a.X, SYN_D, a.M, m0, a.M, SYN_D,
-                                      a.W + ((size_t)(head * 8 + wave) * KS) * 64 + lane, smem);
-        stamp(a.dbg, 1 + head * 3);
-        // ---- q, k -> LDS row-major (swizzled); v -> LDS transposed -----------------------------------
-        // q/k: acc[sl][mf][r] = [token 16mf + lr][d = 16*wave + 4g + r]
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-            const int row = mf * 16 + lr;
-            const int off = row * 256 + ((((2 * wave) + (g >> 1)) ^ lr) << 4) + (g & 1) * 8;
-            *reinterpret_cast<bf16x4*>(Qs + off) = to_bf16x4(acc[0][mf]);
-            *reinterpret_cast<bf16x4*>(Ks + off) = to_bf16x4(acc[1][mf]);
-            // v: acc[2][mf][r] = [token 16mf + 4g + r][d = 16*wave + lr]
-            *reinterpret_cast<bf16x4*>(Vts + (mf >> 1) * (128 * 72) + (wave * 16 + lr) * 72 + ((mf & 1) * 16 + g * 4) * 2) =
-                to_bf16x4(acc[2][mf]);
-        }
-        __syncthreads();
-        stamp(a.dbg, 2 + head * 3);
-        // ---- attention: wave -> (sequence c, 16-query half qh) -----------------------------------------
-        if (wave < MT / 16) {
-            const int c = wave >> 1, qh = wave & 1;
-            const int qrow = c * 32 + qh * 16 + lr;
-            f32x4 sc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int so = (((4 * ks) + g) ^ lr) << 4;
-                const bf16x8 qf = *reinterpret_cast<const bf16x8*>(Qs + qrow * 256 + so);
-#pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (c * 32 + f * 16 + lr) * 256 + so);
-                    sc[f] = MFMA16(kf, qf, sc[f]);
-                }
-            }
-            // sc[f][r] = S[q = lr][key = 16f + 4g + r]
-            const float scale = 0.08838834764831845f * 1.4426950408889634f;
-            float mx = fmaxf(fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3])),
-                             fmaxf(fmaxf(sc[1][0], sc[1][1]), fmaxf(sc[1][2], sc[1][3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            bf16x8 pf;
-            float sum = 0.f;
-#pragma unroll
-            for (int f = 0; f < 2; ++f)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const __bf16 pv = (__bf16)__builtin_amdgcn_exp2f((sc[f][r] - mx) * scale);
-                    pf[f * 4 + r] = pv;
-                    sum += (float)pv;
-                }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
-            const char* vt = Vts + c * (128 * 72);
-            char* own = Qs + (c * 32 + qh * 16) * 256;      // this wave's 16 q rows: private, reused for O
-#pragma unroll
-            for (int df = 0; df < 8; ++df) {
-                const char* vr = vt + (16 * df + lr) * 72 + 8 * g;
-                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr);
-                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + 32);
-                bf16x8 vf;
-                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                const f32x4 o = MFMA16(vf, pf, (f32x4{0.f, 0.f, 0.f, 0.f}));
-                // o[r] = O[q = lr][d = 16df + 4g + r]
-                *reinterpret_cast<bf16x4*>(own + lr * 256 + (16 * df + 4 * g) * 2) = to_bf16x4(o * inv);
-            }
-            // read the 16 x 256 B tile back row-major: 4 rows per instruction, 256 B contiguous per row
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 4 * i + g;
-                const uint4 v = *reinterpret_cast<const uint4*>(own + row * 256 + lr * 16);
-                const int m = m0 + c * 32 + qh * 16 + row;
-                if (m < a.M) *reinterpret_cast<uint4*>(a.O + (size_t)m * SYN_D + head * 128 + lr * 8) = v;
-            }
-        }
-        __syncthreads();
-        stamp(a.dbg, 3 + head * 3);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Fused MLP half of a block (plus the attention output projection in front of it):
-//   h  += o . Wproj^T + bproj ;  x2 = LN2(h)
-//   h  += gelu(x2 . W1^T + b1) . W2^T + b2 ;  y = LN1_next(h)  (or bf16(h) after the last block)
-// One workgroup owns MT = 64 (or 32) rows; the residual rows live in the fc2/proj accumulators
-// (wave w = columns [64w, 64w+64)), x2 (MT x 512 bf16) and one 256-wide slice of the hidden layer live
-// in LDS, so per layer only o (read), h (read+write) and y (write) touch HBM.  The fc1 K-loop reads the
-// resident x2 and needs no barrier; the hidden slices are double-buffered: one barrier per slice.
-//   LDS: [0, 2*MT*128) o K-tiles / LayerNorm scratch | X2 MT x 1024 B | HID 2 x MT x 512 B
-struct BArgs {
-    long long* dbg;       // diagnostics: per-workgroup phase timestamps (null in production)
-    const __bf16* O;  const uint4* Wp; const float* bp;
-    float* H;
-    const float* ln2_g; const float* ln2_b;
-    const uint4* W1; const float* b1; const uint4* W2; const float* b2;
-    const float* lnn_g; const float* lnn_b;     // next LayerNorm (null: y = bf16(h))
-    __bf16* Y;
-    int M;
-};
-
-template <int MT>
-__global__ __launch_bounds__(kThreads) void k_mlp_block(const BArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int MF = MT / 16;
-    constexpr int HC = 256;                       // hidden columns per slice
-#ifndef SYN_D1
-#define SYN_D1 6
-#endif
-#ifndef SYN_D2
-#define SYN_D2 3
-#endif
-    constexpr int D1 = SYN_D1, D2 = SYN_D2;      // weight k-steps in flight in the fc1 / fc2 loops
-    char* const X2 = smem + 2 * MT * 128;
-    char* const HID = X2 + MT * 1024;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, lr = lane & 15;
-    const int m0 = blockIdx.x * MT;
-
-    stamp(a.dbg, 0);
-    // residual + proj bias -> accumulators
-    f32x4 acc[4][MF];
-#pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-        const int n = wave * 64 + nf * 16 + g * 4;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bp + n);
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-            const int m = m0 + mf * 16 + lr;
-            f32x4 h = {0.f, 0.f, 0.f, 0.f};
-            if (m < a.M) h = *reinterpret_cast<const f32x4*>(a.H + (size_t)m * kNT + n);
-            acc[nf][mf] = h + b;
-        }
-    }
-    gemm_mainloop<MT, 4, 1, 0>(acc, a.O, SYN_D, a.M, m0, a.M, SYN_D, a.Wp + ((size_t)(wave * 4) * (SYN_D / 32)) * 64 + lane, smem);
-
-    stamp(a.dbg, 1);
-    // x2 = LN2(h) -> LDS (bf16, 16-B slots swizzled by row & 15); accumulators keep h + b2
-    {
-        float mean[MF], rstd[MF];
-        float* red = reinterpret_cast<float*>(smem);
-        row_stats<MT>(acc, red, red + MT * 8, mean, rstd);
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const int n = wave * 64 + nf * 16 + g * 4;
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(a.ln2_g + n), bb = *reinterpret_cast<const f32x4*>(a.ln2_b + n);
-            const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.b2 + n);
-            const int slot = 8 * wave + 2 * nf + (g >> 1);
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf) {
-                const f32x4 y = (acc[nf][mf] - mean[mf]) * rstd[mf] * gg + bb;
-                *reinterpret_cast<bf16x4*>(X2 + (mf * 16 + lr) * 1024 + ((slot ^ lr) << 4) + (g & 1) * 8) = to_bf16x4(y);
-                acc[nf][mf] = acc[nf][mf] + b2;
-            }
-        }
-    }
-    __syncthreads();
-
-    stamp(a.dbg, 2);
-    constexpr int KS1 = SYN_D / 32, KS2 = SYN_FF / 32;
-    const uint4* W2q = a.W2 + ((size_t)(wave * 4) * KS2) * 64 + lane;
-    for (int c = 0; c < SYN_FF / HC; ++c) {
-        // ---- fc1 slice: hidden[:, 256c + 32*wave + (0..31)] = x2 . W1^T, K = 512, no barriers --------------
-        f32x4 a1[2][MF];
-#pragma unroll
-        for (int nf = 0; nf < 2; ++nf)
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf) a1[nf][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const uint4* W1q = a.W1 + ((size_t)(c * 16 + wave * 2) * KS1) * 64 + lane;
-        uint4 wq[D1][2];                                  // ring of D1 k-steps in flight (latency of L2/MALL)
-#pragma unroll
-        for (int p = 0; p < D1 - 1; ++p)
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf) wq[p][nf] = W1q[((size_t)nf * KS1 + p) * 64];
-#pragma unroll
-        for (int s = 0; s < KS1; ++s) {
-            if (s + D1 - 1 < KS1)
-#pragma unroll
-                for (int nf = 0; nf < 2; ++nf) wq[(s + D1 - 1) % D1][nf] = W1q[((size_t)nf * KS1 + s + D1 - 1) * 64];
-            __builtin_amdgcn_sched_barrier(0);        // keep the prefetch D1-1 k-steps ahead (hipcc would sink it)
-            bf16x8 xf[MF];
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-                xf[mf] = *reinterpret_cast<const bf16x8*>(X2 + (mf * 16 + lr) * 1024 + (((4 * s + g) ^ lr) << 4));
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf) {
-                const bf16x8 wf = __builtin_bit_cast(bf16x8, wq[s % D1][nf]);
-#pragma unroll
-                for (int mf = 0; mf < MF; ++mf) a1[nf][mf] = MFMA16(wf, xf[mf], a1[nf][mf]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (c == 1) stamp(a.dbg, 16 + s);
-        }
-        stamp(a.dbg, 3 + c * 3);
-        // ---- gelu -> hidden slice in LDS (buffer c & 1) ---------------------------------------------------
-        char* const hb = HID + (c & 1) * (MT * 512);
-#pragma unroll
-        for (int nf = 0; nf < 2; ++nf) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(a.b1 + c * HC + wave * 32 + nf * 16 + g * 4);
-            const int slot = 4 * wave + 2 * nf + (g >> 1);
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf) {
-                f32x4 v = a1[nf][mf] + b;
-                v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-                *reinterpret_cast<bf16x4*>(hb + (mf * 16 + lr) * 512 + ((slot ^ lr) << 4) + (g & 1) * 8) = to_bf16x4(v);
-            }
-        }
-        __syncthreads();
-        stamp(a.dbg, 4 + c * 3);
-        // ---- fc2 partial: h[:, 64*wave + ..] += hidden_slice . W2[:, 256c + ..]^T, K = 256 -------------------
-        uint4 w2[D2][4];
-#pragma unroll
-        for (int p = 0; p < D2 - 1; ++p)
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf) w2[p][nf] = W2q[((size_t)nf * KS2 + c * 8 + p) * 64];
-#pragma unroll
-        for (int s = 0; s < HC / 32; ++s) {
-            if (s + D2 - 1 < HC / 32)
-#pragma unroll
-                for (int nf = 0; nf < 4; ++nf) w2[(s + D2 - 1) % D2][nf] = W2q[((size_t)nf * KS2 + c * 8 + s + D2 - 1) * 64];
-            __builtin_amdgcn_sched_barrier(0);
-            bf16x8 xf[MF];
-#pragma unroll
-            for (int mf = 0; mf < MF; ++mf)
-                xf[mf] = *reinterpret_cast<const bf16x8*>(hb + (mf * 16 + lr) * 512 + (((4 * s + g) ^ lr) << 4));
-#pragma unroll
-            for (int nf = 0; nf < 4; ++nf) {
-                const bf16x8 wf = __builtin_bit_cast(bf16x8, w2[s % D2][nf]);
-#pragma unroll
-                for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = MFMA16(wf, xf[mf], acc[nf][mf]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        stamp(a.dbg, 5 + c * 3);
-    }
-    // ---- h out, next LayerNorm (or plain copy) -> y ---------------------------------------------------------
-    GArgs e;
-    e.H = a.H; e.Y = a.Y; e.ldy = SYN_D; e.ln_g = a.lnn_g; e.ln_b = a.lnn_b; e.M = a.M;
-    __syncthreads();                   // LayerNorm scratch aliases the o K-tile buffers; all waves are past them
-    store_h_and_norm<MT>(e, acc, m0, smem);
-    stamp(a.dbg, 15);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1851,9 +1571,6 @@ constexpr int kN128Lds = 128 * 1024;
 // port: a workgroup pulls (MT + 128) x K x 2) and whose activation block fits the LDS; 0 = the shape does not fit this kernel at all.
 int pick_mt128(int M, int N, int K, int chip_parts = 1) {            // chip_parts 2: the GEMM shares the launch (and the chip) with another one
     if (K * 32 > kN128Lds) return 0;
-    static int g_force = -1;
-    if (g_force < 0) { const char* e = getenv("SYN_GEMM_MT128"); g_force = e ? atoi(e) : 0; }
-    if (g_force && g_force * K * 2 <= kN128Lds) return g_force;
     const int cus = device_cus();
     for (int mt = 64; mt > 16; mt >>= 1)
         if (mt * K * 2 <= kN128Lds && ((M + mt - 1) / mt) * (N / 128) >= cus * 3 / (4 * chip_parts)) return mt;
@@ -1915,39 +1632,6 @@ void n128_setup() {
         allow_lds(k_gemm_and_pack<16, 2>, kN128Lds);
         allow_lds(k_gemm_quad, kN128Lds);
     }
-}
-
-int launch_attn_block(const AArgs& a, int mt, hipStream_t s) {
-    static OncePerDevice once;
-    if (once.first()) {
-        allow_lds(k_attn_block<128>, 2 * 128 * 128 + 2 * 128 * 256 + 4 * 128 * 72);
-        allow_lds(k_attn_block<64>, 2 * 64 * 128 + 2 * 64 * 256 + 2 * 128 * 72);
-    }
-    dim3 grid((a.M + mt - 1) / mt), block(kThreads);
-    switch (mt) {
-        case 128: hipLaunchKernelGGL(k_attn_block<128>, grid, block, 2 * 128 * 128 + 2 * 128 * 256 + 4 * 128 * 72, s, a); break;
-        case 64:  hipLaunchKernelGGL(k_attn_block<64>, grid, block, 2 * 64 * 128 + 2 * 64 * 256 + 2 * 128 * 72, s, a); break;
-        case 32:  hipLaunchKernelGGL(k_attn_block<32>, grid, block, 2 * 32 * 128 + 2 * 32 * 256 + 1 * 128 * 72, s, a); break;
-        default:  return fail_msg("attn_block: m_tile must be 32, 64 or 128");
-    }
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("k_attn_block launch", e);
-}
-
-int launch_mlp_block(const BArgs& a, int mt, hipStream_t s) {
-    static OncePerDevice once;
-    if (once.first()) {
-        allow_lds(k_mlp_block<64>, 64 * 2304);
-        allow_lds(k_mlp_block<32>, 32 * 2304);
-    }
-    dim3 grid((a.M + mt - 1) / mt), block(kThreads);
-    switch (mt) {
-        case 64: hipLaunchKernelGGL(k_mlp_block<64>, grid, block, 64 * 2304, s, a); break;
-        case 32: hipLaunchKernelGGL(k_mlp_block<32>, grid, block, 32 * 2304, s, a); break;
-        default: return fail_msg("mlp_block: m_tile must be 32 or 64");
-    }
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("k_mlp_block launch", e);
 }
 
 int launch_stack(const SArgs& a, int mt, hipStream_t s) {
@@ -3039,9 +2723,7 @@ int syn_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* st
 
 int syn_attn_fwd(const float* qkv, float* o, void* o_bf16, int32_t n_seq, void* stream) {
     if (!qkv || (!o && !o_bf16) || n_seq <= 0) return fail_msg("syn_attn_fwd: bad arguments");
-    static const bool v1 = getenv("SYN_ATTN_BWD_V1") != nullptr;    // diagnostics: the first version of the kernels
-    if (v1) hipLaunchKernelGGL(trn::k_attn_fwd, dim3(n_seq * SYN_HEADS), dim3(256), 0, (hipStream_t)stream, qkv, o, (__bf16*)o_bf16);
-    else hipLaunchKernelGGL(trn::k_attn_fwd2, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnFwd2Lds, (hipStream_t)stream, qkv, o, (__bf16*)o_bf16);
+    hipLaunchKernelGGL(trn::k_attn_fwd2, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnFwd2Lds, (hipStream_t)stream, qkv, o, (__bf16*)o_bf16);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_attn_fwd launch", e);
 }
@@ -3049,10 +2731,8 @@ int syn_attn_fwd(const float* qkv, float* o, void* o_bf16, int32_t n_seq, void* 
 int syn_attn_bwd(const float* qkv, const float* d_o, float* dqkv, int32_t n_seq, void* stream) {
     if (!qkv || !d_o || !dqkv || n_seq <= 0) return fail_msg("syn_attn_bwd: bad arguments");
     static OncePerDevice once;
-    static const bool v1 = getenv("SYN_ATTN_BWD_V1") != nullptr;    // diagnostics: the first version of the kernel (one LDS float per FMA)
-    if (once.first()) { allow_lds(trn::k_attn_bwd, trn::kAttnBwdLds); allow_lds(trn::k_attn_bwd2, trn::kAttnBwd2Lds); }
-    if (v1) hipLaunchKernelGGL(trn::k_attn_bwd, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnBwdLds, (hipStream_t)stream, qkv, d_o, dqkv);
-    else hipLaunchKernelGGL(trn::k_attn_bwd2, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnBwd2Lds, (hipStream_t)stream, qkv, d_o, dqkv);
+    if (once.first()) allow_lds(trn::k_attn_bwd2, trn::kAttnBwd2Lds);
+    hipLaunchKernelGGL(trn::k_attn_bwd2, dim3(n_seq * SYN_HEADS), dim3(256), trn::kAttnBwd2Lds, (hipStream_t)stream, qkv, d_o, dqkv);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_attn_bwd launch", e);
 }
@@ -3199,8 +2879,7 @@ static int first_wgrad_groups(int n_clips, int l_out) {
     return (int)(by_work < 1 ? 1 : by_work < want ? by_work : want);
 }
 int32_t syn_conv1d_first_parts(int32_t n_clips, int32_t l_out) {
-    const int chunks = n_clips * ((l_out + wav::kF1Chunk - 1) / wav::kF1Chunk), groups = first_wgrad_groups(n_clips, l_out);
-    return chunks > groups ? chunks : groups;                 // (partial sums: whichever of the kernels runs fits)
+    return n_clips > 0 && l_out > 0 ? first_wgrad_groups(n_clips, l_out) : 0;        // one partial gradient per workgroup
 }
 int32_t syn_conv1d_first_tiles(int32_t n_clips, int32_t l_out) { return n_clips > 0 && l_out > 0 ? n_clips * ((l_out + wav::kF1Tile - 1) / wav::kF1Tile) : 0; }
 
@@ -3245,31 +2924,13 @@ static int first_wgrad_impl(const float* x, const float* dy, const float* bn_y, 
         a.BY = bn_y; a.bn_stats = bn_stats; a.bn_aff = bn_aff; a.bn_dgb = bn_dgb; a.bn_inv_rows = 1.0f / ((float)n_clips * (float)a.L_out); a.bn_act = bn_act;
     }
     hipStream_t s = (hipStream_t)stream;
-    static const bool stream_mfma = getenv("SYN_FIRST_WGRAD_FMA") == nullptr;  // (A/B: the fp32-FMA kernels below)
-    if (stream_mfma) {
-        const int groups = first_wgrad_groups(n_clips, a.L_out);
-        if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_wgrad_m<1>, dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
-        else hipLaunchKernelGGL(wav::k_conv_first_wgrad_m<2>, dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
-        const int n = 64 * cin * 15;
-        hipLaunchKernelGGL(wav::k_conv_first_wsum, dim3((n + 63) / 64), dim3(1024), 0, s, (const float*)ws, groups, n, dw);
-        hipError_t e = hipGetLastError();
-        return e == hipSuccess ? 0 : fail("k_conv_first_wgrad_m launch", e);
-    }
-    static const bool blocked = getenv("SYN_FIRST_WGRAD_V1") == nullptr;       // (A/B: the one-position-per-step kernel)
-    const bool v5 = stride == 5 && (blocked || bn_y);
-    const size_t win = (size_t)((wav::kF1Chunk - 1 + (v5 ? 2 : 0)) * stride + 15) * cin, red = (size_t)8 * cin * 15 * 64;
-    const size_t lds = (win > red ? win : red) * sizeof(float);
-    if (lds > 64 * 1024) return fail_msg("syn_conv1d_first_wgrad: stride too large for the window");
-    const dim3 grid(a.chunks_per_clip, n_clips);
-    if (v5) {
-        if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_wgrad5<1>, grid, dim3(512), lds, s, a);
-        else hipLaunchKernelGGL(wav::k_conv_first_wgrad5<2>, grid, dim3(512), lds, s, a);
-    } else if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_wgrad<1>, grid, dim3(512), lds, s, a);
-    else hipLaunchKernelGGL(wav::k_conv_first_wgrad<2>, grid, dim3(512), lds, s, a);
+    const int groups = first_wgrad_groups(n_clips, a.L_out);
+    if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_wgrad_m<1>, dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
+    else hipLaunchKernelGGL(wav::k_conv_first_wgrad_m<2>, dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
     const int n = 64 * cin * 15;
-    hipLaunchKernelGGL(wav::k_conv_first_wsum, dim3((n + 63) / 64), dim3(1024), 0, s, (const float*)ws, n_clips * a.chunks_per_clip, n, dw);
+    hipLaunchKernelGGL(wav::k_conv_first_wsum, dim3((n + 63) / 64), dim3(1024), 0, s, (const float*)ws, groups, n, dw);
     hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : fail("k_conv_first_wgrad launch", e);
+    return e == hipSuccess ? 0 : fail("k_conv_first_wgrad_m launch", e);
 }
 
 int syn_conv1d_first_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws,
@@ -3367,10 +3028,9 @@ int64_t syn_conv1d_pack_bytes(int32_t cout, int32_t cin, int32_t stride, int32_t
     return (int64_t)cout * kts * cin * 2;
 }
 
-static int conv_variant(int cls);
-
 // Data gradient of a strided, unpadded Conv1d(k = 15) of the encoder: dx [n][l_in][cin] from dy [n][l_out][cout] - a stride-1
-// convolution over dy whose output rows are stride consecutive positions x cin channels; three launches of 128 columns each.
+// convolution over dy whose output rows are stride consecutive positions x cin channels: ONE launch over all stride x cin columns, 64 per
+// workgroup (grid z), a wave 16 channels x 128 / 64 / 32 positions (the decompositions measured in round 5: profiles/r05_ubench_conv_variants.txt).
 static int dgrad_strided_impl(const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t cout,
                               const void* w_hi, const void* w_lo, const float* dy2, const void* w2_hi, const void* w2_lo, float* dx, void* stream) {
     if (!dy || !w_hi || !w_lo || !dx || n_clips <= 0 || l_in < 15 || stride < 2) return fail_msg("syn_conv1d_train_dgrad_strided: bad arguments");
@@ -3378,73 +3038,34 @@ static int dgrad_strided_impl(const float* dy, int32_t n_clips, int32_t l_in, in
     const int l_out = (l_in - 15) / stride + 1, kt = dgrad_taps(stride, cout), q_rows = (l_in + stride - 1) / stride, np = stride * cin;
     if (np % 128) return fail_msg("syn_conv1d_train_dgrad_strided: stride * cin must be a multiple of 128");
     hipStream_t s = (hipStream_t)stream;
-    const int cls = cout == 64 ? 6 : cout == 128 ? 7 : 8;
-    const bool one_launch = conv_variant(cls) != 0;          // all stride x cin columns in one launch, 64 per workgroup (grid z)
-    for (int c0 = 0; c0 < np; c0 += one_launch ? np : 128) {
-        wav::TArgs a;
-        a.X = dy; a.x_clip_stride = (long)l_out * cout; a.x_elems = (long)l_out * cout; a.row0 = -(kt - 1); a.L_out = q_rows;
-        const size_t frag0 = (size_t)(c0 / 16) * (kt * cout / 32) * 64;
-        a.Whi = (const uint4*)w_hi + frag0; a.Wlo = (const uint4*)w_lo + frag0; a.bias = nullptr;
-        a.Y = dx; a.y_clip_stride = (long)l_in * cin; a.y_pitch = np; a.y_col0 = c0; a.y_elems = (long)l_in * cin; a.bn_part = nullptr;
-        a.in_aff = nullptr; a.in_act = 0; a.R = nullptr;
-        a.X2 = dy2; a.Whi2 = dy2 ? (const uint4*)w2_hi + frag0 : nullptr; a.Wlo2 = dy2 ? (const uint4*)w2_lo + frag0 : nullptr;
-        int rc;
-        if (one_launch && cout == 64 && kt == 3) rc = conv_variant(cls) == 1 ? launch_conv_train<64, 3, 4, 1, 8, 1>(a, n_clips, s, np) : launch_conv_train<64, 3, 4, 1, 4, 1>(a, n_clips, s, np);
-        else if (one_launch && cout == 128 && kt == 3) rc = conv_variant(cls) == 1 ? launch_conv_train<128, 3, 4, 1, 4, 1>(a, n_clips, s, np) : launch_conv_train<128, 3, 4, 1, 2, 1>(a, n_clips, s, np);
-        else if (one_launch && cout == 256 && kt == 6) rc = conv_variant(cls) == 1 ? launch_conv_train<256, 6, 4, 1, 3, 1>(a, n_clips, s, np) : launch_conv_train<256, 6, 4, 1, 2, 1>(a, n_clips, s, np);
-        else if (cout == 64 && kt == 3) rc = launch_conv_train<64, 3, 2, 2, 4>(a, n_clips, s);
-        // (a launch covers 128 of the stride x cin columns: tiles halved while it would not fill the chip twice - 32 clips: 45 -> 30 us and
-        // 76 -> 53 us for the three launches of the 128- / 256-channel layers)
-        else if (cout == 128 && kt == 3) rc = (long)n_clips * ((q_rows + 127) / 128) >= 2 * device_cus() ? launch_conv_train<128, 3, 2, 2, 4>(a, n_clips, s)
-                                                                                                           : launch_conv_train<128, 3, 2, 2, 2>(a, n_clips, s);
-        else if (cout == 256 && kt == 6) rc = (long)n_clips * ((q_rows + 63) / 64) >= 2 * device_cus() ? launch_conv_train<256, 6, 2, 2, 2>(a, n_clips, s)
-                                                                                                         : launch_conv_train<256, 6, 2, 2, 1>(a, n_clips, s);
-        else return fail_msg("syn_conv1d_train_dgrad_strided: (cout, stride) must be (64, 6), (128, 6) or (256, 3)");
-        if (rc) return rc;
-    }
-    return 0;
-}
-
-int syn_conv1d_train_dgrad_strided(const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t cout,
-                                   const void* w_hi, const void* w_lo, float* dx, void* stream) {
-    return dgrad_strided_impl(dy, n_clips, l_in, cin, stride, cout, w_hi, w_lo, nullptr, nullptr, nullptr, dx, stream);
+    wav::TArgs a;
+    a.X = dy; a.x_clip_stride = (long)l_out * cout; a.x_elems = (long)l_out * cout; a.row0 = -(kt - 1); a.L_out = q_rows;
+    a.Whi = (const uint4*)w_hi; a.Wlo = (const uint4*)w_lo; a.bias = nullptr;
+    a.Y = dx; a.y_clip_stride = (long)l_in * cin; a.y_pitch = np; a.y_col0 = 0; a.y_elems = (long)l_in * cin; a.bn_part = nullptr;
+    a.in_aff = nullptr; a.in_act = 0; a.R = nullptr;
+    a.X2 = dy2; a.Whi2 = dy2 ? (const uint4*)w2_hi : nullptr; a.Wlo2 = dy2 ? (const uint4*)w2_lo : nullptr;
+    if (cout == 64 && kt == 3) return launch_conv_train<64, 3, 4, 1, 8, 1>(a, n_clips, s, np);
+    if (cout == 128 && kt == 3) return launch_conv_train<128, 3, 4, 1, 4, 1>(a, n_clips, s, np);
+    if (cout == 256 && kt == 6) return launch_conv_train<256, 6, 4, 1, 2, 1>(a, n_clips, s, np);
+    return fail_msg("syn_conv1d_train_dgrad_strided: (cout, stride) must be (64, 6), (128, 6) or (256, 3)");
 }
 
 // row fragments (16 positions) per tile of the K-split kernel: 3 = 48 positions, 78 KB of LDS, so two workgroups share a CU and
 // one's staging overlaps the other's MFMA phase (4 = 64 positions, 103 KB: one workgroup per CU)
 constexpr int kKsRf = 3;
-// positions per workgroup tile of syn_conv1d_train_fwd's kernel instance (0: not one of the encoder's layers)
-// decomposition of a layer class (diagnostics: SYN_CV = one digit per class - 0: 64x1->64, 1: 128x1->128, 2: 256x1->256, 3: 64x6->64, 4: 64x6->128,
-// 5: 128x3->256, 6 - 8: the strided data gradients of 3 - 5; digit 0 = the first version, 64 channels per wave)
-static int conv_variant(int cls) {
-    static int v[16] = {-1};
-    if (v[0] < 0) {
-        static const int dflt[16] = {1, 1, 2, 0, 0, 1, 1, 1, 2};
-        const char* e = getenv("SYN_CV");
-        const size_t n = e ? strlen(e) : 0;
-        for (int i = 15; i >= 0; --i) v[i] = (size_t)i < n && e[i] >= '0' && e[i] <= '9' ? e[i] - '0' : dflt[i];
-    }
-    return v[cls];
-}
+// positions per workgroup tile of syn_conv1d_train_fwd's kernel instance (0: not one of the encoder's layers).  The decomposition of every layer
+// class - channels and positions per wave, channel blocks on grid z - is the one that won round 5's comparison (profiles/r05_ubench_conv_variants.txt;
+// the other variants live in the lab notebook, not here): what bounds these kernels is the CU's L1 port (weight fragments), so a wave takes few
+// channels and many positions.
 static int conv_train_tile(int cinp, int stride, int cout, int n_clips, int l_out) {
-    if (cinp == 384 && stride == 6 && cout == 64 && conv_variant(3)) return conv_variant(3) == 1 ? 32 : 64;
-    if (cinp == 384 && stride == 6 && cout == 64 && !getenv("SYN_CONV_POS_SPLIT")) return 16 * kKsRf;
-    const bool small = getenv("SYN_CONV_BIG_TILES") == nullptr;           // (diagnostics: the large tiles everywhere)
-    // (r5b: 224 positions - two planes of 238 rows x 160 B = 76 KB, two workgroups per CU with the 32-byte row padding)
-    if (cinp == 64 && stride == 1 && cout == 64) return small && (long)n_clips * ((l_out + 255) / 256) < 2 * device_cus() ? 128 : conv_variant(0) ? 224 : 256;
-    if (cinp == 128 && stride == 1 && cout == 128) return conv_variant(1) ? 64 : small && (long)n_clips * ((l_out + 127) / 128) < 2 * device_cus() ? 64 : 128;
-    if (cinp == 256 && stride == 1 && cout == 256) {         // (32 clips x 128 positions: 155 us for forward + data gradient on 64-position tiles, 137 / 113 / 102 on 48 / 32 / 16)
-        if (conv_variant(2)) return conv_variant(2) == 2 ? 32 : 64;
-        if (!small) return 48;
-        for (int mw = 48; mw > 16; mw -= 16)
-            if ((long)n_clips * ((l_out + mw - 1) / mw) >= 2 * device_cus()) return mw;
-        return 16;
-    }
-    if (cinp == 384 && stride == 6) return conv_variant(4) == 1 ? 32 : 64;
-    if (cinp == 384 && stride == 3) {
-        if (conv_variant(5)) return conv_variant(5) == 1 ? 32 : 16;
-        return small && (long)n_clips * ((l_out + 31) / 32) < 2 * device_cus() ? 16 : 32;
-    }
+    if (cinp == 384 && stride == 6 && cout == 64) return 16 * kKsRf;
+    // (224 positions - two planes of 238 rows x 160 B = 76 KB, two workgroups per CU with the 32-byte row padding; short layers: 128, so that the
+    // launch still fills the chip and the last tile of a clip wastes less)
+    if (cinp == 64 && stride == 1 && cout == 64) return (long)n_clips * ((l_out + 255) / 256) < 2 * device_cus() ? 128 : 224;
+    if (cinp == 128 && stride == 1 && cout == 128) return 64;
+    if (cinp == 256 && stride == 1 && cout == 256) return 32;
+    if (cinp == 384 && stride == 6) return 64;
+    if (cinp == 384 && stride == 3) return 32;
     return 0;
 }
 
@@ -3474,45 +3095,14 @@ static int conv_train_fwd_impl(const float* x, int32_t n_clips, int32_t l_in, in
     // (rows of stride * cin floats, ceil(15 / stride) taps; tiles as the eval-mode encoder picks them, halved where two planes
     // of a 384-channel tile would not fit the LDS)
     // (short layers: smaller tiles, so that the launch still fills the chip and the last tile of a clip wastes less)
-    if (cinp == 64 && stride == 1 && cout == 64) {
-        const bool big = conv_train_tile(cinp, stride, cout, n_clips, l_out) > 128;
-        switch (conv_variant(0)) {
-        case 1: return big ? launch_conv_train<64, 15, 2, 2, 7, 2>(a, n_clips, s, 64) : launch_conv_train<64, 15, 2, 2, 4, 2>(a, n_clips, s, 64);   // 32 channels x 112 / 64 positions per wave
-        case 2: return big ? launch_conv_train<64, 15, 4, 1, 14, 1>(a, n_clips, s, 64) : launch_conv_train<64, 15, 4, 1, 8, 1>(a, n_clips, s, 64);  // 16 channels x 224 / 128 positions per wave
-        default: return big ? launch_conv_train<64, 15, 1, 4, 4>(a, n_clips, s) : launch_conv_train<64, 15, 1, 4, 2>(a, n_clips, s);
-        }
-    }
-    if (cinp == 128 && stride == 1 && cout == 128) {
-        switch (conv_variant(1)) {
-        case 1: return launch_conv_train<128, 15, 4, 1, 4, 1>(a, n_clips, s, 128);      // 64 positions x 64 channels per workgroup (z: 2), a wave: 16 channels x 64 positions
-        case 2: return launch_conv_train<128, 15, 4, 1, 4, 2>(a, n_clips, s, 128);      // 64 positions x 128 channels per workgroup, a wave: 32 channels x 64 positions
-        default: break;
-        }
-        return conv_train_tile(cinp, stride, cout, n_clips, l_out) == 128 ? launch_conv_train<128, 15, 2, 2, 4>(a, n_clips, s)
-                                                                          : launch_conv_train<128, 15, 2, 2, 2>(a, n_clips, s);
-    }
-    if (cinp == 256 && stride == 1 && cout == 256) {
-        if (conv_variant(2) == 1) return launch_conv_train<256, 15, 4, 1, 4, 1>(a, n_clips, s, 256);   // 64 positions x 64 channels per workgroup (z: 4)
-        if (conv_variant(2) == 2) return launch_conv_train<256, 15, 4, 1, 2, 1>(a, n_clips, s, 256);   // 32 positions x 64 channels
-        const int mw = conv_train_tile(cinp, stride, cout, n_clips, l_out);
-        return mw == 48 ? launch_conv_train<256, 15, 4, 1, 3>(a, n_clips, s)                                       // (48 positions: 65 KB, two workgroups per CU)
-             : mw == 32 ? launch_conv_train<256, 15, 4, 1, 2>(a, n_clips, s) : launch_conv_train<256, 15, 4, 1, 1>(a, n_clips, s);
-    }
-    static const bool pos_split = getenv("SYN_CONV_POS_SPLIT") != nullptr;      // diagnostics: the waves split positions (the first version)
-    if (cinp == 384 && stride == 6 && cout == 64 && conv_variant(3))
-        return conv_variant(3) == 1 ? launch_conv_train<384, 3, 4, 1, 2, 1>(a, n_clips, s, 64) : launch_conv_train<384, 3, 4, 1, 4, 1>(a, n_clips, s, 64);   // a wave: 16 channels x 32 / 64 positions
-    if (cinp == 384 && stride == 6 && cout == 64)
-        return pos_split ? launch_conv_train<384, 3, 1, 4, 1>(a, n_clips, s) : launch_conv_train_ks<384, 3, kKsRf>(a, n_clips, s);
-    if (cinp == 384 && stride == 6 && cout == 128) {
-        if (conv_variant(4) == 1) return launch_conv_train<384, 3, 4, 1, 2, 1>(a, n_clips, s, 128);   // 32 positions x 64 channels per workgroup (z: 2)
-        if (conv_variant(4) == 2) return launch_conv_train<384, 3, 4, 1, 4, 1>(a, n_clips, s, 128);   // 64 positions x 64 channels
-        return launch_conv_train<384, 3, 2, 2, 2>(a, n_clips, s);   // (32-position tiles, three workgroups per CU: 27 -> 30 us)
-    }
-    if (cinp == 384 && stride == 3 && cout == 256 && conv_variant(5))
-        return conv_variant(5) == 1 ? launch_conv_train<384, 5, 4, 1, 2, 1>(a, n_clips, s, 256) : launch_conv_train<384, 5, 4, 1, 1, 1>(a, n_clips, s, 256);   // 32 / 16 positions x 64 channels (z: 4)
-    if (cinp == 384 && stride == 3 && cout == 256)
-        return conv_train_tile(cinp, stride, cout, n_clips, l_out) == 32 ? launch_conv_train<384, 5, 4, 1, 2>(a, n_clips, s)
-                                                                         : launch_conv_train<384, 5, 4, 1, 1>(a, n_clips, s);
+    if (cinp == 64 && stride == 1 && cout == 64)               // a wave: 32 channels x 112 / 64 positions
+        return conv_train_tile(cinp, stride, cout, n_clips, l_out) > 128 ? launch_conv_train<64, 15, 2, 2, 7, 2>(a, n_clips, s, 64)
+                                                                         : launch_conv_train<64, 15, 2, 2, 4, 2>(a, n_clips, s, 64);
+    if (cinp == 128 && stride == 1 && cout == 128) return launch_conv_train<128, 15, 4, 1, 4, 1>(a, n_clips, s, 128);   // 64 positions x 64 channels per workgroup (z: 2), a wave: 16 channels x 64 positions
+    if (cinp == 256 && stride == 1 && cout == 256) return launch_conv_train<256, 15, 4, 1, 2, 1>(a, n_clips, s, 256);   // 32 positions x 64 channels (z: 4)
+    if (cinp == 384 && stride == 6 && cout == 64) return launch_conv_train_ks<384, 3, kKsRf>(a, n_clips, s);            // the four waves split K
+    if (cinp == 384 && stride == 6 && cout == 128) return launch_conv_train<384, 3, 2, 2, 2>(a, n_clips, s);            // 64-position tiles
+    if (cinp == 384 && stride == 3 && cout == 256) return launch_conv_train<384, 5, 4, 1, 2, 1>(a, n_clips, s, 256);    // 32 positions x 64 channels (z: 4)
     return fail_msg("syn_conv1d_train_fwd: not one of the WavEncoder's convolutions (cin x stride -> cout: 64x1->64, 128x1->128, 256x1->256, 64x6->64, 64x6->128, 128x3->256)");
 }
 
@@ -3612,6 +3202,7 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
         return e == hipSuccess ? 0 : fail("syn_denoise_step", e);
     }
     int mode = st->reserved & 3;
+    if (mode == 2) return fail_msg("syn_denoise_step: kernel selection 2 (two kernels per block) was removed in ABI 8; 1 = the per-operation path");
     // Small batches: the persistent feature-split kernel (syn_latency.inc) beats the token-resident one while a
     // group (XCD) holds at most 4 sequences (measured per step: 161 / 239 / 405 us at 1 / 2 / 4 sequences per
     // group against ~445 us, and 733 us at 8).  Guided batches (V > 1) deal SEQUENCES to the XCDs when the caller
@@ -3625,14 +3216,9 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     // 32-row tile split over 4 (<= 64 sequences) or 2 workgroups of one XCD, see k_stack.  reserved bit 3 (value 8)
     // switches it off, and so does pinning a kernel (bit 2) or a tile size.
     const int tiles = V * B;
-    // 129..256 sequences as 64-row tiles (two sequences) split over 2 workgroups - 256 workgroups at 256 sequences, each streaming HALF the weight set for
-    // twice the rows of the one-tile-per-CU form - was measured in round 5 and is SLOWER (SYN_STACK64_TP=1; one box: 130 / 160 / 192 / 224 / 256 sequences
-    // 417 / 428 / 446 / 482 / 526 us per step against 401 / 406 / 415 / 426 / 448 us of one 32-row tile per CU): the 64-row instance lives at 256 registers and
-    // 130 KB of LDS and adds 16 exchanges of 128 KB partials per member.  Off by default.
-    static const bool tp64 = getenv("SYN_STACK64_TP") != nullptr && atoi(getenv("SYN_STACK64_TP")) != 0;
+    // (129..256 sequences as 64-row tiles split over 2 workgroups: measured in round 5 and slower than one 32-row tile per CU - lab notebook)
     const bool use_tp = mode == 0 && st->m_tile == 0 && !(st->reserved & 12) && st->ws_sync && st->ws_xch &&
-                        tiles >= 9 && tiles <= (tp64 ? 256 : 128) && latency_path_ok();
-    const bool tp_wide = use_tp && tiles > 128;
+                        tiles >= 9 && tiles <= 128 && latency_path_ok();
     if (mode == 0 && !use_tp && !(st->reserved & 4) && st->ws_sync && per_group <= 4 && latency_path_ok()) mode = 3;
     if (mode == 3) {
         // small-batch path: one persistent kernel, output features split over the CUs of an XCD
@@ -3684,9 +3270,8 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
     aout.t_coef = st->t_coef; aout.Xn = st->x_next; aout.Xnb = (__bf16*)st->x_next_bf16; aout.X0 = st->pred_x0;
     const bool fuse_out = mode == 0 && V == 1;
 
-    // layer implementation: 0 = whole stack in one kernel (production), 2 = two fused kernels per block,
-    // 1 = five kernels per block.  1 and 2 are kept for A/B measurements and bitwise cross-checks.
-    const bool fused = mode == 2;
+    // layer implementation: 0 = whole stack in one kernel (production); 1 = five kernels per block, kept as the plain restatement the whole-stack kernel is
+    // checked against bit for bit (tests) and for the h8 tap it leaves in ws_xn.
     if (mode == 0) {
         SArgs sa;
         memset(&sa, 0, sizeof(sa));
@@ -3697,31 +3282,10 @@ static int step_impl(const syn_model* md, const syn_step* st, hipStream_t s, Sta
         int tile_rows = mt > 64 ? 64 : mt;
         sa.tp = 1;
         if (use_tp) {
-            sa.tp = tiles <= 64 ? 4 : 2; sa.tp_tiles = tp_wide ? (tiles + 1) / 2 : tiles; sa.sync = st->ws_sync; sa.xch = st->ws_xch; tile_rows = tp_wide ? 64 : 32;
+            sa.tp = tiles <= 64 ? 4 : 2; sa.tp_tiles = tiles; sa.sync = st->ws_sync; sa.xch = st->ws_xch; tile_rows = 32;
         }
         if ((rc = launch_stack(sa, tile_rows, s))) return rc;
         mark(ST_FC2);
-    } else
-    if (fused) {
-        const int mtb = mt > 64 ? 64 : mt;
-        for (int l = 0; l < SYN_LAYERS; ++l) {
-            const syn_layer& L = md->layer[l];
-            AArgs aa;
-            aa.dbg = l == 3 ? g_dbg_attn : nullptr;
-            aa.X = (const __bf16*)st->ws_xn; aa.W = (const uint4*)L.w_qkv; aa.O = (__bf16*)st->ws_o; aa.M = R;
-            if ((rc = launch_attn_block(aa, mt, s))) return rc;
-            mark(ST_QKV);
-            BArgs bb;
-            bb.dbg = l == 3 ? g_dbg_mlp : nullptr;
-            bb.O = (const __bf16*)st->ws_o; bb.Wp = (const uint4*)L.w_proj; bb.bp = L.b_proj; bb.H = st->ws_h;
-            bb.ln2_g = L.ln2_g; bb.ln2_b = L.ln2_b; bb.W1 = (const uint4*)L.w_fc1; bb.b1 = L.b_fc1;
-            bb.W2 = (const uint4*)L.w_fc2; bb.b2 = L.b_fc2;
-            bb.lnn_g = l + 1 < SYN_LAYERS ? md->layer[l + 1].ln1_g : nullptr;
-            bb.lnn_b = l + 1 < SYN_LAYERS ? md->layer[l + 1].ln1_b : nullptr;
-            bb.Y = (__bf16*)st->ws_xn; bb.M = R;
-            if ((rc = launch_mlp_block(bb, mtb, s))) return rc;
-            mark(ST_FC2);
-        }
     } else
     for (int l = 0; l < SYN_LAYERS; ++l) {
         const syn_layer& L = md->layer[l];

@@ -154,7 +154,7 @@ class MDM(nn.Module):
         self._bufs, self._cond_entry = {}, None
         self.m_tile = 0
         self.layer_mode = 0            # syn_step.reserved: 0 library's choice (small-batch kernel for few sequences, else the
-                                       # whole-step kernel); 4 / 3 pin one of them; 2 / 1: two / five kernels per block (A/B)
+                                       # whole-step kernel); 4 / 3 / 5 pin one of them; 1: five kernels per block (bitwise cross-check, h8 tap)
         self.differentiable_eval = False   # eval() + autograd on: take the differentiable path (gradient tests)
 
     # ---- engine plumbing ----------------------------------------------------------------------

@@ -134,8 +134,8 @@ class StepBuffers:
         self.sync = torch.zeros(320, dtype=torch.int32, device=device)   # small-batch path: barrier counters + error flag
         s = _lib.SynStep()
         s.n_clips, s.n_variants, s.m_tile = B, V, m_tile
-        # 0 auto (small-batch kernel for few sequences, whole-step kernel otherwise); 4 / 3 pin one of them;
-        # 2 / 1 = two / five kernels per block (A/B, bisecting)
+        # 0 auto (small-batch kernel for few sequences, whole-step kernel otherwise); 4 / 3 / 5 pin one of them;
+        # 1 = five kernels per block (the restatement the whole-step kernel is checked against bit for bit)
         s.reserved = layer_mode
         s.cond, s.t_model, s.cfg_w = self.cond.data_ptr(), self.t_model.data_ptr(), _lib.ptr(self.cfg_w)
         s.x_t, s.x_t_bf16, s.noise = self.x.data_ptr(), self.xb.data_ptr(), self.noise.data_ptr()

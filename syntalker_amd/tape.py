@@ -82,10 +82,6 @@ def _wide_order(f: torch.Tensor, split: int = 0) -> torch.Tensor:
     [kc < split][slab tiles 12..15], then whole k chunks [tile 0..15] - the last one slab tiles first (their stores ride in the gaps of
     the twelve MFMAs that follow)."""
     kc = f.shape[0]
-    if _os.environ.get("SYN_TAPE_LEGACY_WIDE"):      # A/B only: the order an older libsyn_hip.so (kernel variants) consumes
-        head = f[:, :REG_TILES].reshape(-1, 64, 8)
-        tail = f[:, REG_TILES:].reshape(kc, (16 - REG_TILES) // 2, 2, 64, 8).permute(1, 0, 2, 3, 4).reshape(-1, 64, 8)
-        return torch.cat([head, tail], 0)
     out = []
     if split:
         out += [f[:split, :REG_TILES].reshape(-1, 64, 8), f[:split, REG_TILES:].reshape(-1, 64, 8)]

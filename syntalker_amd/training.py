@@ -294,104 +294,6 @@ def lin(x, module: nn.Linear):
     return HipLinearFn.apply(x, module.weight, module.bias)
 
 
-# ---- the fp32 block ops as autograd nodes of their own ---------------------------------------------------------------------------------------
-# LayerNorm, the 32-token attention and GELU on the kernels the fused branches below are built from.  The product path runs the fused nodes;
-# these are what tests/test_gpu_kernels.py composes the op-by-op reference of a branch from (and checks against PyTorch's own ops to 1e-5).
-
-class HipLayerNormFn(torch.autograd.Function):
-    """nn.LayerNorm(512, eps 1e-5): fp32 forward / backward kernels (syn_ln_fwd / syn_ln_bwd)."""
-
-    @staticmethod
-    def forward(ctx, x, g, b):
-        engine._require_cuda(x, "LayerNorm input")
-        xc, gc, bc = _f32c(x).view(-1, 512), _f32c(g), _f32c(b)
-        rows = xc.shape[0]
-        y = torch.empty_like(xc)
-        mean, rstd = torch.empty(rows, device=x.device), torch.empty(rows, device=x.device)
-        _lib.check(_lib.load().syn_ln_fwd(xc.data_ptr(), gc.data_ptr(), bc.data_ptr(), y.data_ptr(), None, mean.data_ptr(), rstd.data_ptr(),
-                                          rows, _lib.current_stream(y.device)), "syn_ln_fwd")
-        ctx.save_for_backward(xc, gc, mean, rstd)
-        return y.view(x.shape)
-
-    @staticmethod
-    def backward(ctx, dy):
-        dx, dg, db = HipLayerNormFn._bwd(ctx, dy, None)
-        return dx, dg, db
-
-    @staticmethod
-    def _bwd(ctx, dy, dres):
-        xc, gc, mean, rstd = ctx.saved_tensors
-        rows = xc.shape[0]
-        dyc = _f32c(dy).view(-1, 512)
-        add = None if dres is None else _f32c(dres).view(-1, 512)
-        dx = torch.empty_like(xc)
-        dg, db = torch.empty(512, device=dy.device), torch.empty(512, device=dy.device)
-        scratch = torch.empty((rows + 15) // 16 * 1024, device=dy.device)
-        _lib.check(_lib.load().syn_ln_bwd(dyc.data_ptr(), xc.data_ptr(), gc.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _lib.ptr(add),
-                                          dx.data_ptr(), dg.data_ptr(), db.data_ptr(), scratch.data_ptr(), rows, _lib.current_stream(dx.device)),
-                   "syn_ln_bwd")
-        return dx.view(dy.shape), dg, db
-
-
-class HipLnForkFn(torch.autograd.Function):
-    """A pre-LN residual block's entry (transformer.py:195-198: x + f(norm(x))): returns (LayerNorm(x), x).  x feeds both the
-    norm and the residual add; the residual path's gradient goes into the LayerNorm backward kernel as its addend."""
-
-    @staticmethod
-    def forward(ctx, x, g, b):
-        y = HipLayerNormFn.forward(ctx, x, g, b)
-        return y, x.view_as(x)
-
-    @staticmethod
-    def backward(ctx, dy, dres):
-        return HipLayerNormFn._bwd(ctx, dy, dres)
-
-
-class HipGeluFn(torch.autograd.Function):
-    """nn.GELU() (exact erf form)."""
-
-    @staticmethod
-    def forward(ctx, x):
-        engine._require_cuda(x, "GELU input")
-        xc = _f32c(x)
-        y = torch.empty_like(xc)
-        _lib.check(_lib.load().syn_gelu_fwd(xc.data_ptr(), y.data_ptr(), None, xc.numel(), _lib.current_stream(y.device)), "syn_gelu_fwd")
-        ctx.save_for_backward(xc)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        xc, = ctx.saved_tensors
-        dyc = _f32c(dy)
-        dx = torch.empty_like(xc)
-        _lib.check(_lib.load().syn_gelu_bwd(xc.data_ptr(), dyc.data_ptr(), dx.data_ptr(), xc.numel(), _lib.current_stream(dx.device)), "syn_gelu_bwd")
-        return dx
-
-
-class HipAttentionFn(torch.autograd.Function):
-    """softmax(q k^T / sqrt(128)) v for 4 heads x 128 dims over 32 tokens, on the packed (B, 32, 1536) output of the qkv Linear
-    (models/timm_transformer/transformer.py:83-104; no mask, attention dropout 0)."""
-
-    @staticmethod
-    def forward(ctx, qkv):
-        engine._require_cuda(qkv, "attention input")
-        q = _f32c(qkv)
-        bs, T, _ = q.shape
-        assert T == 32 and q.shape[2] == 1536, q.shape
-        o = torch.empty(bs, T, 512, device=q.device)
-        _lib.check(_lib.load().syn_attn_fwd(q.data_ptr(), o.data_ptr(), None, bs, _lib.current_stream(o.device)), "syn_attn_fwd")
-        ctx.save_for_backward(q)
-        return o
-
-    @staticmethod
-    def backward(ctx, do):
-        q, = ctx.saved_tensors
-        doc = _f32c(do)
-        dqkv = torch.empty_like(q)
-        _lib.check(_lib.load().syn_attn_bwd(q.data_ptr(), doc.data_ptr(), dqkv.data_ptr(), q.shape[0], _lib.current_stream(dqkv.device)), "syn_attn_bwd")
-        return dqkv
-
-
 # ---- a pre-LN residual branch as ONE autograd node ---------------------------------------------------------------------------
 # x + drop_path(attn(norm1(x))) and x + drop_path(mlp(norm2(x))) (timm_transformer/transformer.py:195-198):
 #   forward   LayerNorm -> bf16 rows | GEMM (+ x^T pack; fc1: + GELU -> bf16) | attention -> bf16 | GEMM with `x + factor * (.)` in its epilogue
@@ -901,6 +803,21 @@ def _conv_terms_done():
         _lib.load().syn_debug_conv_terms(-1)
 
 
+def _conv_pack_of(w, cout, cin, stride, transposed):
+    """hi / lo fragment sets of a Conv1d(k 15) weight (cout, cin, [1,] 15): the step's pack, or packed on the spot."""
+    pk = _lookup_conv_pack(w, transposed)
+    if pk is not None:
+        return pk
+    lib = _lib.load()
+    wc = w.detach().float().contiguous()
+    nb = lib.syn_conv1d_pack_bytes(cout, cin, stride, int(bool(transposed)))
+    whi = torch.empty(nb, dtype=torch.uint8, device=w.device)
+    wlo = torch.empty_like(whi)
+    _lib.check(lib.syn_conv1d_pack_split(wc.data_ptr(), cout, cin, stride, int(bool(transposed)), whi.data_ptr(), wlo.data_ptr(), _lib.current_stream(w.device)),
+               "syn_conv1d_pack_split")
+    return whi, wlo
+
+
 class ConvSplitFn(torch.autograd.Function):
     """(N, C, 1, L) channels_last convolution of the audio encoder, forward on the hand-written implicit-GEMM kernel with
     operands split into bf16 hi + lo halves (`syn_conv1d_train_fwd`: three MFMAs per product, fp32-grade - the plain bf16
@@ -921,15 +838,7 @@ class ConvSplitFn(torch.autograd.Function):
         cin, cout = (co_w, ci_w) if transposed else (ci_w, co_w)
         assert cx == cin, (x.shape, w.shape, transposed)
         xc = x.contiguous(memory_format=torch.channels_last)                # physically [n][l][cin]
-        pk = _lookup_conv_pack(w, transposed)
-        if pk is not None:
-            whi, wlo = pk
-        else:
-            kts = -(-15 // stride) * stride
-            whi = torch.empty(cout * kts * cin * 2, dtype=torch.uint8, device=x.device)
-            wlo = torch.empty_like(whi)
-            _lib.check(lib.syn_conv1d_pack_split(wc.data_ptr(), co_w, ci_w, stride, int(transposed), whi.data_ptr(), wlo.data_ptr(),
-                                                 _lib.current_stream(x.device)), "syn_conv1d_pack_split")
+        whi, wlo = _conv_pack_of(w, co_w, ci_w, stride, transposed)
         l_out = (l_in + 2 * pad - 15) // stride + 1
         y = torch.empty(n, cout, 1, l_out, device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         part = None
@@ -967,23 +876,14 @@ class ConvSplitFn(torch.autograd.Function):
                 gx = ConvSplitFn.run(gy, w, 1, 7, transposed=True)[1]
             elif pad == 0 and (cout, stride) in ((64, 6), (128, 6), (256, 3)) and (stride * cin) % 128 == 0:
                 # a strided convolution's data gradient = a stride-1 convolution over dy whose output rows are `stride` consecutive
-                # positions x cin channels (three 128-column launches of the forward kernel)
+                # positions x cin channels (the forward kernel, all stride x cin columns in one launch)
                 lib = _lib.load()
                 n, _, _, l_in = x.shape
-                pk = _lookup_conv_pack(w, True)
-                if pk is not None:
-                    whi, wlo = pk
-                else:
-                    wc = w.detach().float().contiguous()
-                    nb = lib.syn_conv1d_pack_bytes(cout, cin, stride, 1)
-                    whi = torch.empty(nb, dtype=torch.uint8, device=x.device)
-                    wlo = torch.empty_like(whi)
-                    _lib.check(lib.syn_conv1d_pack_split(wc.data_ptr(), cout, cin, stride, 1, whi.data_ptr(), wlo.data_ptr(),
-                                                         _lib.current_stream(x.device)), "syn_conv1d_pack_split")
+                whi, wlo = _conv_pack_of(w, cout, cin, stride, True)
                 gx = torch.empty(n, cin, 1, l_in, device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
                 _conv_terms(1)
-                _lib.check(lib.syn_conv1d_train_dgrad_strided(gy.data_ptr(), n, l_in, cin, stride, cout, whi.data_ptr(), wlo.data_ptr(),
-                                                              gx.data_ptr(), _lib.current_stream(x.device)), "syn_conv1d_train_dgrad_strided")
+                _lib.check(lib.syn_conv1d_train_dgrad_sum(gy.data_ptr(), whi.data_ptr(), wlo.data_ptr(), None, None, None, None, n, l_in, cin, stride, 0, cout,
+                                                          gx.data_ptr(), _lib.current_stream(x.device)), "syn_conv1d_train_dgrad_sum")
                 _conv_terms_done()
             else:
                 raise _unsupported_conv("data gradient", cin, stride, pad, cout)
@@ -1272,19 +1172,7 @@ def _wb_conv_fwd(x3, conv, first, in_aff=None, in_act=0):
 
 
 def _wb_pack(conv, transposed):
-    """hi / lo fragment sets of a Conv1d(k 15) weight: the step's pack, or packed on the spot."""
-    pk = _lookup_conv_pack(conv.weight, transposed)
-    if pk is not None:
-        return pk
-    lib = _lib.load()
-    w = conv.weight.detach()
-    cout, cin, stride = conv.out_channels, conv.in_channels, conv.stride[0]
-    nb = lib.syn_conv1d_pack_bytes(cout, cin, stride, int(transposed))
-    whi = torch.empty(nb, dtype=torch.uint8, device=w.device)
-    wlo = torch.empty_like(whi)
-    _lib.check(lib.syn_conv1d_pack_split(w.data_ptr(), cout, cin, stride, int(transposed), whi.data_ptr(), wlo.data_ptr(), _lib.current_stream(w.device)),
-               "syn_conv1d_pack_split")
-    return whi, wlo
+    return _conv_pack_of(conv.weight, conv.out_channels, conv.in_channels, conv.stride[0], transposed)
 
 
 def _wb_finalize(part, chunks, rows, bn, conv_bias):

@@ -71,3 +71,17 @@ def synth_state_dict(variant="beatx", seed=0):
     sd["sequence_pos_encoder.pe"] = sd["embed_timestep.sequence_pos_encoder.pe"]
     sd["rel_pos.inv_freq"] = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))   # denoiser.py:327
     return sd
+
+
+def wav_features(blocks, wav):
+    """The BN-folded WavEncoder (syntalker_amd.conditioning.fold_wav_encoder's blocks) as plain PyTorch convolutions: what the HIP encoder
+    (syn_wav_encode) is checked against.  wav (B, L, 2) or (B, L) -> (B, 128, 256)  (models/denoiser.py:304-322, models/utils/layer.py:144-184)."""
+    import torch.nn.functional as F
+    x = wav.unsqueeze(1) if wav.dim() == 2 else wav.transpose(1, 2)
+    for blk in blocks:
+        z = F.leaky_relu(F.conv1d(x, *blk["c1"], stride=blk["stride"], padding=blk["pad"]), 0.01)
+        z = F.conv1d(z, *blk["c2"], padding=7)
+        if blk["sc"] is not None:
+            x = F.conv1d(x, *blk["sc"], stride=blk["stride"], padding=blk["pad"])
+        x = F.leaky_relu(z + x, 0.01)
+    return x.transpose(1, 2)

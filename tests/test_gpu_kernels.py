@@ -3,6 +3,7 @@ bf16-rounded operands.  Asymmetric random data so a transposed MFMA fragment can
 import pytest
 import torch
 
+from tests import block_ops, refmodel
 from tests.conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -278,7 +279,7 @@ def test_wav_encoder_vs_torch(B, L):
     blocks = conditioning.fold_wav_encoder(sd)
     g = torch.Generator().manual_seed(L)
     wav = torch.randn(B, L, 2, generator=g)
-    want = conditioning.wav_features(blocks, wav)
+    want = refmodel.wav_features(blocks, wav)
     enc = conditioning.HipWavEncoder(blocks, torch.device("cuda"))
     got = enc(wav.to("cuda")).cpu()
     assert got.shape == want.shape
@@ -306,7 +307,7 @@ def test_training_block_ops_vs_torch_autograd():
     x = (torch.randn(200, 512, generator=g) * 2 + 0.5).to(dev).requires_grad_()
     w, b = torch.randn(512, generator=g).to(dev).requires_grad_(), torch.randn(512, generator=g).to(dev).requires_grad_()
     up = torch.randn(200, 512, generator=g).to(dev)
-    y = training.HipLayerNormFn.apply(x, w, b)
+    y = block_ops.HipLayerNormFn.apply(x, w, b)
     gx, gw, gb = torch.autograd.grad(y, (x, w, b), up)
     yr = F.layer_norm(x, (512,), w, b, 1e-5)
     rx, rw, rb = torch.autograd.grad(yr, (x, w, b), up)
@@ -315,7 +316,7 @@ def test_training_block_ops_vs_torch_autograd():
     # GELU
     x = (torch.randn(64, 1024, generator=g) * 3).to(dev).requires_grad_()
     up = torch.randn(64, 1024, generator=g).to(dev)
-    y = training.HipGeluFn.apply(x)
+    y = block_ops.HipGeluFn.apply(x)
     gx, = torch.autograd.grad(y, x, up)
     yr = F.gelu(x)
     rx, = torch.autograd.grad(yr, x, up)
@@ -323,7 +324,7 @@ def test_training_block_ops_vs_torch_autograd():
     # attention on the packed qkv tensor
     qkv = torch.randn(5, 32, 1536, generator=g).to(dev).requires_grad_()
     up = torch.randn(5, 32, 512, generator=g).to(dev)
-    o = training.HipAttentionFn.apply(qkv)
+    o = block_ops.HipAttentionFn.apply(qkv)
     gq, = torch.autograd.grad(o, qkv, up)
     t = qkv.reshape(5, 32, 3, 4, 128).permute(2, 0, 3, 1, 4)
     orf = F.scaled_dot_product_attention(t[0], t[1], t[2]).transpose(1, 2).reshape(5, 32, 512)
@@ -365,11 +366,11 @@ def test_fused_residual_branches_equal_the_op_by_op_composition():
                         a = training.AttnBranchFn.apply(h, n1.weight, n1.bias, qkv.weight, qkv.bias, proj.weight, proj.bias, f[0])
                         out = training.MlpBranchFn.apply(a, n2.weight, n2.bias, fc1.weight, fc1.bias, fc2.weight, fc2.bias, f[1])
                     else:
-                        z, r = training.HipLnForkFn.apply(h, n1.weight, n1.bias)
-                        br = training.lin(training.HipAttentionFn.apply(training.lin(z, qkv)), proj)
+                        z, r = block_ops.HipLnForkFn.apply(h, n1.weight, n1.bias)
+                        br = training.lin(block_ops.HipAttentionFn.apply(training.lin(z, qkv)), proj)
                         a = r + br if f[0] is None else torch.addcmul(r, br, f[0])
-                        z, r = training.HipLnForkFn.apply(a, n2.weight, n2.bias)
-                        br = training.lin(training.HipGeluFn.apply(training.lin(z, fc1)), fc2)
+                        z, r = block_ops.HipLnForkFn.apply(a, n2.weight, n2.bias)
+                        br = training.lin(block_ops.HipGeluFn.apply(training.lin(z, fc1)), fc2)
                         out = r + br if f[1] is None else torch.addcmul(r, br, f[1])
                     res[fused] = [out.detach()] + list(torch.autograd.grad(out, [h] + params, up))
                 names = ["out", "dh"] + [f"{n}.{k}" for n, mod in zip(("n1", "n2", "qkv", "proj", "fc1", "fc2"), (n1, n2) + layers)
@@ -457,7 +458,7 @@ def test_wav_encoder_single_channel():
     sd = {"WavEncoder." + k: v for k, v in enc.state_dict().items()}
     blocks = conditioning.fold_wav_encoder(sd)
     wav = torch.randn(2, 30000, generator=torch.Generator().manual_seed(6))
-    want = conditioning.wav_features(blocks, wav)
+    want = refmodel.wav_features(blocks, wav)
     got = conditioning.HipWavEncoder(blocks, torch.device("cuda"))(wav.to("cuda")).cpu()
     assert got.shape == want.shape and rel_l2(got, want) < 2e-2
 
@@ -957,19 +958,15 @@ def test_persistent_block_stack_forward_backward_vs_torch_fp32(B, drop):
     assert e_out < 1.5e-2 and e_h < 3e-2 and worst[1] < 3e-2
 
 
-@pytest.mark.parametrize("cv", ["", "000000000", "222222222"])
-def test_training_convolution_decompositions_at_the_bench_shapes(cv):
-    """Every decomposition of the training-mode convolutions (`SYN_CV`, one digit per layer class: '' = the library's choice, 0 = 64 channels per wave -
-    the first version - and the alternative channel / position splits) at the bench shapes (32 clips: the 224-position tiles, the channel blocks on grid z,
-    the one-launch strided data gradients), forward with its BatchNorm partial sums and data gradient against torch's fp32 convolution.
-    `scripts/ubench_conv_variants.py` in a child process (the variant is read once per process)."""
+def test_training_convolutions_at_the_bench_shapes():
+    """The training-mode convolutions at the bench shapes (32 clips: the 224-position tiles, the channel blocks on grid z, the one-launch strided data
+    gradients), forward with its BatchNorm partial sums and data gradient against torch's fp32 convolution (`scripts/ubench_conv_variants.py`)."""
     import os
     import re
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SYN_CV=cv)
-    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "ubench_conv_variants.py"), "32"], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "ubench_conv_variants.py"), "32"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     rows = [l for l in out.stdout.splitlines() if " fwd " in l]
     assert len(rows) == 7, out.stdout

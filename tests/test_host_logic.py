@@ -15,6 +15,7 @@ from oracle.process_ref import RefProcess
 from syntalker_amd import checkpoint, conditioning, engine, guidance, process, resample, synth
 from syntalker_amd._lib import SynHipError
 from tests.conftest import REPO, rel_l2
+from tests import refmodel
 from tests.refmodel import state_spec, synth_state_dict
 
 
@@ -163,7 +164,7 @@ def test_folding_and_conditioning_equal_oracle(variant):
         # the fold behind the conditioning kernels (word path as a table, everything affine collapsed), evaluated on the host:
         # BN-folded convolutions -> folded tables -> cond
         audio, word = cc.audio_word_of(y, flags[1])
-        got = cc.weights.host_eval(conditioning.wav_features(cc.wav_blocks, audio), word, y["seed"], cc.style_of(y, flags[0], 2))
+        got = cc.weights.host_eval(refmodel.wav_features(cc.wav_blocks, audio), word, y["seed"], cc.style_of(y, flags[0], 2))
         assert rel_l2(got, want) < 5e-6, flags
         with pytest.raises(SynHipError):                # the product path itself has no CPU fallback
             cc.cond(y, *flags)
