@@ -227,6 +227,13 @@ typedef struct syn_conv_pack_req { const float* w; void* out_hi; void* out_lo; i
 int syn_conv1d_pack_split_many(const syn_conv_pack_req* reqs, int32_t n_reqs, void* stream);
 /* Bytes of each of syn_conv1d_pack_split's two outputs. */
 int64_t syn_conv1d_pack_bytes(int32_t cout, int32_t cin, int32_t stride, int32_t transposed);
+/* (ABI 8) syn_conv1d_train_wgrad / _wgrad_norm / syn_conv1d_first_wgrad / _wgrad_bn with dw = NULL leave their per-share partial sums in ws; this
+ * adds up to SYN_WGRAD_SUM_MAX such gradients up in ONE launch (the three convolutions of a BasicBlock), each in the order its own launch would have used.
+ * A job: part = that call's ws, dw = the module-layout gradient [cout][cin][15], the call's n_clips / cin / stride / cout and ITS l_out;
+ * first_layer != 0: the job is a syn_conv1d_first_wgrad* call (cin 1 | 2, cout 64). */
+#define SYN_WGRAD_SUM_MAX 4
+typedef struct syn_wgrad_sum_job { const float* part; float* dw; int32_t n_clips, l_out, cin, stride, cout, first_layer; } syn_wgrad_sum_job;
+int syn_conv1d_wgrad_sums(const syn_wgrad_sum_job* jobs, int32_t n_jobs, void* stream);
 /* (ABI 7) The data gradient that reaches a BasicBlock's input, written once: dx [n_clips][l_in][cin] = conv^T dy [+ conv2^T dy2] [+ residual].
  * Strided, unpadded layers (a down-sampling block: conv1 and the shortcut convolution share input and geometry): dy / dy2 [n_clips][l_out][cout] with their
  * transposed fragment sets, both accumulated in one launch instead of two tensors and an add; residual must be NULL.  Stride 1, padding 7 (a block with an
@@ -243,6 +250,12 @@ int32_t syn_conv1d_train_fwd_tiles(int32_t n_clips, int32_t l_in, int32_t cin, i
 /* (ABI 7) the stride-1 layers with the BatchNorm (+ LeakyReLU) of the convolution in front applied to the input as it is staged - x is that
  * convolution's raw output, the kernel reads act(x * in_affine[0][c] + in_affine[1][c]) (in_affine [2][cin] from syn_bn_finalize; in_act != 0:
  * LeakyReLU(0.01)), zero outside the clip; no bias.  The weight gradient with the same view of x. */
+/* (ABI 8) conv1 and the shortcut convolution of a down-sampling BasicBlock (models/utils/layer.py:150-158: the same input, stride, padding and
+ * width) as ONE launch: the input tile is staged (and split into its bf16 halves) once for both weight sets.  The encoder's strided layers only
+ * (64x6->64, 64x6->128, 128x3->256); y_a / y_b and the statistics as syn_conv1d_train_fwd's. */
+int syn_conv1d_train_fwd_pair(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, int32_t cout,
+                              const void* wa_hi, const void* wa_lo, float* y_a, float* bn_part_a,
+                              const void* wb_hi, const void* wb_lo, float* y_b, float* bn_part_b, void* stream);
 int syn_conv1d_train_fwd_norm(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
                               const void* w_hi, const void* w_lo, int32_t cout, const float* in_affine, int32_t in_act, float* y, float* bn_part,
                               void* stream);
@@ -356,6 +369,10 @@ int syn_bn_act_bwd_apply(const float* dz, const float* z, const float* y, const 
  * same way, syn_conv1d_train_wgrad_norm): in_affine [2][cin] = bn1's affine, in_act != 0: LeakyReLU(0.01); positions outside the clip stay zero. */
 int syn_bn_finalize(const float* part, int32_t chunks, int64_t rows, int32_t channels, const float* gamma, const float* beta, float eps, float momentum,
                     float* run_mean, float* run_var, const float* conv_bias, float* stats, float* affine, void* stream);
+/* (ABI 8) Two syn_bn_finalize calls as one launch: bn1 and the shortcut's BatchNorm of a down-sampling block, whose partial sums exist together. */
+typedef struct syn_bn_finalize_job { const float* part; int32_t chunks, channels; int64_t rows; const float* gamma; const float* beta; float eps, momentum;
+                                     float* run_mean; float* run_var; const float* conv_bias; float* stats; float* affine; } syn_bn_finalize_job;
+int syn_bn_finalize_pair(const syn_bn_finalize_job* a, const syn_bn_finalize_job* b, void* stream);
 int syn_bn_apply2(const float* y, const float* affine, const float* shortcut, const float* short_affine, int64_t rows, int32_t channels, int32_t act,
                   float* z, void* stream);
 int syn_bn_block_bwd(const float* dz, const float* y, const float* shortcut, const float* stats, const float* affine, const float* short_stats,

@@ -25,7 +25,7 @@ EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_ste
            "syn_conv1d_first_fwd_stats", "syn_test_mfma_rate", "syn_conv1d_train_dgrad_sum", "syn_conv1d_first_fwd2", "syn_conv1d_first_wgrad_bn",
            "syn_bn_bwd_stats", "syn_train_stack_fwd", "syn_train_stack_bwd", "syn_train_stack_wgrad",
            "syn_masked_smooth_l1_grad", "syn_rows_concat_bf16", "syn_embed_rows_bf16", "syn_bct_to_rows_bf16", "syn_rows_group_sum", "syn_rows_expand",
-           "syn_colsum_parts", "syn_touch")
+           "syn_colsum_parts", "syn_touch", "syn_conv1d_wgrad_sums", "syn_bn_finalize_pair", "syn_conv1d_train_fwd_pair")
 
 # the `void syn_debug_*` switches of the header's diagnostics section (process-wide, A/B runs and scripts/ only)
 DIAGNOSTICS = ("syn_debug_timing", "syn_debug_gemm_resident", "syn_debug_linear_tile", "syn_debug_conv_terms", "syn_debug_seq_skew", "syn_debug_seq_step")
@@ -84,6 +84,15 @@ class SynOptList(C.Structure):
 
 class SynConcatSrc(C.Structure):
     _fields_ = [("p", vp), ("p2", vp), ("width", i32), ("ld", i32), ("row_div", i32), ("pool", i32)]
+
+
+class SynWgradSumJob(C.Structure):
+    _fields_ = [("part", vp), ("dw", vp), ("n_clips", i32), ("l_out", i32), ("cin", i32), ("stride", i32), ("cout", i32), ("first_layer", i32)]
+
+
+class SynBnFinalizeJob(C.Structure):
+    _fields_ = [("part", vp), ("chunks", i32), ("channels", i32), ("rows", i64), ("gamma", vp), ("beta", vp), ("eps", C.c_float), ("momentum", C.c_float),
+                ("run_mean", vp), ("run_var", vp), ("conv_bias", vp), ("stats", vp), ("affine", vp)]
 
 
 class SynConvPackReq(C.Structure):
@@ -177,6 +186,9 @@ def load():
     lib.syn_rows_expand.argtypes = [vp, i32, i32, i32, C.c_float, i32, vp, vp]
     lib.syn_colsum_parts.argtypes = [vp, i32, i32, vp, vp]
     lib.syn_touch.argtypes = [vp, i64, vp]
+    lib.syn_conv1d_wgrad_sums.argtypes = [C.POINTER(SynWgradSumJob), i32, vp]
+    lib.syn_conv1d_train_fwd_pair.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.syn_bn_finalize_pair.argtypes = [C.POINTER(SynBnFinalizeJob), C.POINTER(SynBnFinalizeJob), vp]
     lib.syn_rotary.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.syn_axis_angle_to_rot6d.argtypes = [vp, i64, vp, vp]
     lib.syn_rot6d_to_axis_angle.argtypes = [vp, i64, vp, vp]

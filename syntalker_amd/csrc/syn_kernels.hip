@@ -1730,15 +1730,15 @@ int launch_conv_train_ks(const wav::TArgs& a0, int n_clips, hipStream_t s) {
 }
 
 // n_out: output channels this launch covers (a multiple of the instance's WN x NF x 16 channels per workgroup: grid z)
-template <int CINP, int KT, int WN, int WM, int RF, int NF = 4>
+template <int CINP, int KT, int WN, int WM, int RF, int NF = 4, bool DUAL = false>
 int launch_conv_train(const wav::TArgs& a0, int n_clips, hipStream_t s, int n_out = WN * NF * 16) {
     wav::TArgs a = a0; a.terms = conv_terms(false); a.dbg = g_dbg_attn;
     constexpr int MW = WM * RF * 16, lds = 2 * (MW + KT - 1) * (CINP * 2 + wav::kTrainPad), NT = WN * NF * 16;
     static_assert(lds <= 160 * 1024, "two bf16 planes of the input tile must fit the LDS");
     if (n_out % NT) return fail_msg("k_conv_train: the launch's channels are not a multiple of the instance's channel block");
     static OncePerDevice once;
-    if (once.first()) { allow_lds(wav::k_conv_train<CINP, KT, WN, WM, RF, NF>, lds); }
-    hipLaunchKernelGGL((wav::k_conv_train<CINP, KT, WN, WM, RF, NF>), dim3((a.L_out + MW - 1) / MW, n_clips, n_out / NT), dim3(WN * WM * 64), lds, s, a);
+    if (once.first()) { allow_lds(wav::k_conv_train<CINP, KT, WN, WM, RF, NF, DUAL>, lds); }
+    hipLaunchKernelGGL((wav::k_conv_train<CINP, KT, WN, WM, RF, NF, DUAL>), dim3((a.L_out + MW - 1) / MW, n_clips, n_out / NT), dim3(WN * WM * 64), lds, s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_train launch", e);
 }
@@ -2564,6 +2564,22 @@ int syn_bn_finalize(const float* part, int32_t chunks, int64_t rows, int32_t cha
     return e == hipSuccess ? 0 : fail("syn_bn_finalize", e);
 }
 
+int syn_bn_finalize_pair(const syn_bn_finalize_job* a, const syn_bn_finalize_job* b, void* stream) {
+    if (!a || !b) return fail_msg("syn_bn_finalize_pair: two jobs");
+    trn::FinJob j[2];
+    const syn_bn_finalize_job* q[2] = {a, b};
+    for (int i = 0; i < 2; ++i) {
+        if (!q[i]->part || q[i]->chunks <= 0 || !q[i]->gamma || !q[i]->beta || !q[i]->stats || !q[i]->affine || !bn_shape_ok(q[i]->rows, q[i]->channels))
+            return fail_msg("syn_bn_finalize_pair: bad arguments");
+        j[i].part = q[i]->part; j[i].chunks = q[i]->chunks; j[i].C = q[i]->channels; j[i].rows = (long)q[i]->rows; j[i].eps = q[i]->eps; j[i].momentum = q[i]->momentum;
+        j[i].gamma = q[i]->gamma; j[i].beta = q[i]->beta; j[i].stats = q[i]->stats; j[i].aff = q[i]->affine;
+        j[i].run_mean = q[i]->run_mean; j[i].run_var = q[i]->run_var; j[i].conv_bias = q[i]->conv_bias;
+    }
+    hipLaunchKernelGGL(trn::k_bn_finalize_aff2, dim3(j[0].C + j[1].C), dim3(256), 0, (hipStream_t)stream, j[0], j[1]);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("syn_bn_finalize_pair", e);
+}
+
 int syn_bn_apply2(const float* y, const float* affine, const float* shortcut, const float* short_affine, int64_t rows, int32_t channels, int32_t act,
                   float* z, void* stream) {
     if (!y || !affine || !z || !bn_shape_ok(rows, channels) || (short_affine && !shortcut)) return fail_msg("syn_bn_apply2: bad arguments");
@@ -2832,7 +2848,7 @@ int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows
 
 static int conv_train_wgrad_impl(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
                                  int32_t cout, const float* in_affine, int32_t in_act, float* ws, float* dw, void* stream) {
-    if (!x || !dy || !ws || !dw || n_clips <= 0 || l_in <= 0 || cin % 16 || stride < 1) return fail_msg("syn_conv1d_train_wgrad: bad arguments");
+    if (!x || !dy || !ws || n_clips <= 0 || l_in <= 0 || cin % 16 || stride < 1) return fail_msg("syn_conv1d_train_wgrad: bad arguments");
     if (in_affine && stride != 1) return fail_msg("syn_conv1d_train_wgrad_norm: the input affine is for the stride-1 layers (conv2 of a block)");
     if (!((stride == 1 && pad == 7) || (pad == 0 && stride * cin == 384 && (stride == 3 || stride == 6))))
         return fail_msg("syn_conv1d_train_wgrad: stride 1 with padding 7, or the encoder's unpadded strided layers (stride x cin = 384)");
@@ -2853,7 +2869,7 @@ static int conv_train_wgrad_impl(const float* x, const float* dy, int32_t n_clip
     else if (cout == 128 && taps == 3) rc = launch_wgrad_s<128, 3>(a, s);
     else if (cout == 256 && taps == 5) rc = launch_wgrad_s<64, 5>(a, s);     // (128-channel blocks spill: 20 accumulator tiles per wave is the limit)
     else return fail_msg("syn_conv1d_train_wgrad: 64 / 128 / 256 output channels; strided: (64 | 128, stride 6), (256, stride 3)");
-    if (rc) return rc;
+    if (rc || !dw) return rc;                                    // (dw NULL: the partial sums only - syn_conv1d_wgrad_sums adds several gradients' up in one launch)
     const int total4 = cout * taps * cinp / 4;                   // (cin % 16 == 0: four consecutive channels share r)
     hipLaunchKernelGGL(wav::k_conv_wgrad_sum, dim3((total4 + 31) / 32), dim3(256), 0, s, (const float*)ws, a.shares, cout, cin, stride, taps, dw);
     hipError_t e = hipGetLastError();
@@ -2916,7 +2932,7 @@ int syn_conv1d_first_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
 static int first_wgrad_impl(const float* x, const float* dy, const float* bn_y, const float* bn_stats, const float* bn_aff, const float* bn_dgb,
                             int32_t bn_act, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws, float* dw, void* stream) {
     wav::FArgs a;
-    if (!dy || !ws || !dw) return fail_msg("syn_conv1d_first_wgrad: bad arguments");
+    if (!dy || !ws) return fail_msg("syn_conv1d_first_wgrad: bad arguments");
     if (int rc = first_layer_args(a, x, n_clips, l_in, cin, stride, pad, "syn_conv1d_first_wgrad: bad arguments (cin 1 | 2, 64 output channels)")) return rc;
     a.DY = dy; a.part = ws;
     if (bn_y) {
@@ -2928,9 +2944,36 @@ static int first_wgrad_impl(const float* x, const float* dy, const float* bn_y, 
     if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_wgrad_m<1>, dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
     else hipLaunchKernelGGL(wav::k_conv_first_wgrad_m<2>, dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
     const int n = 64 * cin * 15;
-    hipLaunchKernelGGL(wav::k_conv_first_wsum, dim3((n + 63) / 64), dim3(1024), 0, s, (const float*)ws, groups, n, dw);
+    if (dw) hipLaunchKernelGGL(wav::k_conv_first_wsum, dim3((n + 63) / 64), dim3(1024), 0, s, (const float*)ws, groups, n, dw);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_first_wgrad_m launch", e);
+}
+
+int syn_conv1d_wgrad_sums(const syn_wgrad_sum_job* jobs, int32_t n_jobs, void* stream) {
+    static_assert(SYN_WGRAD_SUM_MAX == wav::kWsumJobs, "include/syn_hip.h: jobs per syn_conv1d_wgrad_sums call");
+    if (!jobs || n_jobs < 1 || n_jobs > SYN_WGRAD_SUM_MAX) return fail_msg("syn_conv1d_wgrad_sums: 1 .. 4 jobs");
+    wav::WSumJobs a;
+    memset(&a, 0, sizeof(a));
+    int blocks = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const syn_wgrad_sum_job& q = jobs[i];
+        wav::WSumJob& J = a.j[i];
+        if (!q.part || !q.dw || q.n_clips <= 0 || q.l_out <= 0) return fail_msg("syn_conv1d_wgrad_sums: null pointer / empty job");
+        J.part = q.part; J.dw = q.dw; J.cin = q.cin; J.stride = q.stride; J.co_n = q.cout; J.first_block = blocks;
+        if (q.first_layer) {
+            if ((q.cin != 1 && q.cin != 2) || q.cout != 64) return fail_msg("syn_conv1d_wgrad_sums: a first-layer job has 1 | 2 input and 64 output channels");
+            J.kind = 1; J.shares = first_wgrad_groups(q.n_clips, q.l_out); J.per = 64 * q.cin * 15; J.taps = 15;
+        } else {
+            if (q.cin % 16 || q.stride < 1) return fail_msg("syn_conv1d_wgrad_sums: cin must be a multiple of 16");
+            J.kind = 0; J.taps = (15 + q.stride - 1) / q.stride; J.shares = syn_conv1d_wgrad_shares(q.n_clips, q.l_out, q.stride * q.cin);
+            J.per = q.cout * J.taps * q.stride * q.cin;
+        }
+        blocks += (J.per / 4 + 31) / 32;
+    }
+    a.n = n_jobs;
+    hipLaunchKernelGGL(wav::k_conv_wgrad_sums, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv_wgrad_sums launch", e);
 }
 
 int syn_conv1d_first_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws,
@@ -3074,9 +3117,11 @@ int32_t syn_conv1d_train_fwd_tiles(int32_t n_clips, int32_t l_in, int32_t cin, i
     return mw ? n_clips * ((l_out + mw - 1) / mw) : 0;
 }
 
+struct ConvDual { const void* w_hi; const void* w_lo; float* y; float* bn_part; };     // a second convolution of the same geometry on the same input
+
 static int conv_train_fwd_impl(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
                                const void* w_hi, const void* w_lo, const float* bias, int32_t cout, const float* in_affine, int32_t in_act,
-                               float* y, float* bn_part, void* stream, const float* residual = nullptr) {
+                               float* y, float* bn_part, void* stream, const float* residual = nullptr, const ConvDual* dual = nullptr) {
     if (residual && !(stride == 1 && cin * stride != 384)) return fail_msg("syn_conv1d_train_dgrad_sum: the residual rides the stride-1 kernel");
     if (!x || !w_hi || !w_lo || !y || n_clips <= 0 || l_in <= 0) return fail_msg("syn_conv1d_train_fwd: null pointer / empty batch");
     if (in_affine && stride != 1) return fail_msg("syn_conv1d_train_fwd_norm: the input affine is for the stride-1 layers (conv2 of a block)");
@@ -3089,6 +3134,12 @@ static int conv_train_fwd_impl(const float* x, int32_t n_clips, int32_t l_in, in
     a.y_pitch = 0; a.y_col0 = 0; a.y_elems = 0; a.bn_part = bn_part;
     a.in_aff = in_affine; a.in_act = in_act;
     a.X2 = nullptr; a.Whi2 = a.Wlo2 = nullptr; a.R = residual;
+    a.WhiB = a.WloB = nullptr; a.YB = nullptr; a.bn_partB = nullptr;
+    if (dual) {
+        if (stride == 1 || bias || !dual->w_hi || !dual->w_lo || !dual->y || ((dual->bn_part == nullptr) != (bn_part == nullptr)))
+            return fail_msg("syn_conv1d_train_fwd_pair: the encoder's strided layers, no bias, both or neither with statistics");
+        a.WhiB = (const uint4*)dual->w_hi; a.WloB = (const uint4*)dual->w_lo; a.YB = dual->y; a.bn_partB = dual->bn_part;
+    }
     if (bn_part && bias) return fail_msg("syn_conv1d_train_fwd: the statistics are those of the convolution without its bias (pass bias = NULL)");
     hipStream_t s = (hipStream_t)stream;
     const int cinp = stride * cin;
@@ -3100,15 +3151,29 @@ static int conv_train_fwd_impl(const float* x, int32_t n_clips, int32_t l_in, in
                                                                          : launch_conv_train<64, 15, 2, 2, 4, 2>(a, n_clips, s, 64);
     if (cinp == 128 && stride == 1 && cout == 128) return launch_conv_train<128, 15, 4, 1, 4, 1>(a, n_clips, s, 128);   // 64 positions x 64 channels per workgroup (z: 2), a wave: 16 channels x 64 positions
     if (cinp == 256 && stride == 1 && cout == 256) return launch_conv_train<256, 15, 4, 1, 2, 1>(a, n_clips, s, 256);   // 32 positions x 64 channels (z: 4)
-    if (cinp == 384 && stride == 6 && cout == 64) return launch_conv_train_ks<384, 3, kKsRf>(a, n_clips, s);            // the four waves split K
-    if (cinp == 384 && stride == 6 && cout == 128) return launch_conv_train<384, 3, 2, 2, 2>(a, n_clips, s);            // 64-position tiles
-    if (cinp == 384 && stride == 3 && cout == 256) return launch_conv_train<384, 5, 4, 1, 2, 1>(a, n_clips, s, 256);    // 32 positions x 64 channels (z: 4)
+    if (cinp == 384 && stride == 6 && cout == 64) {            // the four waves split K
+        // (a pair goes out as two launches: on this kernel - 48-position tiles, bound by its fixed costs, not by staging - sharing the tile measured
+        //  145 us against 2 x 66)
+        if (int rc = launch_conv_train_ks<384, 3, kKsRf>(a, n_clips, s)) return rc;
+        if (!dual) return 0;
+        a.Whi = a.WhiB; a.Wlo = a.WloB; a.Y = a.YB; a.bn_part = a.bn_partB;
+        return launch_conv_train_ks<384, 3, kKsRf>(a, n_clips, s);
+    }
+    if (cinp == 384 && stride == 6 && cout == 128) return dual ? launch_conv_train<384, 3, 2, 2, 2, 4, true>(a, n_clips, s) : launch_conv_train<384, 3, 2, 2, 2>(a, n_clips, s);   // 64-position tiles
+    if (cinp == 384 && stride == 3 && cout == 256) return dual ? launch_conv_train<384, 5, 4, 1, 2, 1, true>(a, n_clips, s, 256) : launch_conv_train<384, 5, 4, 1, 2, 1>(a, n_clips, s, 256);   // 32 positions x 64 channels (z: 4)
     return fail_msg("syn_conv1d_train_fwd: not one of the WavEncoder's convolutions (cin x stride -> cout: 64x1->64, 128x1->128, 256x1->256, 64x6->64, 64x6->128, 128x3->256)");
 }
 
 int syn_conv1d_train_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
                          const void* w_hi, const void* w_lo, const float* bias, int32_t cout, float* y, float* bn_part, void* stream) {
     return conv_train_fwd_impl(x, n_clips, l_in, cin, stride, pad, w_hi, w_lo, bias, cout, nullptr, 0, y, bn_part, stream);
+}
+
+int syn_conv1d_train_fwd_pair(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, int32_t cout,
+                              const void* wa_hi, const void* wa_lo, float* y_a, float* bn_part_a,
+                              const void* wb_hi, const void* wb_lo, float* y_b, float* bn_part_b, void* stream) {
+    const ConvDual d{wb_hi, wb_lo, y_b, bn_part_b};
+    return conv_train_fwd_impl(x, n_clips, l_in, cin, stride, pad, wa_hi, wa_lo, nullptr, cout, nullptr, 0, y_a, bn_part_a, stream, nullptr, &d);
 }
 
 int syn_conv1d_train_fwd_norm(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,

@@ -1171,21 +1171,54 @@ def _wb_conv_fwd(x3, conv, first, in_aff=None, in_act=0):
     return y, part, chunks
 
 
+def _wb_conv_fwd_pair(x3, conv_a, conv_b):
+    """conv1 and the shortcut convolution of a down-sampling block - the same input and geometry - as one launch (`syn_conv1d_train_fwd_pair`: the
+    input tile is staged once): -> (y_a, part_a, y_b, part_b, chunks)."""
+    lib, dev = _lib.load(), x3.device
+    n, l_in, cin = x3.shape
+    stride, pad, cout = conv_a.stride[0], conv_a.padding[0], conv_a.out_channels
+    l_out = (l_in + 2 * pad - 15) // stride + 1
+    chunks = lib.syn_conv1d_train_fwd_tiles(n, l_in, cin, stride, pad, cout)
+    ya, yb = (torch.empty(n, l_out, cout, device=dev, dtype=torch.float32) for _ in range(2))
+    pa, pb = (torch.empty(chunks, 2, cout, device=dev, dtype=torch.float32) for _ in range(2))
+    (ah, al), (bh, bl) = _wb_pack(conv_a, False), _wb_pack(conv_b, False)
+    _conv_terms(0)
+    _lib.check(lib.syn_conv1d_train_fwd_pair(x3.data_ptr(), n, l_in, cin, stride, pad, cout, ah.data_ptr(), al.data_ptr(), ya.data_ptr(), pa.data_ptr(),
+                                             bh.data_ptr(), bl.data_ptr(), yb.data_ptr(), pb.data_ptr(), _lib.current_stream(dev)), "syn_conv1d_train_fwd_pair")
+    _conv_terms_done()
+    return ya, pa, yb, pb, chunks
+
+
 def _wb_pack(conv, transposed):
     return _conv_pack_of(conv.weight, conv.out_channels, conv.in_channels, conv.stride[0], transposed)
 
 
-def _wb_finalize(part, chunks, rows, bn, conv_bias):
-    c = bn.num_features
-    stats = torch.empty(2, c, device=part.device, dtype=torch.float32)
-    aff = torch.empty(2, c, device=part.device, dtype=torch.float32)
-    cb = None if conv_bias is None else conv_bias.detach()
-    _lib.check(_lib.load().syn_bn_finalize(part.data_ptr(), chunks, rows, c, bn.weight.detach().data_ptr(), bn.bias.detach().data_ptr(), float(bn.eps),
-                                           float(bn.momentum), _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), _lib.ptr(cb), stats.data_ptr(),
-                                           aff.data_ptr(), _lib.current_stream(part.device)), "syn_bn_finalize")
-    if bn.num_batches_tracked is not None:
-        _tracked.append(bn.num_batches_tracked)
-    return stats, aff
+def _wb_finalize(part, chunks, rows, bn, conv_bias, pair=None):
+    """Per-channel sums -> (mean, rstd) and the affine (scale, shift) of a batch-statistics BatchNorm, running statistics updated (`syn_bn_finalize`).
+    pair: a second (part, chunks, bn, conv_bias) of the same rows finalised by the same launch -> both results."""
+    dev = part.device
+    jobs, outs = [], []
+    for pt, ch, b, cb in [(part, chunks, bn, conv_bias)] + ([pair] if pair is not None else []):
+        c = b.num_features
+        stats, aff = torch.empty(2, c, device=dev, dtype=torch.float32), torch.empty(2, c, device=dev, dtype=torch.float32)
+        jobs.append((pt, ch, c, b, None if cb is None else cb.detach(), stats, aff))
+        outs.append((stats, aff))
+        if b.num_batches_tracked is not None:
+            _tracked.append(b.num_batches_tracked)
+    lib, st = _lib.load(), _lib.current_stream(dev)
+    if pair is None:
+        pt, ch, c, b, cb, stats, aff = jobs[0]
+        _lib.check(lib.syn_bn_finalize(pt.data_ptr(), ch, rows, c, b.weight.detach().data_ptr(), b.bias.detach().data_ptr(), float(b.eps), float(b.momentum),
+                                       _lib.ptr(b.running_mean), _lib.ptr(b.running_var), _lib.ptr(cb), stats.data_ptr(), aff.data_ptr(), st), "syn_bn_finalize")
+        return outs[0]
+    arr = []
+    for pt, ch, c, b, cb, stats, aff in jobs:
+        j = _lib.SynBnFinalizeJob()
+        j.part, j.chunks, j.channels, j.rows, j.gamma, j.beta, j.eps, j.momentum = pt.data_ptr(), ch, c, rows, b.weight.detach().data_ptr(), b.bias.detach().data_ptr(), float(b.eps), float(b.momentum)
+        j.run_mean, j.run_var, j.conv_bias, j.stats, j.affine = _lib.ptr(b.running_mean), _lib.ptr(b.running_var), _lib.ptr(cb), stats.data_ptr(), aff.data_ptr()
+        arr.append(j)
+    _lib.check(lib.syn_bn_finalize_pair(C.byref(arr[0]), C.byref(arr[1]), st), "syn_bn_finalize_pair")
+    return outs[0], outs[1]
 
 
 def _wb_dgrad(dy3, conv, l_in, dy3b=None, conv_b=None, residual=None):
@@ -1212,30 +1245,43 @@ def _wb_dgrad(dy3, conv, l_in, dy3b=None, conv_b=None, residual=None):
     return dx
 
 
-def _wb_wgrad(x3, dy3, conv, first, in_aff=None, in_act=0):
-    """Weight gradient (Cout, Cin, 15) of `conv` from its input x (N, L_in, Cin) and dy (N, L_out, Cout)."""
+def _wb_wgrad(x3, dy3, conv, first, in_aff=None, in_act=0, sums=None):
+    """Weight gradient (Cout, Cin, 15) of `conv` from its input x (N, L_in, Cin) and dy (N, L_out, Cout).  With `sums` (a list) the launch leaves its
+    partial sums and the job is appended: `_wb_wgrad_sums` adds up all of a block's gradients in one launch."""
     lib, dev = _lib.load(), x3.device
     n, l_in, cin = x3.shape
     stride, pad, cout = conv.stride[0], conv.padding[0], conv.out_channels
     l_out = dy3.shape[1]
     gw = _grad_out(conv.weight, (cout, cin, 15))
     st = _lib.current_stream(dev)
+    target = None if sums is not None else gw.data_ptr()
     if first:
         ws = torch.empty(lib.syn_conv1d_first_parts(n, l_out) * 64 * cin * 15, device=dev, dtype=torch.float32)
-        _lib.check(lib.syn_conv1d_first_wgrad(x3.data_ptr(), dy3.data_ptr(), n, l_in, cin, stride, pad, ws.data_ptr(), gw.data_ptr(), st),
-                   "syn_conv1d_first_wgrad")
-        return gw
-    kts = -(-15 // stride) * stride
-    ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l_out, stride * cin) * cout * kts * cin, device=dev, dtype=torch.float32)
-    _conv_terms(2)
-    if in_aff is None:
-        _lib.check(lib.syn_conv1d_train_wgrad(x3.data_ptr(), dy3.data_ptr(), n, l_in, cin, stride, pad, cout, ws.data_ptr(), gw.data_ptr(), st),
-                   "syn_conv1d_train_wgrad")
+        _lib.check(lib.syn_conv1d_first_wgrad(x3.data_ptr(), dy3.data_ptr(), n, l_in, cin, stride, pad, ws.data_ptr(), target, st), "syn_conv1d_first_wgrad")
     else:
-        _lib.check(lib.syn_conv1d_train_wgrad_norm(x3.data_ptr(), dy3.data_ptr(), n, l_in, cin, stride, pad, cout, in_aff.data_ptr(), int(in_act),
-                                                   ws.data_ptr(), gw.data_ptr(), st), "syn_conv1d_train_wgrad_norm")
-    _conv_terms_done()
+        kts = -(-15 // stride) * stride
+        ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l_out, stride * cin) * cout * kts * cin, device=dev, dtype=torch.float32)
+        _conv_terms(2)
+        if in_aff is None:
+            _lib.check(lib.syn_conv1d_train_wgrad(x3.data_ptr(), dy3.data_ptr(), n, l_in, cin, stride, pad, cout, ws.data_ptr(), target, st), "syn_conv1d_train_wgrad")
+        else:
+            _lib.check(lib.syn_conv1d_train_wgrad_norm(x3.data_ptr(), dy3.data_ptr(), n, l_in, cin, stride, pad, cout, in_aff.data_ptr(), int(in_act),
+                                                       ws.data_ptr(), target, st), "syn_conv1d_train_wgrad_norm")
+        _conv_terms_done()
+    if sums is not None:
+        sums.append((ws, gw, n, l_out, cin, stride, cout, int(bool(first))))
     return gw
+
+
+def _wb_wgrad_sums(sums, device):
+    """The partial-sum reductions of a block's weight gradients as one launch (`syn_conv1d_wgrad_sums`)."""
+    if not sums:
+        return
+    arr = (_lib.SynWgradSumJob * len(sums))()
+    for i, (ws, gw, n, l_out, cin, stride, cout, first) in enumerate(sums):
+        arr[i].part, arr[i].dw, arr[i].n_clips, arr[i].l_out, arr[i].cin, arr[i].stride, arr[i].cout, arr[i].first_layer = ws.data_ptr(), gw.data_ptr(), n, l_out, cin, stride, cout, first
+    _lib.check(_lib.load().syn_conv1d_wgrad_sums(arr, len(sums), _lib.current_stream(device)), "syn_conv1d_wgrad_sums")
+    sums.clear()
 
 
 class WavBlockFn(torch.autograd.Function):
@@ -1262,14 +1308,16 @@ class WavBlockFn(torch.autograd.Function):
             _lib.check(lib.syn_conv1d_first_fwd2(x3.data_ptr(), n, l_in, cin, c0.stride[0], c0.padding[0], c0.weight.detach().data_ptr(),
                                                  c1m.weight.detach().data_ptr(), y1.data_ptr(), ysc.data_ptr(), p1.data_ptr(), ps.data_ptr(),
                                                  _lib.current_stream(x3.device)), "syn_conv1d_first_fwd2")
+        elif ds:
+            y1, p1, ysc, ps, c1 = _wb_conv_fwd_pair(x3, blk.conv1, blk.downsample[0])
+            cs = c1
         else:
             y1, p1, c1 = _wb_conv_fwd(x3, blk.conv1, first)
-            if ds:
-                ysc, ps, cs = _wb_conv_fwd(x3, blk.downsample[0], first)
         rows = n * y1.shape[1]
-        st1, af1 = _wb_finalize(p1, c1, rows, blk.bn1, blk.conv1.bias)
         if ds:
-            sts, afs = _wb_finalize(ps, cs, rows, blk.downsample[1], blk.downsample[0].bias)
+            (st1, af1), (sts, afs) = _wb_finalize(p1, c1, rows, blk.bn1, blk.conv1.bias, pair=(ps, cs, blk.downsample[1], blk.downsample[0].bias))
+        else:
+            st1, af1 = _wb_finalize(p1, c1, rows, blk.bn1, blk.conv1.bias)
         y2, p2, c2 = _wb_conv_fwd(y1, blk.conv2, False, in_aff=af1, in_act=1)
         st2, af2 = _wb_finalize(p2, c2, rows, blk.bn2, blk.conv2.bias)
         c = y2.shape[2]
@@ -1303,7 +1351,8 @@ class WavBlockFn(torch.autograd.Function):
                                         _lib.current_stream(dev)), "syn_bn_block_bwd")
         # conv2: data gradient to z1 = act(bn1(y1)), weight gradient with z1 recomputed from y1 while its rows are staged
         dz1 = _wb_dgrad(dy2, blk.conv2, l1)
-        gw2 = _wb_wgrad(y1, dy2, blk.conv2, False, in_aff=af1, in_act=1)
+        sums = []
+        gw2 = _wb_wgrad(y1, dy2, blk.conv2, False, in_aff=af1, in_act=1, sums=sums)
         # bn1 + activation (no shortcut entered it: the sign comes from y1)
         ws1 = torch.empty(2 * lib.syn_bn_chunks(rows) * c, device=dev, dtype=torch.float32)
         dgb1 = torch.empty(3, c, device=dev, dtype=torch.float32)
@@ -1317,14 +1366,15 @@ class WavBlockFn(torch.autograd.Function):
             wsg = torch.empty(lib.syn_conv1d_first_parts(nn_, l1) * 64 * cin * 15, device=dev, dtype=torch.float32)
             gw1 = _grad_out(cv.weight, (64, cin, 15))
             _lib.check(lib.syn_conv1d_first_wgrad_bn(x3.data_ptr(), dz1.data_ptr(), y1.data_ptr(), st1.data_ptr(), af1.data_ptr(), dgb1.data_ptr(), 1,
-                                                     nn_, l_in, cin, cv.stride[0], cv.padding[0], wsg.data_ptr(), gw1.data_ptr(), _lib.current_stream(dev)),
+                                                     nn_, l_in, cin, cv.stride[0], cv.padding[0], wsg.data_ptr(), None, _lib.current_stream(dev)),
                        "syn_conv1d_first_wgrad_bn")
+            sums.append((wsg, gw1, nn_, l1, cin, cv.stride[0], 64, 1))
             dy1 = None
         else:
             dy1 = torch.empty_like(y1)
             _lib.check(lib.syn_bn_act_bwd(dz1.data_ptr(), None, y1.data_ptr(), st1.data_ptr(), g1.data_ptr(), b1.data_ptr(), rows, c, 1, ws1.data_ptr(),
                                           dgb1.data_ptr(), dy1.data_ptr(), None, _lib.current_stream(dev)), "syn_bn_act_bwd")
-            gw1 = _wb_wgrad(x3, dy1, blk.conv1, first)
+            gw1 = _wb_wgrad(x3, dy1, blk.conv1, first, sums=sums)
         dx = None
         if not first and ctx.needs_input_grad[0]:
             # what reaches the block's input, written once: conv1^T dy1 + (shortcut^T dy_sc | the gradient along the identity shortcut)
@@ -1334,9 +1384,10 @@ class WavBlockFn(torch.autograd.Function):
                  gw2, dgb2[2] if blk.conv2.bias is not None else None, dgb2[0], dgb2[1]]
         owners = [None, blk.conv1.bias, blk.bn1.weight, blk.bn1.bias, None, blk.conv2.bias, blk.bn2.weight, blk.bn2.bias]
         if ds:
-            gws = _wb_wgrad(x3, dsh, blk.downsample[0], first)
+            gws = _wb_wgrad(x3, dsh, blk.downsample[0], first, sums=sums)
             grads += [gws, dgbs[2] if blk.downsample[0].bias is not None else None, dgbs[0], dgbs[1]]
             owners += [None, blk.downsample[0].bias, blk.downsample[1].weight, blk.downsample[1].bias]
+        _wb_wgrad_sums(sums, dev)                              # the block's weight gradients: their partial sums added up in one launch
         _into_bound_buffers(grads, owners)
         return (None if dx is None else _as4(dx), None, None, *grads)
 
