@@ -537,6 +537,40 @@ def test_train_mode_loss_gradients_and_bn_buffers_vs_golden(golden):
     assert float(params["WavEncoder.feat_extractor.1.conv1.bias"].grad.abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("variant,B", [("beatx", 5), ("h3d", 3), ("beatx", 1)])
+def test_training_step_at_batch_sizes_that_are_not_multiples_of_four(variant, B):
+    """The block kernels and the GEMM pairs work on tiles of 4 clips; other batch sizes get empty clips appended behind the audio encoder (zero rows,
+    DropPath factor 1) whose rows carry zero gradients and are cut from the output (`training.train_forward`).  5, 3 and 1 clips - the text-prompt variant
+    with its style input and input_process3 among them - in train mode: loss and every parameter gradient against autograd through the oracle."""
+    from oracle import denoiser_ref as dr
+    from oracle.process_ref import RefProcess
+    from syntalker_amd.process import create_gaussian_diffusion
+    m = _model(variant).train()
+    m.drop_path = 0.0
+    m.cond_mask_prob = 0.0                             # (h3d: the Bernoulli style dropout is random)
+    y = synth.synth_clip_inputs(B, seed=15, style_dim=256, style_zero=False) if variant == "h3d" else synth.synth_clip_inputs(B, seed=15)
+    x0, eps = synth.synth_latent(B, seed=15, name="x0"), synth.synth_latent(B, seed=16, name="eps")
+    t = (torch.arange(B) * 211 + 3) % 1000
+    d = create_gaussian_diffusion()
+    loss = d.training_losses(m, x0.to(DEV), t.to(DEV), model_kwargs={"y": synth.to_device(y, DEV)}, noise=eps.to(DEV))["loss"]
+    assert loss.shape == (B,)
+    loss.mean().backward()
+    buffers = ("running_mean", "running_var", "num_batches_tracked", ".pe", "inv_freq")
+    sd = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(buffers)) for k, v in synth_state_dict(variant).items()}
+    fwd = (lambda a, b, c: dr.mdm_forward(sd, a, b, c, train_bn=True, variant="h3d")) if variant == "h3d" else (lambda a, b, c: dr.mdm_forward(sd, a, b, c, train_bn=True))
+    ref = RefProcess(False).training_losses(fwd, x0, t, y, eps)["loss"]
+    assert np.allclose(loss.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-2), (loss, ref)
+    ref.mean().backward()
+    worst = ("", 0.0)
+    for n, p in m.named_parameters():
+        if p.grad is None or n not in sd or sd[n].grad is None or float(sd[n].grad.norm()) < 1e-5:
+            continue
+        e = rel_l2(p.grad.cpu(), sd[n].grad)
+        worst = max(worst, (n, e), key=lambda v: v[1])
+        assert e < 3e-2, (n, e)
+    print(f"{variant}, {B} clips: worst per-tensor gradient rel-L2 vs oracle {worst[1]:.3e} ({worst[0]})")
+
+
 def test_fused_wav_block_equals_the_per_convolution_nodes():
     """training.WavBlockFn (round 5: a BasicBlock of the audio encoder as one autograd node - bn1 + LeakyReLU applied by conv2 as it stages its
     tile, the shortcut's BatchNorm inside the block's one elementwise pass, one statistics + one apply pass for both BatchNorms in the backward,
