@@ -72,6 +72,7 @@ struct GArgs {
     int mt128;    // row tile of the 128-column plain GEMM (16 / 32 / 64), chosen by the host per shape
     // plain epilogue of a residual branch's last Linear: Yf = res + rscale[m / rows_per_scale] * (acc + bias) (rscale NULL: factor 1)
     const float* res; const float* rscale; int rows_per_scale;
+    int w_ks;     // 128-column GEMM on a K slice (linear_impl: K beyond the resident block): k-steps of the FULL packed weight (its pitch per 16 columns); 0 = K / 32
 };
 
 // Rotary pair (models/denoiser.py:178-186) with its roundings pinned: u' = fma(u, cos, -(w sin)), w' = fma(w, cos, u sin), the
@@ -591,7 +592,7 @@ __device__ __forceinline__ void gemm_body_n128(const GArgs& a, const int bx, con
     f32x4 acc[1][MF];
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) acc[0][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const uint4* Wq = a.W + ((size_t)(by * 8 + wave) * KS) * 64 + lane;
+    const uint4* Wq = a.W + ((size_t)(by * 8 + wave) * (a.w_ks ? a.w_ks : KS)) * 64 + lane;
     gemm_mainloop_resident<MT, 1, 16>(acc, a.X, a.ldx, a.x_rows, m0, a.M, a.K, Wq, smem);
     const int n = by * 128 + wave * 16 + g * 4;
     f32x4 b = {0.f, 0.f, 0.f, 0.f};
@@ -2142,11 +2143,20 @@ static int linear_impl(const void* x_bf16, const void* w_packed, const float* bi
     a.Y = (__bf16*)gelu_bf16;
     if (n % kNT) {
         // 128 or 256 output features (mix_audio_text: 512 -> 256): the 128-column tiles only
-        const int m128 = (g_gemm_resident == 2 && !res && !gelu_bf16) ? pick_mt128(m_rows, n, k) : 0;
-        if (!m128) return fail_msg("syn_linear: n % 512 != 0 needs the plain epilogue and k <= 4096 (128-column tiles)");
-        a.mt128 = m128;
+        if (g_gemm_resident != 2 || res || gelu_bf16) return fail_msg("syn_linear: n % 512 != 0 needs the plain epilogue (128-column tiles)");
+        // The kernel keeps its activation block [row tile][K] resident in the LDS: 4096 of K at 16 rows.  A longer K (the weight gradient of a Linear
+        // with 128 / 256 / 384 inputs over more than 4096 rows: text_encoder_body beyond 32 clips) goes out as slices of 4096, every slice after the
+        // first adding to what the one before it stored (the residual epilogue reading the output in place) - a fixed order, run-to-run identical.
+        constexpr int kSlice = kN128Lds / 32;
         n128_setup();
-        hipLaunchKernelGGL(k_gemm_n128, dim3((m_rows + m128 - 1) / m128, n / 128), dim3(kThreads), m128 * k * 2, (hipStream_t)stream, a);
+        for (int k0 = 0; k0 < k; k0 += kSlice) {
+            GArgs b = a;
+            b.K = k - k0 < kSlice ? k - k0 : kSlice;
+            b.X = a.X + k0; b.W = a.W + (size_t)(k0 / 32) * 64; b.w_ks = k / 32;
+            if (k0) { b.bias = nullptr; b.res = y; }
+            b.mt128 = pick_mt128(m_rows, n, b.K);
+            hipLaunchKernelGGL(k_gemm_n128, dim3((m_rows + b.mt128 - 1) / b.mt128, n / 128), dim3(kThreads), b.mt128 * b.K * 2, (hipStream_t)stream, b);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(who, e);
         return xt_packed ? syn_pack_weight_t(x_bf16, 1, k, m_rows, xt_packed, stream) : 0;

@@ -152,11 +152,13 @@ def test_linear_backward_operand_pass_and_pair_bias_sum(lib):
 
 def test_linear_pair_on_128_column_shapes(lib):
     """syn_linear_pair where an output width is a multiple of 128 but not of 512 (input_process2: 1280 input features; mix_audio_text: 256 outputs):
-    the pair runs on the 128-column tiles, and equals two syn_linear launches bitwise."""
+    the pair runs on the 128-column tiles, and equals two syn_linear launches bitwise.  Beyond 4096 rows (text_encoder_body's weight gradient at more
+    than 32 clips) the 128-column kernel's resident activation block no longer holds the contraction: slices of 4096, added up in order
+    (4608 = 36 clips, 9216 = 72 clips: a partial and a full last slice)."""
     from syntalker_amd import training
     g = torch.Generator().manual_seed(19)
     L, st = lib.load(), lib.current_stream()
-    for M, N, K in ((1024, 512, 1280), (1024, 256, 512), (4096, 256, 384)):
+    for M, N, K in ((1024, 512, 1280), (1024, 256, 512), (4096, 256, 384), (4608, 256, 384), (9216, 256, 384), (8192, 128, 128)):
         dyb = _bf(torch.randn(M, N, generator=g)).cuda().contiguous()
         dybt = dyb.t().contiguous()
         xb = _bf(torch.randn(M, K, generator=g)).cuda().contiguous()
