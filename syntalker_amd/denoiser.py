@@ -163,7 +163,7 @@ class MDM(nn.Module):
         return self.variant == "h3d" or self.use_motionclip
 
     def _weights_key(self):
-        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+        return (engine.raw_write_epoch(),) + tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
 
     def packed(self) -> engine.PackedModel:
         """Folded/packed weights, rebuilt when any parameter was modified in place or moved."""

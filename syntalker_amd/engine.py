@@ -24,6 +24,22 @@ from .conditioning import ClipConditioner, fold_input_stage, rotary_tables, time
 T, CH, D, FF, LAYERS = 32, 1536, 512, 1024, 8
 
 
+# Parameters and buffers are also written where PyTorch's in-place version counters do not see it: `ClipAdam`'s update and the BatchNorm running
+# statistics go through raw pointers, and a replayed `GraphedTrainStep` is one opaque launch.  Every such writer calls `note_raw_write()`; the caches of
+# derived weights (`MDM.packed()`, `RVQVAE.packed()`) key on this count next to the tensors' versions, so the first sampling call after any training
+# step folds and packs the weights again (the reference's trainer samples between epochs: diffusion_rvqvae_trainer.py `val` / `test`).
+_raw_writes = 0
+
+
+def note_raw_write():
+    global _raw_writes
+    _raw_writes += 1
+
+
+def raw_write_epoch() -> int:
+    return _raw_writes
+
+
 def _require_cuda(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise _lib.SynHipError(

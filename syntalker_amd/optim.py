@@ -247,6 +247,7 @@ class ClipAdam(torch.optim.Optimizer):
                                            0.0 if lr_dev is not None else float(lr), b1, b2, step.data_ptr(), scal[gi].data_ptr(), st), "syn_opt_scalars")
             for L in lists:
                 _lib.check(lib.syn_opt_adam(C.byref(L), scal[gi].data_ptr(), b1, b2, group["eps"], group["weight_decay"], st), "syn_opt_adam")
+        engine.note_raw_write()                                          # (the parameters moved and their version counters did not)
         return loss
 
 
@@ -383,6 +384,7 @@ class GraphedTrainStep:
             if torch.is_tensor(v):
                 self.y[k].copy_(v)
         self.graph.replay()
+        engine.note_raw_write()                                          # (parameters, BatchNorm statistics: one opaque launch to the version counters)
         return self.loss.clone()        # (stream-ordered copy: the static tensor is overwritten by the next replay)
 
     def close(self):

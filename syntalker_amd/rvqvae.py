@@ -17,7 +17,7 @@ import ctypes as C
 import torch
 import torch.nn as nn
 
-from . import _lib, synth
+from . import _lib, engine, synth
 
 NUM_Q, NB_CODE, CODE_DIM = 6, 512, 512
 
@@ -98,7 +98,7 @@ class RVQVAE(nn.Module):
         """syn_vq_model of this module: fragment-packed conv weights, padded biases, codebook views.  Rebuilt when a
         parameter changes (version counters) or moves."""
         tensors = list(self.parameters()) + list(self.buffers())
-        ver = tuple((v._version, v.data_ptr()) for v in tensors)
+        ver = (engine.raw_write_epoch(),) + tuple((v._version, v.data_ptr()) for v in tensors)
         if self._packed is not None and self._packed["ver"] == ver:
             return self._packed
         sd = self.state_dict()

@@ -1487,6 +1487,8 @@ def train_forward(m, x, timesteps, y, drop_path: float = 0.1):
     if torch.is_grad_enabled() and any(getattr(p, "_syn_grad_handed", False) for p in m.parameters()):
         _reset_handed(m)                                       # a new step: every bound gradient buffer may be handed out again (`_grad_out`)
     _step_packs(m, training)
+    if training:
+        engine.note_raw_write()                                # (the BatchNorm running statistics are written by the finalize kernels, not by a tensor op)
     h3d = m.variant == "h3d"
     te = m.embed_timestep
     e = te.sequence_pos_encoder.pe[timesteps]                                   # (B,1,512)

@@ -861,6 +861,52 @@ def test_guided_small_batch_both_group_layouts(h3d):
     assert rel_l2(a1, c1) < 1.5e-2 and rel_l2(b1, c1) < 1.5e-2
 
 
+@pytest.mark.parametrize("how", ["captured-step", "eager-clipadam-eval-bn"])
+def test_sampling_after_training_sees_the_trained_weights(how):
+    """The reference's trainer samples between epochs (diffusion_rvqvae_trainer.py: `val` / `test` from `train`).  The sampling kernels read folded, packed
+    copies of the weights (`MDM.packed()`), cached against the tensors' in-place version counters - which neither a hipGraph replay nor `ClipAdam`'s
+    raw-pointer update moves.  After training either way, the model's samples must equal those of a FRESH model loaded from its state_dict."""
+    from syntalker_amd import training
+    from syntalker_amd.process import create_gaussian_diffusion
+    d = create_gaussian_diffusion()
+    m = _model("beatx")
+    y = synth.to_device(synth.synth_clip_inputs(4, seed=71), DEV)
+    x0 = synth.synth_latent(4, seed=71, name="x0").to(DEV)
+    t = torch.tensor([100, 300, 500, 700], device=DEV)
+    xT = synth.synth_latent(4, seed=72, name="xT").to(DEV)
+
+    def sample(mod):
+        mod.eval()
+        with torch.no_grad():
+            return d.p_sample_loop(mod, tuple(x0.shape), noise=xT, clip_denoised=False, model_kwargs={"y": y}, progress=False, skip_timesteps=995, seed=9).clone()
+
+    before = sample(m)                                     # the packed copies exist from here on
+    opt = training.ClipAdam(m.parameters(), lr=1e-3, max_norm=0.99)
+    if how == "captured-step":
+        m.train()
+        step = training.GraphedTrainStep(m, d, opt, x0, {"y": y})
+        before = sample(m)                                 # (constructing the step restored the weights with tensor ops: pack again, THEN replay)
+        m.train()
+        for _ in range(3):
+            step(x0, t, {"y": y})
+        torch.cuda.synchronize()
+        step.close()
+    else:
+        m.eval()
+        m.differentiable_eval = True                       # fine-tuning with frozen BatchNorm statistics: nothing in the step touches a version counter
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            d.training_losses(m, x0, t, model_kwargs={"y": y})["loss"].mean().backward()
+            opt.step()
+        m.differentiable_eval = False
+    after = sample(m)
+    fresh = _model("beatx")
+    fresh.load_state_dict(m.state_dict())
+    want = sample(fresh)
+    assert rel_l2(after.cpu(), before.cpu()) > 1e-3        # three steps at lr 1e-3 move the samples
+    assert torch.equal(after, want), rel_l2(after.cpu(), want.cpu())
+
+
 def test_graph_replayed_train_step(beatx):
     """training.GraphedTrainStep: the captured step trains (parameters move, loss finite and falling on a fixed batch)."""
     from syntalker_amd import training
