@@ -784,6 +784,72 @@ def test_train_mode_step_runs_and_updates(beatx):
     assert torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("variant", ["beatx", "h3d"])
+def test_frozen_parameter_groups_weighted_losses_and_accumulation(variant):
+    """What a fine-tuning script does to the reference model and autograd takes in its stride; here every group of operations is ONE hand-written
+    autograd node, so each case is the node's own bookkeeping: parameter groups with requires_grad False (the audio encoder; everything but the
+    blocks; the blocks; the word embedding), the schedule sampler's per-sample weights on the loss (diffusion_rvqvae_trainer.py:345-349), two
+    backward passes into the same .grad, and a train()-mode forward under no_grad (a validation loss without eval(): batch statistics, running
+    statistics move).  Gradients of what stays trainable must equal the all-trainable run's."""
+    from syntalker_amd.process import create_gaussian_diffusion
+    d = create_gaussian_diffusion()
+    B = 8
+    y = synth.synth_clip_inputs(B, seed=81, style_dim=256, style_zero=False) if variant == "h3d" else synth.synth_clip_inputs(B, seed=81)
+    y = synth.to_device(y, DEV)
+    x0, eps = synth.synth_latent(B, seed=81, name="x0").to(DEV), synth.synth_latent(B, seed=82, name="eps").to(DEV)
+    t = ((torch.arange(B) * 131 + 7) % 1000).to(DEV)
+    wts = torch.linspace(0.5, 2.0, B, device=DEV)
+
+    hit = lambda n, freeze: any(n == f.rstrip(".") or n.startswith(f) for f in freeze)
+
+    def run(freeze=(), weights=None, passes=1):
+        m = _model(variant).train()
+        m.drop_path = 0.0
+        m.cond_mask_prob = 0.0
+        for n, p in m.named_parameters():
+            if hit(n, freeze):
+                p.requires_grad_(False)
+        for _ in range(passes):
+            loss = d.training_losses(m, x0, t, model_kwargs={"y": y}, noise=eps)["loss"]
+            ((loss * weights).mean() if weights is not None else loss.mean()).backward()
+        torch.cuda.synchronize()
+        return loss.detach(), {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in m.named_parameters()}, m
+
+    l0, g0, m0 = run()
+    for freeze in (("WavEncoder.",), tuple(n.split(".")[0] + "." for n, _ in m0.named_parameters() if not n.startswith("mytimmblocks")), ("mytimmblocks.",),
+                   ("text_pre_encoder_body.",), ("WavEncoder.feat_extractor.0.", "mytimmblocks.3.", "output_process."),
+                   tuple(n for n, _ in m0.named_parameters() if n.endswith(".bias"))):
+        l1, g1, _ = run(freeze=freeze)
+        assert torch.equal(l1, l0), freeze
+        for n in g0:
+            if hit(n, freeze):
+                assert g1[n] is None, (freeze[:2], n)
+            elif g0[n] is None:
+                assert g1[n] is None, n
+            else:
+                assert g1[n] is not None and rel_l2(g1[n].cpu(), g0[n].cpu()) < 1e-5, (freeze[:2], n, rel_l2(g1[n].cpu(), g0[n].cpu()))
+    # per-sample weights: the gradient is linear in them - weights w and 2 w
+    _, gw, _ = run(weights=wts)
+    _, g2w, _ = run(weights=2 * wts)
+    _, gacc, _ = run(weights=wts, passes=2)
+    for n in gw:
+        if gw[n] is None or float(gw[n].norm()) < 1e-6:
+            continue
+        assert rel_l2(g2w[n].cpu(), (2 * gw[n]).cpu()) < 1e-5, n
+        # (the second pass starts from updated BatchNorm running statistics only - batch statistics are what the forward uses)
+        assert rel_l2(gacc[n].cpu(), (2 * gw[n]).cpu()) < 1e-5, n
+    assert rel_l2(gw["output_process.poseFinal.weight"].cpu(), g0["output_process.poseFinal.weight"].cpu()) > 1e-2      # (the weights do something)
+    # train() under no_grad
+    m = _model(variant).train()
+    m.drop_path = 0.0
+    m.cond_mask_prob = 0.0
+    rm = m.WavEncoder.feat_extractor[2].bn2.running_mean.clone()
+    with torch.no_grad():
+        lv = d.training_losses(m, x0, t, model_kwargs={"y": y}, noise=eps)["loss"]
+    assert torch.allclose(lv, l0, rtol=2e-3) and not lv.requires_grad       # (other kernels where nothing is saved for a backward: bf16-level differences)
+    assert not torch.equal(rm, m.WavEncoder.feat_extractor[2].bn2.running_mean)
+
+
 def test_two_forwards_then_one_backward_and_two_models_alive():
     """The fused residual branches carry the W^T fragments their forward saw on the autograd node - views of the model's per-step
     pack buffers, which the NEXT forward rewrites in place (training.WeightPacks.refresh).  Gradient accumulation (two forwards, then
