@@ -157,6 +157,15 @@ class MDM(nn.Module):
                                        # whole-step kernel); 4 / 3 / 5 pin one of them; 1: five kernels per block (bitwise cross-check, h8 tap)
         self.differentiable_eval = False   # eval() + autograd on: take the differentiable path (gradient tests)
 
+    def __getstate__(self):
+        """copy.deepcopy(model) (an EMA copy) and torch.save(model) take the module as nn.Module defines it - parameters, buffers, attributes - and none
+        of the device-side caches derived from them (ctypes structs of raw pointers into THIS module's packed tensors): the copy builds its own."""
+        st = self.__dict__.copy()
+        st["_packed"], st["_packed_key"], st["_bufs"], st["_cond_entry"] = None, None, {}, None
+        for k in [k for k in st if k.startswith("_syn_") or k == "_ident"]:
+            del st[k]
+        return st
+
     # ---- engine plumbing ----------------------------------------------------------------------
     @property
     def uses_style(self):

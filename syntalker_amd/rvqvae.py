@@ -88,6 +88,11 @@ class RVQVAE(nn.Module):
         self._packed = None
         self.eval()
 
+    def __getstate__(self):
+        st = self.__dict__.copy()               # (deepcopy / torch.save: without the packed copy - ctypes pointers into this module's tensors)
+        st["_packed"] = None
+        return st
+
     def train(self, mode: bool = True):
         if mode:
             raise NotImplementedError("RVQVAE is an inference module here (the reference keeps it in eval(), trainer :159-161)")

@@ -785,6 +785,48 @@ def test_train_mode_step_runs_and_updates(beatx):
 
 
 @pytest.mark.parametrize("variant", ["beatx", "h3d"])
+def test_used_model_deep_copies_and_pickles_like_an_nn_module(variant):
+    """copy.deepcopy(model) (an EMA copy next to the trained model) and torch.save(model) / torch.load of a model that has already sampled and trained:
+    its caches are ctypes structs of raw pointers into its own packed tensors and must not travel (`MDM.__getstate__`).  The copy samples bit-equal,
+    trains, and is independent of the original."""
+    import copy
+    import io
+    from syntalker_amd.process import create_gaussian_diffusion
+    d = create_gaussian_diffusion()
+    m = _model(variant)
+    y = synth.synth_clip_inputs(4, seed=91, style_dim=256, style_zero=False) if variant == "h3d" else synth.synth_clip_inputs(4, seed=91)
+    y = synth.to_device(y, DEV)
+    x0, eps = synth.synth_latent(4, seed=91, name="x0").to(DEV), synth.synth_latent(4, seed=92, name="eps").to(DEV)
+    tt = torch.tensor([10, 200, 600, 990], device=DEV)
+
+    def train_once(mod):
+        mod.train()
+        mod.drop_path, mod.cond_mask_prob = 0.0, 0.0
+        mod.zero_grad(set_to_none=True)
+        d.training_losses(mod, x0, tt, model_kwargs={"y": y}, noise=eps)["loss"].mean().backward()
+        mod.eval()
+
+    with torch.no_grad():
+        m(x0, tt, y)
+    train_once(m)                                      # (moves the BatchNorm running statistics)
+    with torch.no_grad():
+        o1 = m(x0, tt, y)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    for m2 in (copy.deepcopy(m), torch.load(buf, weights_only=False)):
+        assert m2._packed is None and not any(k.startswith("_syn_") for k in m2.__dict__)
+        with torch.no_grad():
+            assert torch.equal(m2(x0, tt, y), o1)
+        train_once(m2)
+        g, g2 = m.output_process.poseFinal.weight.grad, m2.output_process.poseFinal.weight.grad
+        assert g2 is not None and g2.data_ptr() != g.data_ptr() and torch.equal(g, g2)
+        with torch.no_grad():
+            m2.output_process.poseFinal.weight.mul_(0.5)                       # the copy's weights are its own
+            assert not torch.equal(m2(x0, tt, y), o1) and torch.equal(m(x0, tt, y), o1)
+
+
+@pytest.mark.parametrize("variant", ["beatx", "h3d"])
 def test_frozen_parameter_groups_weighted_losses_and_accumulation(variant):
     """What a fine-tuning script does to the reference model and autograd takes in its stride; here every group of operations is ONE hand-written
     autograd node, so each case is the node's own bookkeeping: parameter groups with requires_grad False (the audio encoder; everything but the
