@@ -341,6 +341,7 @@ class GraphedTrainStep:
             with torch.cuda.stream(side):
                 self._restore(snap)
             torch.cuda.current_stream(x0.device).wait_stream(side)
+        self._baked0 = self._baked(self.y)
 
     def _snapshot(self):
         tensors = [p for p in self.model.parameters()] + list(self.model.buffers())
@@ -362,6 +363,19 @@ class GraphedTrainStep:
                     if torch.is_tensor(v):               # state born during the warm-up goes back to its initial value: zero
                         v.copy_(snap[1][p][k]) if p in snap[1] and k in snap[1][p] else v.zero_()
 
+    _BAKED = ("optimizer hyper-parameters held as Python numbers (lr, betas, eps, weight_decay: pass lr as a device tensor to change it between replays)",
+              "keys, non-tensor values or tensor shapes of y", "model.training", "drop_path", "cond_mask_prob", "the parameters' requires_grad pattern")
+
+    def _baked(self, y):
+        """Everything the capture turned into constants of the graph.  A call that brings something else would replay the OLD behaviour silently:
+        `__call__` compares and raises instead (construct a new GraphedTrainStep for the new configuration)."""
+        num = lambda v: None if torch.is_tensor(v) else v
+        hyper = [tuple(num(g.get(k)) for k in ("lr", "betas", "eps", "weight_decay")) for g in self.opt.param_groups]
+        core = getattr(self.model, "module", self.model)
+        ys = sorted((k, tuple(v.shape) if torch.is_tensor(v) else v) for k, v in y.items())
+        return [hyper, ys, bool(self.model.training), getattr(core, "drop_path", None), getattr(core, "cond_mask_prob", None),
+                [p.requires_grad for p in self.model.parameters()]]
+
     def _body(self):
         self.opt.zero_grad(set_to_none=True)
         if self.bound:
@@ -374,6 +388,13 @@ class GraphedTrainStep:
         return loss.detach()
 
     def __call__(self, x0, t, model_kwargs, noise=None):
+        now = self._baked(model_kwargs["y"])
+        if now != self._baked0:
+            what = [w for w, a, b in zip(self._BAKED, now, self._baked0) if a != b]
+            raise RuntimeError("GraphedTrainStep: the captured step is fixed in " + "; ".join(what) + " - this call differs from the construction. "
+                               "Build a new GraphedTrainStep for the new configuration.")
+        if tuple(x0.shape) != tuple(self.x0.shape) or tuple(t.shape) != tuple(self.t.shape):
+            raise RuntimeError(f"GraphedTrainStep: static shapes - constructed for x0 {tuple(self.x0.shape)}, called with {tuple(x0.shape)}")
         self.x0.copy_(x0)
         self.t.copy_(t)
         if (noise is None) != (self.noise is None):

@@ -1037,6 +1037,22 @@ def test_graph_replayed_train_step(beatx):
     before = m.mytimmblocks[0].attn.qkv.weight.detach().clone()
     losses = [float(step(x0, t, {"y": y})) for _ in range(25)]
     assert float(st["step"]) == 25.0 and int(bn.num_batches_tracked) == nb0 + 25
+    # what the capture made a constant cannot change silently between replays: each of these raises and leaves the step usable
+    for change, undo in ((lambda: opt.param_groups[0].__setitem__("lr", 1e-5), lambda: opt.param_groups[0].__setitem__("lr", 2e-4)),
+                         (lambda: m.eval(), lambda: m.train()),
+                         (lambda: setattr(m, "drop_path", 0.3), lambda: setattr(m, "drop_path", 0.1)),
+                         (lambda: m.embed_text.weight.requires_grad_(False), lambda: m.embed_text.weight.requires_grad_(True))):
+        dp0 = m.drop_path
+        change()
+        with pytest.raises(RuntimeError, match="captured step is fixed"):
+            step(x0, t, {"y": y})
+        undo()
+        m.drop_path = dp0
+    with pytest.raises(RuntimeError, match="captured step is fixed"):
+        step(x0, t, {"y": dict(y, uncond=True)})
+    with pytest.raises(RuntimeError, match="static shapes"):
+        step(x0[:2], t[:2], {"y": y})
+    losses.append(float(step(x0, t, {"y": y})))
     step.close()
     assert all(np.isfinite(losses)) and not torch.equal(before, m.mytimmblocks[0].attn.qkv.weight)
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
