@@ -2843,9 +2843,11 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, 
 }
 
 int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows) {
+    if (n_clips <= 0 || l_out <= 0 || cin_rows < 16) return 0;          // (a size query: 0 for a geometry no kernel takes, as the other queries answer)
     const int chunks = n_clips * ((l_out + wav::kWgP - 1) / wav::kWgP);
     const bool strided = cin_rows == 384;                           // (the stride-1 layers have 64 / 128 / 256 row channels)
     const int blocks = strided ? cin_rows / wav::kWsJ : cin_rows / (16 * wav::wgrad_cb(cin_rows));   // (stride-1 layers: cout = cin)
+    if (blocks < 1) return 0;
     int shares = strided ? device_cus() / blocks : (device_cus() + blocks - 1) / blocks;   // one workgroup per CU in total (the partial sums are read back once per share)
     if (shares > chunks) shares = chunks;
     // every share writes a partial sum of the whole gradient block and k_conv_wgrad_sum reads them all back: with few chunks per
@@ -3076,6 +3078,7 @@ int syn_conv1d_pack_split(const float* w, int32_t cout, int32_t cin, int32_t str
 }
 
 int64_t syn_conv1d_pack_bytes(int32_t cout, int32_t cin, int32_t stride, int32_t transposed) {
+    if (cout <= 0 || cin <= 0 || stride < 1) return 0;
     if (transposed && stride > 1) return (int64_t)stride * cin * dgrad_taps(stride, cout) * cout * 2;
     const int kts = (15 + stride - 1) / stride * stride;
     return (int64_t)cout * kts * cin * 2;
@@ -3123,6 +3126,7 @@ static int conv_train_tile(int cinp, int stride, int cout, int n_clips, int l_ou
 }
 
 int32_t syn_conv1d_train_fwd_tiles(int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, int32_t cout) {
+    if (stride < 1) return 0;
     const int l_out = (l_in + 2 * pad - 15) / stride + 1, mw = l_out > 0 && n_clips > 0 ? conv_train_tile(stride * cin, stride, cout, n_clips, l_out) : 0;
     return mw ? n_clips * ((l_out + mw - 1) / mw) : 0;
 }

@@ -251,6 +251,49 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert sizes[0] == 16 + 8 * 23 + 8 and sizes[2] == 8 * 5 + 88 * 8 + 16 + 24
 
 
+def test_c_abi_entry_points_reject_null_and_zero_arguments_without_crashing():
+    """A C host gets no exceptions: every entry point called with NULL pointers and zero / negative sizes must come back with an error code (the size
+    queries with 0), not take the process down (round 6: three size queries divided by a zero stride - SIGFPE).  Each call in a forked child; no
+    call gets as far as a launch, so this runs without a GPU."""
+    from syntalker_amd import _lib
+    lib = _lib.load()
+    queries = {"syn_wav_workspace_bytes", "syn_wav_out_frames", "syn_bn_chunks", "syn_conv1d_first_parts", "syn_vq_quantize_groups", "syn_prefers_fragment_order",
+               "syn_conv1d_first_tiles", "syn_conv1d_train_fwd_tiles", "syn_conv1d_pack_bytes", "syn_conv1d_wgrad_shares", "syn_vq_workspace_bytes", "syn_opt_blocks"}
+
+    def args_of(f, fill):
+        out = []
+        for a in f.argtypes:
+            if fill == "zeroed structs" and hasattr(a, "_type_") and isinstance(a._type_, type) and issubclass(a._type_, ctypes.Structure):
+                out.append(ctypes.pointer(a._type_()))              # a struct of NULL pointers and zero counts
+            elif a in (ctypes.c_void_p, ctypes.c_char_p) or (hasattr(a, "_type_") and isinstance(a._type_, type)):
+                out.append(None)
+            elif a in (ctypes.c_float, ctypes.c_double):
+                out.append(0.0)
+            else:
+                out.append(0 if fill == "zeroed structs" else fill)
+        return out
+
+    crashed, accepted = [], []
+    for name in _lib.EXPORTS:
+        f = getattr(lib, name)
+        if f.argtypes is None:
+            continue
+        for fill in (0, -1, "zeroed structs"):
+            pid = os.fork()
+            if pid == 0:
+                try:
+                    os._exit(0 if f(*args_of(f, fill)) == 0 else 1)
+                except BaseException:
+                    os._exit(2)
+            _, st = os.waitpid(pid, 0)
+            if os.WIFSIGNALED(st):
+                crashed.append((name, fill, os.WTERMSIG(st)))
+            elif os.WEXITSTATUS(st) == 0 and name not in queries:
+                accepted.append((name, fill))
+    assert not crashed, crashed
+    assert not accepted, accepted
+
+
 def test_dropin_aliases_resolve():
     from syntalker_amd import dropin
     dropin.install()
