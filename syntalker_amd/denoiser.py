@@ -162,7 +162,7 @@ class MDM(nn.Module):
         of the device-side caches derived from them (ctypes structs of raw pointers into THIS module's packed tensors): the copy builds its own."""
         st = self.__dict__.copy()
         st["_packed"], st["_packed_key"], st["_bufs"], st["_cond_entry"] = None, None, {}, None
-        for k in [k for k in st if k.startswith("_syn_") or k == "_ident"]:
+        for k in [k for k in st if k.startswith("_syn_") or k in ("_ident", "_graphs")]:          # (`_graphs`: the captured loops of process._fused)
             del st[k]
         return st
 
