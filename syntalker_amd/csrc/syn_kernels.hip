@@ -1755,6 +1755,21 @@ int launch_wgrad_s(const wav::WArgs& a0, hipStream_t s) {
     return e == hipSuccess ? 0 : fail("k_conv_wgrad_s launch", e);
 }
 
+// The 128- / 256-channel stride-1 layers on 64-channel output tiles (grid z) with 32 input channels per workgroup: the gradient is cut in cout / 64 x cin / 32 slices
+// (8 / 32) instead of cin / 32 (4) or cin / 16 (16), so the same number of workgroups needs that many fewer position shares - and every share is a full-size partial
+// gradient written here and read back by syn_conv1d_wgrad_sums (r6: 87 MB -> 22 MB per 128-channel layer, 126 -> 31 MB for the 256-channel one; the three launches
+// 104 + 49 -> 120 us, the sums 159 -> 137 us per step; 16 input channels per workgroup measured 134 us - the dy fragments are then re-read from the LDS per 24 MFMAs)
+constexpr int kWgradWideCb = 2;
+template <int CO_T, int TAPS, int CB>
+int launch_wgrad_tiled(const wav::WArgs& a0, hipStream_t s) {
+    wav::WArgs a = a0; a.terms = conv_terms(true); a.dbg = nullptr;
+    static OncePerDevice once;
+    if (once.first()) { allow_lds(wav::k_conv_wgrad<CO_T, TAPS, CB>, wav::wgrad_lds2(CO_T, CB)); }
+    hipLaunchKernelGGL((wav::k_conv_wgrad<CO_T, TAPS, CB>), dim3(a.cin / (16 * CB), a.shares, a.co_n / CO_T), dim3(512), wav::wgrad_lds2(CO_T, CB), s, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv_wgrad (tiled) launch", e);
+}
+
 template <int CO, int TAPS>
 int launch_wgrad(const wav::WArgs& a0, hipStream_t s) {
     wav::WArgs a = a0; a.terms = conv_terms(true); a.dbg = g_dbg_attn;
@@ -2846,7 +2861,8 @@ int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows
     if (n_clips <= 0 || l_out <= 0 || cin_rows < 16) return 0;          // (a size query: 0 for a geometry no kernel takes, as the other queries answer)
     const int chunks = n_clips * ((l_out + wav::kWgP - 1) / wav::kWgP);
     const bool strided = cin_rows == 384;                           // (the stride-1 layers have 64 / 128 / 256 row channels)
-    const int blocks = strided ? cin_rows / wav::kWsJ : cin_rows / (16 * wav::wgrad_cb(cin_rows));   // (stride-1 layers: cout = cin)
+    int blocks = strided ? cin_rows / wav::kWsJ : cin_rows / (16 * wav::wgrad_cb(cin_rows));   // (stride-1 layers: cout = cin; 64 channels: one 64 x 64 slice)
+    if (!strided && cin_rows >= 128) blocks = (cin_rows / (16 * kWgradWideCb)) * (cin_rows / 64);   // (64-channel output tiles: launch_wgrad_tiled)
     if (blocks < 1) return 0;
     int shares = strided ? device_cus() / blocks : (device_cus() + blocks - 1) / blocks;   // one workgroup per CU in total (the partial sums are read back once per share)
     if (shares > chunks) shares = chunks;
@@ -2874,8 +2890,7 @@ static int conv_train_wgrad_impl(const float* x, const float* dy, int32_t n_clip
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (cout == 64 && taps == 15) rc = launch_wgrad<64, 15>(a, s);
-    else if (cout == 128 && taps == 15) rc = launch_wgrad<128, 15>(a, s);
-    else if (cout == 256 && taps == 15) rc = launch_wgrad<256, 15>(a, s);
+    else if ((cout == 128 || cout == 256) && taps == 15) rc = launch_wgrad_tiled<64, 15, kWgradWideCb>(a, s);
     // the strided layers, read as stride-1 ones over rows of stride * Cin = 384 channels: waves = row channels, not taps
     else if (cout == 64 && taps == 3) rc = launch_wgrad_s<64, 3>(a, s);
     else if (cout == 128 && taps == 3) rc = launch_wgrad_s<128, 3>(a, s);
