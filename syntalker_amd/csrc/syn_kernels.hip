@@ -1760,6 +1760,9 @@ int launch_wgrad_s(const wav::WArgs& a0, hipStream_t s) {
 // gradient written here and read back by syn_conv1d_wgrad_sums (r6: 87 MB -> 22 MB per 128-channel layer, 126 -> 31 MB for the 256-channel one; the three launches
 // 104 + 49 -> 120 us, the sums 159 -> 137 us per step; 16 input channels per workgroup measured 134 us - the dy fragments are then re-read from the LDS per 24 MFMAs)
 constexpr int kWgradWideCb = 2;
+// The short 64-channel layers (blocks 1 - 2: 18 chunks per clip) likewise on two slices of 32 input channels (186 -> 93 shares of 245 KB: the three launches 134 -> 103 us);
+// block 0's conv2 (105 chunks per clip, dy = 117 MB) stays on one slice: staging its dy tiles twice costs what the smaller partial sums save (166 -> 174 us)
+static bool wgrad64_two_slices(int l_out) { return (l_out + wav::kWgP - 1) / wav::kWgP < 50; }
 template <int CO_T, int TAPS, int CB>
 int launch_wgrad_tiled(const wav::WArgs& a0, hipStream_t s) {
     wav::WArgs a = a0; a.terms = conv_terms(true); a.dbg = nullptr;
@@ -2863,6 +2866,7 @@ int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows
     const bool strided = cin_rows == 384;                           // (the stride-1 layers have 64 / 128 / 256 row channels)
     int blocks = strided ? cin_rows / wav::kWsJ : cin_rows / (16 * wav::wgrad_cb(cin_rows));   // (stride-1 layers: cout = cin; 64 channels: one 64 x 64 slice)
     if (!strided && cin_rows >= 128) blocks = (cin_rows / (16 * kWgradWideCb)) * (cin_rows / 64);   // (64-channel output tiles: launch_wgrad_tiled)
+    if (!strided && cin_rows == 64 && wgrad64_two_slices(l_out)) blocks = 2;
     if (blocks < 1) return 0;
     int shares = strided ? device_cus() / blocks : (device_cus() + blocks - 1) / blocks;   // one workgroup per CU in total (the partial sums are read back once per share)
     if (shares > chunks) shares = chunks;
@@ -2889,7 +2893,8 @@ static int conv_train_wgrad_impl(const float* x, const float* dy, int32_t n_clip
     a.in_aff = in_affine; a.in_act = in_act;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (cout == 64 && taps == 15) rc = launch_wgrad<64, 15>(a, s);
+    if (cout == 64 && taps == 15 && wgrad64_two_slices(l_out)) rc = launch_wgrad_tiled<64, 15, 2>(a, s);
+    else if (cout == 64 && taps == 15) rc = launch_wgrad<64, 15>(a, s);
     else if ((cout == 128 || cout == 256) && taps == 15) rc = launch_wgrad_tiled<64, 15, kWgradWideCb>(a, s);
     // the strided layers, read as stride-1 ones over rows of stride * Cin = 384 channels: waves = row channels, not taps
     else if (cout == 64 && taps == 3) rc = launch_wgrad_s<64, 3>(a, s);
