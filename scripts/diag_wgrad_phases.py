@@ -16,13 +16,17 @@ dev = torch.device("cuda:0")
 lib = _lib.load()
 lib.syn_debug_timing.argtypes = [C.c_void_p, C.c_void_p]
 st = _lib.current_stream(dev)
-for name, cin, cout, l_in in (("b0.conv2 64", 64, 64, 14331), ("b1.conv2 64", 64, 64, 2387), ("b3.conv2 128", 128, 128, 396), ("b5.conv2 256", 256, 256, 128)):
+for name, cin, cout, l_in, stride in (("b0.conv2 64", 64, 64, 14331, 1), ("b1.conv2 64", 64, 64, 2387, 1), ("b3.conv2 128", 128, 128, 396, 1), ("b5.conv2 256", 256, 256, 128, 1),
+                                      ("b1.conv1 64 s6", 64, 64, 13437, 6), ("b3.conv1 128 s6", 64, 128, 2238, 6), ("b5.conv1 256 s3", 128, 256, 372, 3)):
+    pad = 7 if stride == 1 else 0
+    l_out = (l_in + 2 * pad - 15) // stride + 1
     x = torch.randn(N, l_in, cin, device=dev)
-    dy = torch.randn(N, l_in, cout, device=dev)
-    shares = lib.syn_conv1d_wgrad_shares(N, l_in, cin)
-    ws = torch.empty(shares * cout * 15 * cin, device=dev)
+    dy = torch.randn(N, l_out, cout, device=dev)
+    shares = lib.syn_conv1d_wgrad_shares(N, l_out, stride * cin)
+    taps = (15 + stride - 1) // stride
+    ws = torch.empty(shares * cout * taps * stride * cin, device=dev)
     dw = torch.empty(cout, cin, 15, device=dev)
-    run = lambda: _lib.check(lib.syn_conv1d_train_wgrad(x.data_ptr(), dy.data_ptr(), N, l_in, cin, 1, 7, cout, ws.data_ptr(), dw.data_ptr(), st), "wgrad")  # noqa: E731
+    run = lambda: _lib.check(lib.syn_conv1d_train_wgrad(x.data_ptr(), dy.data_ptr(), N, l_in, cin, stride, pad, cout, ws.data_ptr(), dw.data_ptr(), st), "wgrad")  # noqa: E731
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -33,7 +37,7 @@ for name, cin, cout, l_in in (("b0.conv2 64", 64, 64, 14331), ("b1.conv2 64", 64
     b.record()
     torch.cuda.synchronize()
     us = a.elapsed_time(b) / 20 * 1e3
-    ref = torch.nn.grad.conv2d_weight(x.transpose(1, 2).unsqueeze(2), (cout, cin, 1, 15), dy.transpose(1, 2).unsqueeze(2), padding=(0, 7)).squeeze(2)
+    ref = torch.nn.grad.conv2d_weight(x.transpose(1, 2).unsqueeze(2), (cout, cin, 1, 15), dy.transpose(1, 2).unsqueeze(2), stride=(1, stride), padding=(0, pad)).squeeze(2)
     err = float((dw - ref).norm() / ref.norm())
     buf = torch.zeros(1 << 16, dtype=torch.int64, device=dev)
     lib.syn_debug_timing(buf.data_ptr(), None)
@@ -43,4 +47,4 @@ for name, cin, cout, l_in in (("b0.conv2 64", 64, 64, 14331), ("b1.conv2 64", 64
     d = buf.cpu().numpy().reshape(-1, 8)
     d = d[d[:, 2] > 0]
     print(f"{name}: {us:7.1f} us (wgrad + sum), rel {err:.1e}, shares {shares}; per workgroup ({len(d)}): chunks {d[:, 3].mean():.1f}, stores {d[:, 0].mean():.0f}, "
-          f"k loop {d[:, 1].mean():.0f}, all {d[:, 2].mean():.0f} cycles; per chunk: stores {d[:, 0].sum() / d[:, 3].sum():.0f}, k loop {d[:, 1].sum() / d[:, 3].sum():.0f}")
+          f"k loop {d[:, 1].mean():.0f}, all {d[:, 2].mean():.0f} (max {d[:, 2].max()}) cycles, before the epilogue {d[:, 4].mean():.0f}; per chunk: stores {d[:, 0].sum() / d[:, 3].sum():.0f}, k loop {d[:, 1].sum() / d[:, 3].sum():.0f}")

@@ -1746,7 +1746,7 @@ int launch_conv_train(const wav::TArgs& a0, int n_clips, hipStream_t s, int n_ou
 
 template <int CO_T, int TAPS>
 int launch_wgrad_s(const wav::WArgs& a0, hipStream_t s) {
-    wav::WArgs a = a0; a.terms = conv_terms(true); a.dbg = nullptr;
+    wav::WArgs a = a0; a.terms = conv_terms(true); a.dbg = g_dbg_attn;
     static_assert(wav::wgrad_s_lds(CO_T) <= 160 * 1024, "dy and x' tiles must fit the LDS");
     static OncePerDevice once;
     if (once.first()) { allow_lds(wav::k_conv_wgrad_s<CO_T, TAPS>, wav::wgrad_s_lds(CO_T)); }
@@ -1765,7 +1765,7 @@ constexpr int kWgradWideCb = 2;
 static bool wgrad64_two_slices(int l_out) { return (l_out + wav::kWgP - 1) / wav::kWgP < 50; }
 template <int CO_T, int TAPS, int CB>
 int launch_wgrad_tiled(const wav::WArgs& a0, hipStream_t s) {
-    wav::WArgs a = a0; a.terms = conv_terms(true); a.dbg = nullptr;
+    wav::WArgs a = a0; a.terms = conv_terms(true); a.dbg = g_dbg_attn;
     static OncePerDevice once;
     if (once.first()) { allow_lds(wav::k_conv_wgrad<CO_T, TAPS, CB>, wav::wgrad_lds2(CO_T, CB)); }
     hipLaunchKernelGGL((wav::k_conv_wgrad<CO_T, TAPS, CB>), dim3(a.cin / (16 * CB), a.shares, a.co_n / CO_T), dim3(512), wav::wgrad_lds2(CO_T, CB), s, a);
