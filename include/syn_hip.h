@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define SYN_ABI_VERSION 8     /* 8: the seams of the training step (syn_rows_concat_bf16, syn_embed_rows_bf16, syn_bct_to_rows_bf16, syn_rows_group_sum, syn_touch,
+#define SYN_ABI_VERSION 9     /* 9: syn_conv1d_wgrad_shares takes the layer's output channels (the share count follows the number of gradient slices a layer is cut in);
+                                * 8: the seams of the training step (syn_rows_concat_bf16, syn_embed_rows_bf16, syn_bct_to_rows_bf16, syn_rows_group_sum, syn_touch,
                                 * syn_masked_smooth_l1 / _grad on the output Linear's rows), syn_linear_bwd_prep reads a strided / row-repeated dy, syn_pack_job.src_dim,
                                 * syn_linear_pair on 128-column tiles, syn_embedding_wgrad ld; superseded kernels and their switches removed;
                                 * 7: fused tail of the audio encoder's BasicBlock in training (syn_bn_finalize / syn_bn_apply2 / syn_bn_block_bwd,
@@ -178,9 +179,10 @@ int syn_denoise_step_profile(const syn_model* model, const syn_step* step, void*
  * over rows of stride x cin = 384 channels): dw [cout][cin][15] = sum over clips and output
  * positions of dy[l][co] x[l stride + t - pad][ci], x fp32 channels-last [n_clips][l_in][cin], dy [n_clips][l_out][cout].
  * Split operands like the forward (fp32-grade); workgroup partial sums go through ws -
- * syn_conv1d_wgrad_shares(n_clips, l_out, stride * cin) * cout * ceil(15 / stride) * stride * cin floats - and are added in a
- * fixed order (no atomics). */
-int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows);
+ * syn_conv1d_wgrad_shares(n_clips, l_out, stride * cin, cout) * cout * ceil(15 / stride) * stride * cin floats - and are added in a
+ * fixed order (no atomics).  (ABI 9: cout - a workgroup owns a slice of the gradient (output-channel tile x input-channel block) and a share of the
+ * positions; the more slices a layer is cut in, the fewer shares fill the chip, and every share is a full-size partial gradient through HBM.) */
+int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows, int32_t cout);
 int syn_conv1d_train_wgrad(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
                            int32_t cout, float* ws, float* dw, void* stream);
 

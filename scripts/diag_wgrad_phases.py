@@ -22,7 +22,7 @@ for name, cin, cout, l_in, stride in (("b0.conv2 64", 64, 64, 14331, 1), ("b1.co
     l_out = (l_in + 2 * pad - 15) // stride + 1
     x = torch.randn(N, l_in, cin, device=dev)
     dy = torch.randn(N, l_out, cout, device=dev)
-    shares = lib.syn_conv1d_wgrad_shares(N, l_out, stride * cin)
+    shares = lib.syn_conv1d_wgrad_shares(N, l_out, stride * cin, cout)
     taps = (15 + stride - 1) // stride
     ws = torch.empty(shares * cout * taps * stride * cin, device=dev)
     dw = torch.empty(cout, cin, 15, device=dev)

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SYN_HIP_LIB") or os.path.join(_HERE, "csrc", "libsyn_hip.so")   # env override: kernel A/B builds
 
 SYN_LAYERS = 8
-ABI_VERSION = 8             # include/syn_hip.h SYN_ABI_VERSION: a library built from other sources is refused at load time
+ABI_VERSION = 9             # include/syn_hip.h SYN_ABI_VERSION: a library built from other sources is refused at load time
 EXPORTS = ("syn_version", "syn_last_error", "syn_denoise_step", "syn_denoise_steps", "syn_denoise_step_profile", "syn_pack_weight", "syn_pack_weight_t", "syn_to_token_major",
            "syn_from_token_major", "syn_axpby_rows", "syn_randn", "syn_linear", "syn_linear_pair", "syn_linear_and_pack", "syn_linear_res", "syn_linear_gelu", "syn_opt_blocks", "syn_opt_sqnorm", "syn_opt_scalars", "syn_opt_adam", "syn_test_gemm", "syn_test_attention", "syn_test_handoff",
            "syn_wav_encode", "syn_wav_workspace_bytes", "syn_wav_out_frames", "syn_linear_bwd_prep", "syn_embedding_wgrad", "syn_pack_weights", "syn_bn_chunks", "syn_bn_act_fwd", "syn_bn_act_bwd", "syn_bn_sums", "syn_bn_act_apply", "syn_bn_bwd_sums", "syn_bn_act_bwd_apply", "syn_conv1d_train_fwd", "syn_conv1d_train_fwd_tiles", "syn_conv1d_pack_split", "syn_conv1d_pack_split_many", "syn_conv1d_pack_bytes", "syn_conv1d_train_wgrad", "syn_conv1d_wgrad_shares", "syn_conv1d_first_parts", "syn_conv1d_first_fwd", "syn_conv1d_first_wgrad", "syn_cond_encode",
@@ -224,7 +224,7 @@ def load():
     lib.syn_pack_weights.argtypes = [vp, i32, C.c_int64, vp]
     lib.syn_embedding_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp]
     lib.syn_conv1d_train_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
-    lib.syn_conv1d_wgrad_shares.argtypes = [i32, i32, i32]
+    lib.syn_conv1d_wgrad_shares.argtypes = [i32, i32, i32, i32]
     lib.syn_conv1d_first_parts.argtypes = [i32, i32]
     lib.syn_conv1d_first_fwd.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.syn_conv1d_first_wgrad.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]

@@ -2860,11 +2860,15 @@ int syn_wav_encode(const syn_wavenc* enc, const float* wav_in, int32_t n_clips, 
     return e == hipSuccess ? 0 : fail("syn_wav_encode", e);
 }
 
-int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows) {
-    if (n_clips <= 0 || l_out <= 0 || cin_rows < 16) return 0;          // (a size query: 0 for a geometry no kernel takes, as the other queries answer)
+// output-channel tile of the strided layers' weight gradient (k_conv_wgrad_s<CO_T, TAPS>; conv_train_wgrad_impl launches what this says)
+static int wgrad_s_tile(int cout) { return cout >= 64 ? 64 : 0; }   // (128-channel tiles for block 3 meant 3 slices x 85 shares of 590 KB; 64: 6 x 42)
+
+int32_t syn_conv1d_wgrad_shares(int32_t n_clips, int32_t l_out, int32_t cin_rows, int32_t cout) {
+    if (n_clips <= 0 || l_out <= 0 || cin_rows < 16 || cout < 64 || cout % 64) return 0;   // (a size query: 0 for a geometry no kernel takes, as the other queries answer)
     const int chunks = n_clips * ((l_out + wav::kWgP - 1) / wav::kWgP);
     const bool strided = cin_rows == 384;                           // (the stride-1 layers have 64 / 128 / 256 row channels)
-    int blocks = strided ? cin_rows / wav::kWsJ : cin_rows / (16 * wav::wgrad_cb(cin_rows));   // (stride-1 layers: cout = cin; 64 channels: one 64 x 64 slice)
+    // slices of the gradient = workgroups per position share (stride-1 layers: cout = cin; 64 channels: one 64 x 64 slice)
+    int blocks = strided ? (cin_rows / wav::kWsJ) * (cout / wgrad_s_tile(cout)) : cin_rows / (16 * wav::wgrad_cb(cin_rows));
     if (!strided && cin_rows >= 128) blocks = (cin_rows / (16 * kWgradWideCb)) * (cin_rows / 64);   // (64-channel output tiles: launch_wgrad_tiled)
     if (!strided && cin_rows == 64 && wgrad64_two_slices(l_out)) blocks = 2;
     if (blocks < 1) return 0;
@@ -2889,7 +2893,7 @@ static int conv_train_wgrad_impl(const float* x, const float* dy, int32_t n_clip
     wav::WArgs a;
     a.GY = dy; a.gy_clip_stride = (long)l_out * cout; a.L_out = l_out; a.X = x; a.x_clip_stride = (long)l_in * cin; a.x_elems = (long)l_in * cin;
     a.cin = cinp; a.co_n = cout; a.n_clips = n_clips; a.chunks_per_clip = (l_out + wav::kWgP - 1) / wav::kWgP; a.row0 = stride == 1 ? -7 : 0;
-    a.shares = syn_conv1d_wgrad_shares(n_clips, l_out, cinp); a.part = ws;
+    a.shares = syn_conv1d_wgrad_shares(n_clips, l_out, cinp, cout); a.part = ws;
     a.in_aff = in_affine; a.in_act = in_act;
     hipStream_t s = (hipStream_t)stream;
     int rc;
@@ -2898,7 +2902,7 @@ static int conv_train_wgrad_impl(const float* x, const float* dy, int32_t n_clip
     else if ((cout == 128 || cout == 256) && taps == 15) rc = launch_wgrad_tiled<64, 15, kWgradWideCb>(a, s);
     // the strided layers, read as stride-1 ones over rows of stride * Cin = 384 channels: waves = row channels, not taps
     else if (cout == 64 && taps == 3) rc = launch_wgrad_s<64, 3>(a, s);
-    else if (cout == 128 && taps == 3) rc = launch_wgrad_s<128, 3>(a, s);
+    else if (cout == 128 && taps == 3) rc = launch_wgrad_s<64, 3>(a, s);      // (two 64-channel tiles: twice the slices, half the shares)
     else if (cout == 256 && taps == 5) rc = launch_wgrad_s<64, 5>(a, s);     // (128-channel blocks spill: 20 accumulator tiles per wave is the limit)
     else return fail_msg("syn_conv1d_train_wgrad: 64 / 128 / 256 output channels; strided: (64 | 128, stride 6), (256, stride 3)");
     if (rc || !dw) return rc;                                    // (dw NULL: the partial sums only - syn_conv1d_wgrad_sums adds several gradients' up in one launch)
@@ -2997,7 +3001,7 @@ int syn_conv1d_wgrad_sums(const syn_wgrad_sum_job* jobs, int32_t n_jobs, void* s
             J.kind = 1; J.shares = first_wgrad_groups(q.n_clips, q.l_out); J.per = 64 * q.cin * 15; J.taps = 15;
         } else {
             if (q.cin % 16 || q.stride < 1) return fail_msg("syn_conv1d_wgrad_sums: cin must be a multiple of 16");
-            J.kind = 0; J.taps = (15 + q.stride - 1) / q.stride; J.shares = syn_conv1d_wgrad_shares(q.n_clips, q.l_out, q.stride * q.cin);
+            J.kind = 0; J.taps = (15 + q.stride - 1) / q.stride; J.shares = syn_conv1d_wgrad_shares(q.n_clips, q.l_out, q.stride * q.cin, q.cout);
             J.per = q.cout * J.taps * q.stride * q.cin;
         }
         blocks += (J.per / 4 + 31) / 32;

@@ -894,7 +894,7 @@ class ConvSplitFn(torch.autograd.Function):
                 lib = _lib.load()
                 n, _, _, l = x.shape
                 l_out, kts = gy.shape[-1], -(-15 // stride) * stride
-                ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l_out, stride * cin) * cout * kts * cin, device=x.device, dtype=torch.float32)
+                ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l_out, stride * cin, cout) * cout * kts * cin, device=x.device, dtype=torch.float32)
                 gw = _grad_out(ctx.owner, (cout, cin, 1, 15)) if ctx.owner is not None else torch.empty(cout, cin, 1, 15, device=x.device, dtype=torch.float32)
                 _conv_terms(2)
                 _lib.check(lib.syn_conv1d_train_wgrad(x.data_ptr(), gy.data_ptr(), n, l, cin, stride, pad, cout, ws.data_ptr(), gw.data_ptr(),
@@ -1260,7 +1260,7 @@ def _wb_wgrad(x3, dy3, conv, first, in_aff=None, in_act=0, sums=None):
         _lib.check(lib.syn_conv1d_first_wgrad(x3.data_ptr(), dy3.data_ptr(), n, l_in, cin, stride, pad, ws.data_ptr(), target, st), "syn_conv1d_first_wgrad")
     else:
         kts = -(-15 // stride) * stride
-        ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l_out, stride * cin) * cout * kts * cin, device=dev, dtype=torch.float32)
+        ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l_out, stride * cin, cout) * cout * kts * cin, device=dev, dtype=torch.float32)
         _conv_terms(2)
         if in_aff is None:
             _lib.check(lib.syn_conv1d_train_wgrad(x3.data_ptr(), dy3.data_ptr(), n, l_in, cin, stride, pad, cout, ws.data_ptr(), target, st), "syn_conv1d_train_wgrad")

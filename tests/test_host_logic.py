@@ -233,7 +233,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     exported = {l.split()[-1] for l in nm.splitlines() if " T syn_" in l}
     diagnostics = set(re.findall(r"^\s*void\s+(syn_debug_[a-z_0-9]+)\s*\(", header, flags=re.M))
     assert diagnostics == set(_lib.DIAGNOSTICS) and exported == declared | diagnostics, exported ^ (declared | diagnostics)
-    assert lib.syn_version() == 8 == _lib.ABI_VERSION
+    assert lib.syn_version() == 9 == _lib.ABI_VERSION
     # every entry point that takes arguments has its ctypes signature declared (ctypes' default passes a 64-bit pointer or count as a C int)
     loaded = _lib.load()
     no_args = {"syn_version", "syn_last_error"}
