@@ -31,6 +31,7 @@ extern "C" {
 #endif
 
 #define SYN_ABI_VERSION 9     /* 9: syn_conv1d_wgrad_shares takes the layer's output channels (the share count follows the number of gradient slices a layer is cut in);
+                                * syn_conv1d_first_wgrad_tail, syn_bn_block_bwd with dy = NULL;
                                 * 8: the seams of the training step (syn_rows_concat_bf16, syn_embed_rows_bf16, syn_bct_to_rows_bf16, syn_rows_group_sum, syn_touch,
                                 * syn_masked_smooth_l1 / _grad on the output Linear's rows), syn_linear_bwd_prep reads a strided / row-repeated dy, syn_pack_job.src_dim,
                                 * syn_linear_pair on 128-column tiles, syn_embedding_wgrad ld; superseded kernels and their switches removed;
@@ -209,6 +210,14 @@ int syn_conv1d_first_fwd2(const float* x, int32_t n_clips, int32_t l_in, int32_t
  * dp = dz act'(a(y)), is formed as the values are loaded and never written.  stride 5 (the encoder's). */
 int syn_conv1d_first_wgrad_bn(const float* x, const float* dz, const float* y, const float* stats, const float* affine, const float* dgamma_dbeta,
                               int32_t act, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws, float* dw, void* stream);
+/* (ABI 9) Block 0's SHORTCUT convolution: its weight-gradient partial sums (ws as syn_conv1d_first_wgrad) with the block tail's backward folded into the loads -
+ * dout = the gradient at the block's output, y2 / y_short the raw outputs of conv2 and of the shortcut convolution with the statistics, affines and
+ * [dgamma | dbeta | 0] of their BatchNorms (syn_bn_block_bwd with dy = NULL leaves exactly those).  d = dout act'(a2(y2) + a_s(y_short)); the shortcut's
+ * dy_s = its BatchNorm's backward of d feeds the matrix pipe and is never written; dy2 = bn2's backward of d IS written ([n_clips][l_out][64]: conv2's data
+ * and weight gradients read it).  Against syn_bn_block_bwd's apply pass + syn_conv1d_first_wgrad: one write and one read of a 117 MB tensor less.  stride 5. */
+int syn_conv1d_first_wgrad_tail(const float* x, const float* dout, const float* y2, const float* y_short, const float* stats2, const float* affine2,
+                                const float* short_stats, const float* short_affine, const float* dgb2, const float* short_dgb, int32_t act,
+                                int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws, float* dy2, void* stream);
 /* (ABI 7) the statistics half of syn_bn_act_bwd: dgamma_dbeta [3][channels] only (ws as there). */
 int syn_bn_bwd_stats(const float* dz, const float* z, const float* y, const float* stats, const float* gamma, const float* beta, int64_t rows,
                      int32_t channels, int32_t act, float* ws, float* dgamma_dbeta, void* stream);
@@ -366,7 +375,8 @@ int syn_bn_act_bwd_apply(const float* dz, const float* z, const float* y, const 
  *   syn_bn_block_bwd  from dz = d loss / d z: dp = dz act'(p) with the pre-activation p RECOMPUTED from y and the shortcut (the block's output is neither
  *                     read nor needed by the backward); dgb [3][channels] = dgamma, dbeta, 0 of a; dy; with a normalised shortcut also short_dgb and
  *                     dshortcut = the data gradient of ITS BatchNorm, with a raw one dshortcut = dp.  One statistics pass and one apply pass over
- *                     (dz, y, shortcut) for both BatchNorms.  ws: 3 * syn_bn_chunks(rows) * channels floats.
+ *                     (dz, y, shortcut) for both BatchNorms.  ws: 3 * syn_bn_chunks(rows) * channels floats.  (ABI 9) dy = NULL (and dshortcut NULL): the
+ *                     statistics pass and [dgamma | dbeta | 0] only - the caller's next kernel forms the gradients itself (syn_conv1d_first_wgrad_tail).
  * bn1 + LeakyReLU in front of conv2 is applied by conv2 itself while it stages its input (syn_conv1d_train_fwd_norm; the weight gradient recomputes it the
  * same way, syn_conv1d_train_wgrad_norm): in_affine [2][cin] = bn1's affine, in_act != 0: LeakyReLU(0.01); positions outside the clip stay zero. */
 int syn_bn_finalize(const float* part, int32_t chunks, int64_t rows, int32_t channels, const float* gamma, const float* beta, float eps, float momentum,

@@ -2620,8 +2620,9 @@ int syn_bn_apply2(const float* y, const float* affine, const float* shortcut, co
 int syn_bn_block_bwd(const float* dz, const float* y, const float* shortcut, const float* stats, const float* affine, const float* short_stats,
                      const float* short_affine, int64_t rows, int32_t channels, int32_t act, float* ws, float* dgb, float* short_dgb, float* dy,
                      float* dshortcut, void* stream) {
-    if (!dz || !y || !stats || !affine || !ws || !dgb || !dy || !bn_shape_ok(rows, channels)) return fail_msg("syn_bn_block_bwd: bad arguments");
-    if ((short_affine != nullptr) != (short_stats != nullptr) || (short_affine && (!shortcut || !short_dgb || !dshortcut)))
+    if (!dz || !y || !stats || !affine || !ws || !dgb || !bn_shape_ok(rows, channels)) return fail_msg("syn_bn_block_bwd: bad arguments");
+    if (!dy && dshortcut) return fail_msg("syn_bn_block_bwd: dy NULL (statistics and dgamma / dbeta only) takes no dshortcut either");
+    if ((short_affine != nullptr) != (short_stats != nullptr) || (short_affine && (!shortcut || !short_dgb || (dy && !dshortcut))))
         return fail_msg("syn_bn_block_bwd: a normalised shortcut needs its tensor, statistics, affine, gradient buffer and dshortcut");
     if (dshortcut && !shortcut) return fail_msg("syn_bn_block_bwd: dshortcut without a shortcut");
     hipStream_t s = (hipStream_t)stream;
@@ -2629,8 +2630,9 @@ int syn_bn_block_bwd(const float* dz, const float* y, const float* shortcut, con
     hipLaunchKernelGGL(trn::k_bn_bwd_stats2, dim3(chunks), dim3(256), 0, s, dz, y, shortcut, stats, affine, short_stats, short_affine, (long)rows, channels, act, ws);
     hipLaunchKernelGGL(trn::k_bn_bwd_finalize2, dim3(channels), dim3(256), 0, s, (const float*)ws, chunks, channels, dgb, short_affine ? short_dgb : nullptr);
     const long n4 = rows * channels / 4;
-    hipLaunchKernelGGL(trn::k_bn_bwd_apply2, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dz, y, shortcut, stats, affine, short_stats, short_affine,
-                       (const float*)dgb, (const float*)short_dgb, channels, n4, (long)rows, act, dy, dshortcut);
+    if (dy)                                                   // (dy NULL: the caller's next kernel forms dy / dshortcut itself - syn_conv1d_first_wgrad_tail)
+        hipLaunchKernelGGL(trn::k_bn_bwd_apply2, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dz, y, shortcut, stats, affine, short_stats, short_affine,
+                           (const float*)dgb, (const float*)short_dgb, channels, n4, (long)rows, act, dy, dshortcut);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("syn_bn_block_bwd", e);
 }
@@ -2942,6 +2944,7 @@ static int first_layer_args(wav::FArgs& a, const float* x, int32_t n_clips, int3
     if (a.L_out <= 0) return fail_msg(who);
     a.W = nullptr; a.Y = nullptr; a.DY = nullptr; a.part = nullptr; a.chunks_per_clip = (a.L_out + wav::kF1Chunk - 1) / wav::kF1Chunk;
     a.BY = nullptr; a.bn_stats = a.bn_aff = a.bn_dgb = nullptr; a.bn_inv_rows = 0.f; a.bn_act = 0; a.W2 = nullptr; a.Y2 = nullptr; a.part2 = nullptr;
+    a.T_y2 = nullptr; a.t_stats = a.t_aff = a.t_dgb = nullptr; a.T_dy2 = nullptr;
     return 0;
 }
 
@@ -2965,8 +2968,10 @@ int syn_conv1d_first_fwd(const float* x, int32_t n_clips, int32_t l_in, int32_t 
     return syn_conv1d_first_fwd_stats(x, n_clips, l_in, cin, stride, pad, w, y, nullptr, stream);
 }
 
+struct FirstTail { const float* y2; const float* stats2; const float* aff2; const float* dgb2; float* dy2; };
 static int first_wgrad_impl(const float* x, const float* dy, const float* bn_y, const float* bn_stats, const float* bn_aff, const float* bn_dgb,
-                            int32_t bn_act, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws, float* dw, void* stream) {
+                            int32_t bn_act, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws, float* dw, void* stream,
+                            const FirstTail* tail = nullptr) {
     wav::FArgs a;
     if (!dy || !ws) return fail_msg("syn_conv1d_first_wgrad: bad arguments");
     if (int rc = first_layer_args(a, x, n_clips, l_in, cin, stride, pad, "syn_conv1d_first_wgrad: bad arguments (cin 1 | 2, 64 output channels)")) return rc;
@@ -2975,10 +2980,19 @@ static int first_wgrad_impl(const float* x, const float* dy, const float* bn_y, 
         if (stride != 5 || !bn_stats || !bn_aff || !bn_dgb) return fail_msg("syn_conv1d_first_wgrad_bn: stride 5 (the encoder's), statistics, affine and dgamma / dbeta");
         a.BY = bn_y; a.bn_stats = bn_stats; a.bn_aff = bn_aff; a.bn_dgb = bn_dgb; a.bn_inv_rows = 1.0f / ((float)n_clips * (float)a.L_out); a.bn_act = bn_act;
     }
+    if (tail) {
+        if (!bn_y || !tail->y2 || !tail->stats2 || !tail->aff2 || !tail->dgb2 || !tail->dy2) return fail_msg("syn_conv1d_first_wgrad_tail: null pointer");
+        a.T_y2 = tail->y2; a.t_stats = tail->stats2; a.t_aff = tail->aff2; a.t_dgb = tail->dgb2; a.T_dy2 = tail->dy2;
+    }
     hipStream_t s = (hipStream_t)stream;
     const int groups = first_wgrad_groups(n_clips, a.L_out);
-    if (cin == 1) hipLaunchKernelGGL(wav::k_conv_first_wgrad_m<1>, dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
-    else hipLaunchKernelGGL(wav::k_conv_first_wgrad_m<2>, dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
+    if (tail) {
+        if ((long)n_clips * a.L_out * 64 >= (1L << 32)) return fail_msg("syn_conv1d_first_wgrad_tail: n_clips x l_out x 64 must stay below 2^32 elements");
+        if (cin == 1) hipLaunchKernelGGL((wav::k_conv_first_wgrad_m<1, true>), dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
+        else hipLaunchKernelGGL((wav::k_conv_first_wgrad_m<2, true>), dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
+    }
+    else if (cin == 1) hipLaunchKernelGGL((wav::k_conv_first_wgrad_m<1>), dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
+    else hipLaunchKernelGGL((wav::k_conv_first_wgrad_m<2>), dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
     const int n = 64 * cin * 15;
     if (dw) hipLaunchKernelGGL(wav::k_conv_first_wsum, dim3((n + 63) / 64), dim3(1024), 0, s, (const float*)ws, groups, n, dw);
     hipError_t e = hipGetLastError();
@@ -3021,6 +3035,13 @@ int syn_conv1d_first_wgrad_bn(const float* x, const float* dz, const float* y, c
                               int32_t act, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws, float* dw, void* stream) {
     if (!y) return fail_msg("syn_conv1d_first_wgrad_bn: y is NULL (use syn_conv1d_first_wgrad)");
     return first_wgrad_impl(x, dz, y, stats, affine, dgamma_dbeta, act, n_clips, l_in, cin, stride, pad, ws, dw, stream);
+}
+
+int syn_conv1d_first_wgrad_tail(const float* x, const float* dout, const float* y2, const float* y_short, const float* stats2, const float* affine2,
+                                const float* short_stats, const float* short_affine, const float* dgb2, const float* short_dgb, int32_t act,
+                                int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws, float* dy2, void* stream) {
+    const FirstTail t = {y2, stats2, affine2, dgb2, dy2};
+    return first_wgrad_impl(x, dout, y_short, short_stats, short_affine, short_dgb, act, n_clips, l_in, cin, stride, pad, ws, nullptr, stream, &t);
 }
 
 int syn_conv1d_first_fwd2(const float* x, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, const float* w_a, const float* w_b,

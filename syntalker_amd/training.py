@@ -1344,14 +1344,28 @@ class WavBlockFn(torch.autograd.Function):
         ws = torch.empty(3 * lib.syn_bn_chunks(rows) * c, device=dev, dtype=torch.float32)
         dgb2 = torch.empty(3, c, device=dev, dtype=torch.float32)
         dgbs = torch.empty(3, c, device=dev, dtype=torch.float32) if ds else None
-        dy2, dsh = torch.empty_like(y2), torch.empty_like(y2)
         short = ysc if ds else x3
+        sums = []
+        # block 0 with its shortcut convolution: the tail's apply pass and the shortcut's weight gradient are ONE kernel - it reads (dout, y2, y_sc) once,
+        # writes dy2 and feeds the shortcut's dy straight into the weight gradient's matrix products (that tensor is never written or read back)
+        tail0 = first and ds and blk.conv1.stride[0] == 5
+        dy2 = torch.empty_like(y2)
+        dsh = None if tail0 else torch.empty_like(y2)
         _lib.check(lib.syn_bn_block_bwd(d3.data_ptr(), y2.data_ptr(), short.data_ptr(), st2.data_ptr(), af2.data_ptr(), _lib.ptr(sts), _lib.ptr(afs),
-                                        rows, c, 1, ws.data_ptr(), dgb2.data_ptr(), _lib.ptr(dgbs), dy2.data_ptr(), dsh.data_ptr(),
+                                        rows, c, 1, ws.data_ptr(), dgb2.data_ptr(), _lib.ptr(dgbs), None if tail0 else dy2.data_ptr(), _lib.ptr(dsh),
                                         _lib.current_stream(dev)), "syn_bn_block_bwd")
+        gws = None
+        if tail0:
+            cs_ = blk.downsample[0]
+            nn_, l_in, cin = x3.shape
+            wss = torch.empty(lib.syn_conv1d_first_parts(nn_, l1) * 64 * cin * 15, device=dev, dtype=torch.float32)
+            gws = _grad_out(cs_.weight, (64, cin, 15))
+            _lib.check(lib.syn_conv1d_first_wgrad_tail(x3.data_ptr(), d3.data_ptr(), y2.data_ptr(), ysc.data_ptr(), st2.data_ptr(), af2.data_ptr(), sts.data_ptr(),
+                                                       afs.data_ptr(), dgb2.data_ptr(), dgbs.data_ptr(), 1, nn_, l_in, cin, cs_.stride[0], cs_.padding[0],
+                                                       wss.data_ptr(), dy2.data_ptr(), _lib.current_stream(dev)), "syn_conv1d_first_wgrad_tail")
+            sums.append((wss, gws, nn_, l1, cin, cs_.stride[0], 64, 1))
         # conv2: data gradient to z1 = act(bn1(y1)), weight gradient with z1 recomputed from y1 while its rows are staged
         dz1 = _wb_dgrad(dy2, blk.conv2, l1)
-        sums = []
         gw2 = _wb_wgrad(y1, dy2, blk.conv2, False, in_aff=af1, in_act=1, sums=sums)
         # bn1 + activation (no shortcut entered it: the sign comes from y1)
         ws1 = torch.empty(2 * lib.syn_bn_chunks(rows) * c, device=dev, dtype=torch.float32)
@@ -1384,7 +1398,8 @@ class WavBlockFn(torch.autograd.Function):
                  gw2, dgb2[2] if blk.conv2.bias is not None else None, dgb2[0], dgb2[1]]
         owners = [None, blk.conv1.bias, blk.bn1.weight, blk.bn1.bias, None, blk.conv2.bias, blk.bn2.weight, blk.bn2.bias]
         if ds:
-            gws = _wb_wgrad(x3, dsh, blk.downsample[0], first, sums=sums)
+            if gws is None:
+                gws = _wb_wgrad(x3, dsh, blk.downsample[0], first, sums=sums)
             grads += [gws, dgbs[2] if blk.downsample[0].bias is not None else None, dgbs[0], dgbs[1]]
             owners += [None, blk.downsample[0].bias, blk.downsample[1].weight, blk.downsample[1].bias]
         _wb_wgrad_sums(sums, dev)                              # the block's weight gradients: their partial sums added up in one launch
