@@ -1014,6 +1014,58 @@ def test_first_layer_weight_gradient_at_the_bench_shape_vs_fp64(n, L, fold):
     assert e < 1e-5
 
 
+@pytest.mark.parametrize("n,L", [(32, 68266), (3, 20011)])
+def test_block0_backward_tail_folded_into_the_shortcut_weight_gradient(n, L):
+    """syn_conv1d_first_wgrad_tail (round 6): block 0's tail backward (both BatchNorms' data gradients from dout, y2, y_sc) and the shortcut convolution's
+    weight gradient as ONE kernel - dy2 written, the shortcut's dy fed straight into the matrix products.  Against the two-kernel path it replaces
+    (syn_bn_block_bwd's apply pass, then syn_conv1d_first_wgrad on the stored dshortcut) and against float64."""
+    from syntalker_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + L)
+    cin, stride, pad, C = 2, 5, 1700, 64
+    l_out = (L + 2 * pad - 15) // stride + 1
+    rows = n * l_out
+    x = torch.randn(n, L, cin, generator=g).cuda()
+    dout, y2, ysc = (torch.randn(n, l_out, C, generator=g).cuda() for _ in range(3))
+    mk = lambda: (torch.cat([torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5]).cuda(),
+                  torch.cat([torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3]).cuda())
+    (st2, af2), (sts, afs) = mk(), mk()
+    st = _lib.current_stream(x.device)
+    ws = torch.empty(3 * lib.syn_bn_chunks(rows) * C, device="cuda")
+    dgb2, dgbs = torch.empty(3, C, device="cuda"), torch.empty(3, C, device="cuda")
+    dy2_a, dsh_a = torch.empty_like(y2), torch.empty_like(y2)
+    args = (dout.data_ptr(), y2.data_ptr(), ysc.data_ptr(), st2.data_ptr(), af2.data_ptr(), sts.data_ptr(), afs.data_ptr(), rows, C, 1, ws.data_ptr(), dgb2.data_ptr(), dgbs.data_ptr())
+    _lib.check(lib.syn_bn_block_bwd(*args, dy2_a.data_ptr(), dsh_a.data_ptr(), st), "syn_bn_block_bwd")
+    parts = lib.syn_conv1d_first_parts(n, l_out)
+    wsa, dwa = torch.empty(parts * C * cin * 15, device="cuda"), torch.empty(C, cin, 15, device="cuda")
+    _lib.check(lib.syn_conv1d_first_wgrad(x.data_ptr(), dsh_a.data_ptr(), n, L, cin, stride, pad, wsa.data_ptr(), dwa.data_ptr(), st), "syn_conv1d_first_wgrad")
+    g2a, gsa = dgb2.clone(), dgbs.clone()
+    # the fused path: statistics only, then the one kernel; the partial sums added by the block's reduction launch
+    _lib.check(lib.syn_bn_block_bwd(*args, None, None, st), "syn_bn_block_bwd (statistics only)")
+    assert torch.equal(dgb2, g2a) and torch.equal(dgbs, gsa)
+    dy2_b = torch.empty_like(y2)
+    wsb, dwb = torch.empty(parts * C * cin * 15, device="cuda"), torch.empty(C, cin, 15, device="cuda")
+    _lib.check(lib.syn_conv1d_first_wgrad_tail(x.data_ptr(), dout.data_ptr(), y2.data_ptr(), ysc.data_ptr(), st2.data_ptr(), af2.data_ptr(), sts.data_ptr(), afs.data_ptr(),
+                                               dgb2.data_ptr(), dgbs.data_ptr(), 1, n, L, cin, stride, pad, wsb.data_ptr(), dy2_b.data_ptr(), st), "syn_conv1d_first_wgrad_tail")
+    job = (_lib.SynWgradSumJob * 1)()
+    job[0].part, job[0].dw, job[0].n_clips, job[0].l_out, job[0].cin, job[0].stride, job[0].cout, job[0].first_layer = wsb.data_ptr(), dwb.data_ptr(), n, l_out, cin, stride, C, 1
+    _lib.check(lib.syn_conv1d_wgrad_sums(job, 1, st), "syn_conv1d_wgrad_sums")
+    torch.cuda.synchronize()
+    assert rel_l2(dy2_b.cpu(), dy2_a.cpu()) < 1e-6 and rel_l2(dwb.cpu(), dwa.cpu()) < 1e-5
+    # float64 restatement
+    m = float(rows)
+    D = lambda t: t.double()
+    p = D(y2) * D(af2[:C]) + D(af2[C:]) + D(ysc) * D(afs[:C]) + D(afs[C:])
+    d = torch.where(p > 0, D(dout), 0.01 * D(dout))
+    dy2 = D(af2[:C]) * (d - D(dgb2[1]) / m - (D(y2) - D(st2[:C])) * D(st2[C:]) * D(dgb2[0]) / m)
+    dys = D(afs[:C]) * (d - D(dgbs[1]) / m - (D(ysc) - D(sts[:C])) * D(sts[C:]) * D(dgbs[0]) / m)
+    x4 = x.permute(0, 2, 1).unsqueeze(2).double()
+    want = torch.nn.grad.conv2d_weight(x4, (C, cin, 1, 15), dys.permute(0, 2, 1).unsqueeze(2).contiguous(), stride=(1, stride), padding=(0, pad)).squeeze(2)
+    e1, e2 = rel_l2(dy2_b.double().cpu(), dy2.cpu()), rel_l2(dwb.double().cpu(), want.cpu())
+    print(f"block-0 tail folded into the shortcut's weight gradient, {n} clips: dy2 {e1:.2e}, dW {e2:.2e} vs float64")
+    assert e1 < 1e-6 and e2 < 1e-5
+
+
 @pytest.mark.parametrize("cin,stride,cout,pad,L", [(64, 1, 64, 7, 14331), (64, 6, 64, 0, 14331), (64, 1, 64, 7, 2387), (64, 6, 128, 0, 2387),
                                                   (128, 1, 128, 7, 396), (128, 3, 256, 0, 396), (256, 1, 256, 7, 128)])
 def test_training_conv_weight_gradients_at_the_bench_shapes(cin, stride, cout, pad, L):
