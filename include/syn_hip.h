@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define SYN_ABI_VERSION 9     /* 9: syn_conv1d_wgrad_shares takes the layer's output channels (the share count follows the number of gradient slices a layer is cut in);
-                                * syn_conv1d_first_wgrad_tail, syn_bn_block_bwd with dy = NULL;
+                                * syn_conv1d_first_wgrad_tail, syn_bn_block_bwd with dy = NULL, syn_conv1d_train_wgrad_pair, syn_wgrad_sum_job.share_pitch;
                                 * 8: the seams of the training step (syn_rows_concat_bf16, syn_embed_rows_bf16, syn_bct_to_rows_bf16, syn_rows_group_sum, syn_touch,
                                 * syn_masked_smooth_l1 / _grad on the output Linear's rows), syn_linear_bwd_prep reads a strided / row-repeated dy, syn_pack_job.src_dim,
                                 * syn_linear_pair on 128-column tiles, syn_embedding_wgrad ld; superseded kernels and their switches removed;
@@ -243,7 +243,10 @@ int64_t syn_conv1d_pack_bytes(int32_t cout, int32_t cin, int32_t stride, int32_t
  * A job: part = that call's ws, dw = the module-layout gradient [cout][cin][15], the call's n_clips / cin / stride / cout and ITS l_out;
  * first_layer != 0: the job is a syn_conv1d_first_wgrad* call (cin 1 | 2, cout 64). */
 #define SYN_WGRAD_SUM_MAX 4
-typedef struct syn_wgrad_sum_job { const float* part; float* dw; int32_t n_clips, l_out, cin, stride, cout, first_layer; } syn_wgrad_sum_job;
+typedef struct syn_wgrad_sum_job { const float* part; float* dw; int32_t n_clips, l_out, cin, stride, cout, first_layer;
+                                   int32_t share_pitch;   /* (ABI 9) floats between consecutive shares of `part`; 0 = the gradient's own size (a share that holds two
+                                                           * gradients - syn_conv1d_train_wgrad_pair - has twice that, and the second job's `part` starts one gradient in) */
+                                   int32_t reserved; } syn_wgrad_sum_job;
 int syn_conv1d_wgrad_sums(const syn_wgrad_sum_job* jobs, int32_t n_jobs, void* stream);
 /* (ABI 7) The data gradient that reaches a BasicBlock's input, written once: dx [n_clips][l_in][cin] = conv^T dy [+ conv2^T dy2] [+ residual].
  * Strided, unpadded layers (a down-sampling block: conv1 and the shortcut convolution share input and geometry): dy / dy2 [n_clips][l_out][cout] with their
@@ -272,6 +275,12 @@ int syn_conv1d_train_fwd_norm(const float* x, int32_t n_clips, int32_t l_in, int
                               void* stream);
 int syn_conv1d_train_wgrad_norm(const float* x, const float* dy, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
                                 int32_t cout, const float* in_affine, int32_t in_act, float* ws, float* dw, void* stream);
+/* (ABI 9) conv1 and the shortcut convolution of a down-sampling block - same input, stride, padding and width - leave BOTH weight gradients' partial sums from one
+ * launch that stages the input once: ws [shares][2 cout][taps][stride cin] with shares = syn_conv1d_wgrad_shares(n_clips, l_out, stride cin, cout); rows 0 .. cout - 1 of
+ * a share are dy_a's gradient, the rest dy_b's (two syn_wgrad_sum_job with share_pitch = 2 cout taps stride cin, the second's part one gradient in).
+ * (cin, stride, pad, cout) = (64, 6, 0, 64): block 1, whose input is the encoder's largest tensor. */
+int syn_conv1d_train_wgrad_pair(const float* x, const float* dy_a, const float* dy_b, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
+                                int32_t cout, float* ws, void* stream);
 
 /* Every bf16 fragment set the training step's Linear layers need, from the fp32 master weights in ONE launch (the weights change
  * once per step, in optimizer.step()): job j packs src (n x k row-major, transposed = 0: as syn_pack_weight; k x n row-major,

@@ -1744,13 +1744,13 @@ int launch_conv_train(const wav::TArgs& a0, int n_clips, hipStream_t s, int n_ou
     return e == hipSuccess ? 0 : fail("k_conv_train launch", e);
 }
 
-template <int CO_T, int TAPS>
+template <int CO_T, int TAPS, bool DUAL = false>
 int launch_wgrad_s(const wav::WArgs& a0, hipStream_t s) {
     wav::WArgs a = a0; a.terms = conv_terms(true); a.dbg = g_dbg_attn;
     static_assert(wav::wgrad_s_lds(CO_T) <= 160 * 1024, "dy and x' tiles must fit the LDS");
     static OncePerDevice once;
-    if (once.first()) { allow_lds(wav::k_conv_wgrad_s<CO_T, TAPS>, wav::wgrad_s_lds(CO_T)); }
-    hipLaunchKernelGGL((wav::k_conv_wgrad_s<CO_T, TAPS>), dim3(a.cin / wav::kWsJ, a.shares, a.co_n / CO_T), dim3(512), wav::wgrad_s_lds(CO_T), s, a);
+    if (once.first()) { allow_lds(wav::k_conv_wgrad_s<CO_T, TAPS, DUAL>, wav::wgrad_s_lds(CO_T)); }
+    hipLaunchKernelGGL((wav::k_conv_wgrad_s<CO_T, TAPS, DUAL>), dim3(a.cin / wav::kWsJ, a.shares, DUAL ? 1 : a.co_n / CO_T), dim3(512), wav::wgrad_s_lds(CO_T), s, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("k_conv_wgrad_s launch", e);
 }
@@ -2896,7 +2896,7 @@ static int conv_train_wgrad_impl(const float* x, const float* dy, int32_t n_clip
     a.GY = dy; a.gy_clip_stride = (long)l_out * cout; a.L_out = l_out; a.X = x; a.x_clip_stride = (long)l_in * cin; a.x_elems = (long)l_in * cin;
     a.cin = cinp; a.co_n = cout; a.n_clips = n_clips; a.chunks_per_clip = (l_out + wav::kWgP - 1) / wav::kWgP; a.row0 = stride == 1 ? -7 : 0;
     a.shares = syn_conv1d_wgrad_shares(n_clips, l_out, cinp, cout); a.part = ws;
-    a.in_aff = in_affine; a.in_act = in_act;
+    a.in_aff = in_affine; a.in_act = in_act; a.GY2 = nullptr;
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (cout == 64 && taps == 15 && wgrad64_two_slices(l_out)) rc = launch_wgrad_tiled<64, 15, 2>(a, s);
@@ -2923,6 +2923,22 @@ int syn_conv1d_train_wgrad_norm(const float* x, const float* dy, int32_t n_clips
                                 int32_t cout, const float* in_affine, int32_t in_act, float* ws, float* dw, void* stream) {
     if (!in_affine) return fail_msg("syn_conv1d_train_wgrad_norm: in_affine is NULL (use syn_conv1d_train_wgrad)");
     return conv_train_wgrad_impl(x, dy, n_clips, l_in, cin, stride, pad, cout, in_affine, in_act, ws, dw, stream);
+}
+
+/* conv1 and the shortcut convolution of a down-sampling block (same input, same geometry): both weight gradients' partial sums from ONE launch that stages the
+ * input once (k_conv_wgrad_s<128, 3, true>: the tile's two halves are the two dy).  (64, 6, 64) only - block 1, whose input is the encoder's largest tensor. */
+int syn_conv1d_train_wgrad_pair(const float* x, const float* dy_a, const float* dy_b, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad,
+                                int32_t cout, float* ws, void* stream) {
+    if (!x || !dy_a || !dy_b || !ws || n_clips <= 0 || l_in <= 0) return fail_msg("syn_conv1d_train_wgrad_pair: bad arguments");
+    if (!(cin == 64 && stride == 6 && pad == 0 && cout == 64)) return fail_msg("syn_conv1d_train_wgrad_pair: the (64, stride 6, 64) layer pair only (block 1 of the audio encoder)");
+    const int l_out = (l_in - 15) / stride + 1, cinp = stride * cin;
+    if (l_out <= 0) return fail_msg("syn_conv1d_train_wgrad_pair: input shorter than the kernel");
+    wav::WArgs a;
+    a.GY = dy_a; a.GY2 = dy_b; a.gy_clip_stride = (long)l_out * cout; a.L_out = l_out; a.X = x; a.x_clip_stride = (long)l_in * cin; a.x_elems = (long)l_in * cin;
+    a.cin = cinp; a.co_n = cout; a.n_clips = n_clips; a.chunks_per_clip = (l_out + wav::kWgP - 1) / wav::kWgP; a.row0 = 0;
+    a.shares = syn_conv1d_wgrad_shares(n_clips, l_out, cinp, cout); a.part = ws;          // (3 slices, as for one of the two: ws holds shares x 2 gradients)
+    a.in_aff = nullptr; a.in_act = 0;
+    return launch_wgrad_s<128, 3, true>(a, (hipStream_t)stream);
 }
 
 // workgroups of the persistent first-layer weight gradient (k_conv_first_wgrad_m): four per CU once there is that much work, never more than there are
@@ -3018,6 +3034,8 @@ int syn_conv1d_wgrad_sums(const syn_wgrad_sum_job* jobs, int32_t n_jobs, void* s
             J.kind = 0; J.taps = (15 + q.stride - 1) / q.stride; J.shares = syn_conv1d_wgrad_shares(q.n_clips, q.l_out, q.stride * q.cin, q.cout);
             J.per = q.cout * J.taps * q.stride * q.cin;
         }
+        J.pitch = q.share_pitch > 0 ? q.share_pitch : J.per;
+        if (J.pitch < J.per || J.pitch % 4) return fail_msg("syn_conv1d_wgrad_sums: share_pitch must be 0 or a multiple of 4 not below the gradient's size");
         blocks += (J.per / 4 + 31) / 32;
     }
     a.n = n_jobs;

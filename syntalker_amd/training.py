@@ -1273,13 +1273,35 @@ def _wb_wgrad(x3, dy3, conv, first, in_aff=None, in_act=0, sums=None):
     return gw
 
 
+def _wb_wgrad_pair(x3, dy_a, dy_b, conv_a, conv_b, sums):
+    """conv1's and the shortcut convolution's weight gradients of block 1 ((64, stride 6, 64), unpadded: the same 117 MB input) from one launch that stages the
+    input once (`syn_conv1d_train_wgrad_pair`); None where the pair kernel does not apply.  Partial sums only: two jobs appended to `sums`."""
+    n, l_in, cin = x3.shape
+    key = lambda c: (c.in_channels, c.stride[0], c.padding[0], c.out_channels)
+    if not (key(conv_a) == key(conv_b) == (64, 6, 0, 64) and cin == 64):
+        return None
+    lib, dev = _lib.load(), x3.device
+    l_out = dy_a.shape[1]
+    per = 64 * 18 * 64                                            # cout x (ceil(15 / 6) x 6 taps) x cin
+    ws = torch.empty(lib.syn_conv1d_wgrad_shares(n, l_out, 6 * 64, 64) * 2 * per, device=dev, dtype=torch.float32)
+    ga, gb = _grad_out(conv_a.weight, (64, 64, 15)), _grad_out(conv_b.weight, (64, 64, 15))
+    _conv_terms(2)
+    _lib.check(lib.syn_conv1d_train_wgrad_pair(x3.data_ptr(), dy_a.data_ptr(), dy_b.data_ptr(), n, l_in, 64, 6, 0, 64, ws.data_ptr(), _lib.current_stream(dev)),
+               "syn_conv1d_train_wgrad_pair")
+    _conv_terms_done()
+    sums.append((ws, ga, n, l_out, 64, 6, 64, 0, 2 * per))
+    sums.append((ws[per:], gb, n, l_out, 64, 6, 64, 0, 2 * per))
+    return ga, gb
+
+
 def _wb_wgrad_sums(sums, device):
     """The partial-sum reductions of a block's weight gradients as one launch (`syn_conv1d_wgrad_sums`)."""
     if not sums:
         return
     arr = (_lib.SynWgradSumJob * len(sums))()
-    for i, (ws, gw, n, l_out, cin, stride, cout, first) in enumerate(sums):
+    for i, (ws, gw, n, l_out, cin, stride, cout, first, *pitch) in enumerate(sums):
         arr[i].part, arr[i].dw, arr[i].n_clips, arr[i].l_out, arr[i].cin, arr[i].stride, arr[i].cout, arr[i].first_layer = ws.data_ptr(), gw.data_ptr(), n, l_out, cin, stride, cout, first
+        arr[i].share_pitch = pitch[0] if pitch else 0            # (a share that holds two gradients: `_wb_wgrad_pair`)
     _lib.check(_lib.load().syn_conv1d_wgrad_sums(arr, len(sums), _lib.current_stream(device)), "syn_conv1d_wgrad_sums")
     sums.clear()
 
@@ -1388,7 +1410,11 @@ class WavBlockFn(torch.autograd.Function):
             dy1 = torch.empty_like(y1)
             _lib.check(lib.syn_bn_act_bwd(dz1.data_ptr(), None, y1.data_ptr(), st1.data_ptr(), g1.data_ptr(), b1.data_ptr(), rows, c, 1, ws1.data_ptr(),
                                           dgb1.data_ptr(), dy1.data_ptr(), None, _lib.current_stream(dev)), "syn_bn_act_bwd")
-            gw1 = _wb_wgrad(x3, dy1, blk.conv1, first, sums=sums)
+            pair = _wb_wgrad_pair(x3, dy1, dsh, blk.conv1, blk.downsample[0], sums) if (ds and not first) else None
+            if pair is not None:
+                gw1, gws = pair
+            else:
+                gw1 = _wb_wgrad(x3, dy1, blk.conv1, first, sums=sums)
         dx = None
         if not first and ctx.needs_input_grad[0]:
             # what reaches the block's input, written once: conv1^T dy1 + (shortcut^T dy_sc | the gradient along the identity shortcut)

@@ -1014,6 +1014,38 @@ def test_first_layer_weight_gradient_at_the_bench_shape_vs_fp64(n, L, fold):
     assert e < 1e-5
 
 
+@pytest.mark.parametrize("n,L", [(32, 13437), (5, 2000)])
+def test_paired_strided_weight_gradients_equal_two_single_launches(n, L):
+    """syn_conv1d_train_wgrad_pair (round 6): conv1's and the shortcut convolution's weight gradients of block 1 from one launch that stages their common input
+    once (the tile's two halves are the two dy; a share of the partial sums holds both gradients).  Same shares, same chunk order, same products: bit-equal to
+    the two single launches."""
+    from syntalker_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + L)
+    cin, stride, cout = 64, 6, 64
+    l_out = (L - 15) // stride + 1
+    x = torch.randn(n, L, cin, generator=g).cuda()
+    dya, dyb = torch.randn(n, l_out, cout, generator=g).cuda(), torch.randn(n, l_out, cout, generator=g).cuda()
+    st = _lib.current_stream(x.device)
+    shares, per = lib.syn_conv1d_wgrad_shares(n, l_out, stride * cin, cout), cout * 18 * cin
+    singles = []
+    for dy in (dya, dyb):
+        ws, dw = torch.empty(shares * per, device="cuda"), torch.empty(cout, cin, 15, device="cuda")
+        _lib.check(lib.syn_conv1d_train_wgrad(x.data_ptr(), dy.data_ptr(), n, L, cin, stride, 0, cout, ws.data_ptr(), dw.data_ptr(), st), "syn_conv1d_train_wgrad")
+        singles.append(dw)
+    ws = torch.empty(shares * 2 * per, device="cuda")
+    _lib.check(lib.syn_conv1d_train_wgrad_pair(x.data_ptr(), dya.data_ptr(), dyb.data_ptr(), n, L, cin, stride, 0, cout, ws.data_ptr(), st), "syn_conv1d_train_wgrad_pair")
+    outs = [torch.empty(cout, cin, 15, device="cuda") for _ in range(2)]
+    jobs = (_lib.SynWgradSumJob * 2)()
+    for i in range(2):
+        jobs[i].part, jobs[i].dw, jobs[i].n_clips, jobs[i].l_out, jobs[i].cin, jobs[i].stride, jobs[i].cout, jobs[i].first_layer = ws.data_ptr() + 4 * per * i, outs[i].data_ptr(), n, l_out, cin, stride, cout, 0
+        jobs[i].share_pitch = 2 * per
+    _lib.check(lib.syn_conv1d_wgrad_sums(jobs, 2, st), "syn_conv1d_wgrad_sums")
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], singles[0]) and torch.equal(outs[1], singles[1])
+    assert lib.syn_conv1d_train_wgrad_pair(x.data_ptr(), dya.data_ptr(), dyb.data_ptr(), n, L, cin, 3, 0, cout, ws.data_ptr(), st) != 0      # (block 1's geometry only)
+
+
 @pytest.mark.parametrize("n,L", [(32, 68266), (3, 20011)])
 def test_block0_backward_tail_folded_into_the_shortcut_weight_gradient(n, L):
     """syn_conv1d_first_wgrad_tail (round 6): block 0's tail backward (both BatchNorms' data gradients from dout, y2, y_sc) and the shortcut convolution's
