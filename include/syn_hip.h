@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 #define SYN_ABI_VERSION 9     /* 9: syn_conv1d_wgrad_shares takes the layer's output channels (the share count follows the number of gradient slices a layer is cut in);
-                                * syn_conv1d_first_wgrad_tail, syn_bn_block_bwd with dy = NULL, syn_conv1d_train_wgrad_pair, syn_wgrad_sum_job.share_pitch;
+                                * syn_conv1d_first_wgrad_tail, syn_bn_block_bwd with dy = NULL, syn_conv1d_train_wgrad_pair, syn_wgrad_sum_job.share_pitch, syn_conv1d_first_wgrad_bn_lin;
                                 * 8: the seams of the training step (syn_rows_concat_bf16, syn_embed_rows_bf16, syn_bct_to_rows_bf16, syn_rows_group_sum, syn_touch,
                                 * syn_masked_smooth_l1 / _grad on the output Linear's rows), syn_linear_bwd_prep reads a strided / row-repeated dy, syn_pack_job.src_dim,
                                 * syn_linear_pair on 128-column tiles, syn_embedding_wgrad ld; superseded kernels and their switches removed;
@@ -210,6 +210,12 @@ int syn_conv1d_first_fwd2(const float* x, int32_t n_clips, int32_t l_in, int32_t
  * dp = dz act'(a(y)), is formed as the values are loaded and never written.  stride 5 (the encoder's). */
 int syn_conv1d_first_wgrad_bn(const float* x, const float* dz, const float* y, const float* stats, const float* affine, const float* dgamma_dbeta,
                               int32_t act, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws, float* dw, void* stream);
+/* (ABI 9) Block 0's conv1: its weight gradient AND bn1's backward sums from ONE pass over (dz, y) - the BatchNorm backward is linear in dgamma / dbeta and only a
+ * reduction consumes dy here (the waveform takes no gradient): dW = scale (S1 - dbeta / M S2 - dgamma / M S3) with S1 = sum dp win, S2 = sum win, S3 = sum xhat win
+ * accumulated side by side.  Replaces syn_bn_bwd_stats + syn_conv1d_first_wgrad_bn (a second read of both tensors).  dw [64][cin][15] and dgamma_dbeta [3][64] are
+ * written by this call (no partial sums left for syn_conv1d_wgrad_sums); ws: syn_conv1d_first_parts(n_clips, l_out) * (2 * 64 * cin * 15 + 160) floats.  stride 5. */
+int syn_conv1d_first_wgrad_bn_lin(const float* x, const float* dz, const float* y, const float* stats, const float* affine, int32_t act,
+                                  int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws, float* dw, float* dgamma_dbeta, void* stream);
 /* (ABI 9) Block 0's SHORTCUT convolution: its weight-gradient partial sums (ws as syn_conv1d_first_wgrad) with the block tail's backward folded into the loads -
  * dout = the gradient at the block's output, y2 / y_short the raw outputs of conv2 and of the shortcut convolution with the statistics, affines and
  * [dgamma | dbeta | 0] of their BatchNorms (syn_bn_block_bwd with dy = NULL leaves exactly those).  d = dout act'(a2(y2) + a_s(y_short)); the shortcut's

@@ -2943,9 +2943,9 @@ int syn_conv1d_train_wgrad_pair(const float* x, const float* dy_a, const float* 
 
 // workgroups of the persistent first-layer weight gradient (k_conv_first_wgrad_m): four per CU once there is that much work, never more than there are
 // 64-pair work items per workgroup
-static int first_wgrad_groups(int n_clips, int l_out) {
+static int first_wgrad_groups(int n_clips, int l_out, int per_cu = 4) {
     const long pairs = (long)n_clips * ((l_out + 1) / 2);
-    const long want = 4L * device_cus(), by_work = (pairs + 255) / 256;      // (1 / 2 / 4 / 8 per CU at the bench shape: 190 / 123 / 108 / 107 us for the two launches)
+    const long want = (long)per_cu * device_cus(), by_work = (pairs + 255) / 256;      // (1 / 2 / 4 / 8 per CU at the bench shape: 190 / 123 / 108 / 107 us for the two launches)
     return (int)(by_work < 1 ? 1 : by_work < want ? by_work : want);
 }
 int32_t syn_conv1d_first_parts(int32_t n_clips, int32_t l_out) {
@@ -3053,6 +3053,27 @@ int syn_conv1d_first_wgrad_bn(const float* x, const float* dz, const float* y, c
                               int32_t act, int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws, float* dw, void* stream) {
     if (!y) return fail_msg("syn_conv1d_first_wgrad_bn: y is NULL (use syn_conv1d_first_wgrad)");
     return first_wgrad_impl(x, dz, y, stats, affine, dgamma_dbeta, act, n_clips, l_in, cin, stride, pad, ws, dw, stream);
+}
+
+int syn_conv1d_first_wgrad_bn_lin(const float* x, const float* dz, const float* y, const float* stats, const float* affine, int32_t act,
+                                  int32_t n_clips, int32_t l_in, int32_t cin, int32_t stride, int32_t pad, float* ws, float* dw, float* dgamma_dbeta, void* stream) {
+    wav::FArgs a;
+    if (!dz || !y || !stats || !affine || !ws || !dw || !dgamma_dbeta) return fail_msg("syn_conv1d_first_wgrad_bn_lin: null pointer");
+    if (int rc = first_layer_args(a, x, n_clips, l_in, cin, stride, pad, "syn_conv1d_first_wgrad_bn_lin: bad arguments (cin 1 | 2, 64 output channels)")) return rc;
+    if (stride != 5) return fail_msg("syn_conv1d_first_wgrad_bn_lin: stride 5 (the encoder's)");
+    a.DY = dz; a.BY = y; a.bn_stats = stats; a.bn_aff = affine; a.bn_act = act; a.part = ws;
+    hipStream_t s = (hipStream_t)stream;
+    const int groups = first_wgrad_groups(n_clips, a.L_out, 3);      // (64 accumulator + 73 other registers: three waves per SIMD - a fourth workgroup per CU would run in a second round)
+    const float inv_rows = 1.0f / ((float)n_clips * (float)a.L_out);
+    if (cin == 1) {
+        hipLaunchKernelGGL(wav::k_conv_first_wgrad_lin<1>, dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
+        hipLaunchKernelGGL(wav::k_conv_first_wgrad_lin_fin<1>, dim3(64), dim3(1024), 0, s, (const float*)ws, groups, affine, inv_rows, dw, dgamma_dbeta);
+    } else {
+        hipLaunchKernelGGL(wav::k_conv_first_wgrad_lin<2>, dim3(groups), dim3(wav::kF1mWaves * 64), 0, s, a);
+        hipLaunchKernelGGL(wav::k_conv_first_wgrad_lin_fin<2>, dim3(64), dim3(1024), 0, s, (const float*)ws, groups, affine, inv_rows, dw, dgamma_dbeta);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : fail("k_conv_first_wgrad_lin launch", e);
 }
 
 int syn_conv1d_first_wgrad_tail(const float* x, const float* dout, const float* y2, const float* y_short, const float* stats2, const float* affine2,

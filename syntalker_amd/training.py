@@ -1395,16 +1395,15 @@ class WavBlockFn(torch.autograd.Function):
         g1, b1 = blk.bn1.weight.detach(), blk.bn1.bias.detach()
         if first and blk.conv1.stride[0] == 5:
             # block 0: nothing but conv1's weight gradient reads dy1 (the waveform takes no gradient) - it forms dy1 itself from (dz1, y1)
-            _lib.check(lib.syn_bn_bwd_stats(dz1.data_ptr(), None, y1.data_ptr(), st1.data_ptr(), g1.data_ptr(), b1.data_ptr(), rows, c, 1, ws1.data_ptr(),
-                                            dgb1.data_ptr(), _lib.current_stream(dev)), "syn_bn_bwd_stats")
+            # ... and linear in bn1's two backward sums: ONE pass over (dz1, y1) accumulates the gradient's three terms and the sums side by side
+            # (`syn_conv1d_first_wgrad_bn_lin`; a statistics pass and a second read of both 117 MB tensors before)
             cv = blk.conv1
             nn_, l_in, cin = x3.shape
-            wsg = torch.empty(lib.syn_conv1d_first_parts(nn_, l1) * 64 * cin * 15, device=dev, dtype=torch.float32)
+            wsg = torch.empty(lib.syn_conv1d_first_parts(nn_, l1) * (2 * 64 * cin * 15 + 160), device=dev, dtype=torch.float32)
             gw1 = _grad_out(cv.weight, (64, cin, 15))
-            _lib.check(lib.syn_conv1d_first_wgrad_bn(x3.data_ptr(), dz1.data_ptr(), y1.data_ptr(), st1.data_ptr(), af1.data_ptr(), dgb1.data_ptr(), 1,
-                                                     nn_, l_in, cin, cv.stride[0], cv.padding[0], wsg.data_ptr(), None, _lib.current_stream(dev)),
-                       "syn_conv1d_first_wgrad_bn")
-            sums.append((wsg, gw1, nn_, l1, cin, cv.stride[0], 64, 1))
+            _lib.check(lib.syn_conv1d_first_wgrad_bn_lin(x3.data_ptr(), dz1.data_ptr(), y1.data_ptr(), st1.data_ptr(), af1.data_ptr(), 1, nn_, l_in, cin,
+                                                         cv.stride[0], cv.padding[0], wsg.data_ptr(), gw1.data_ptr(), dgb1.data_ptr(), _lib.current_stream(dev)),
+                       "syn_conv1d_first_wgrad_bn_lin")
             dy1 = None
         else:
             dy1 = torch.empty_like(y1)

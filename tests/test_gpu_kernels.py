@@ -1014,6 +1014,51 @@ def test_first_layer_weight_gradient_at_the_bench_shape_vs_fp64(n, L, fold):
     assert e < 1e-5
 
 
+@pytest.mark.parametrize("n,L", [(32, 68266), (3, 20011)])
+def test_block0_conv1_weight_gradient_and_bn1_sums_in_one_pass(n, L):
+    """syn_conv1d_first_wgrad_bn_lin (round 6): dW of block 0's conv1 = scale (S1 - dbeta / M S2 - dgamma / M S3) with the three sums and bn1's dbeta / dgamma
+    accumulated in ONE pass over (dz, y) - against the two passes it replaces (syn_bn_bwd_stats, then syn_conv1d_first_wgrad_bn with the finished sums) and against
+    float64.  The subtraction is where accuracy could go: the waveform here has a DC offset (S2 far from zero) and dz a per-channel mean (dbeta far from zero)."""
+    from syntalker_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n + L)
+    cin, stride, pad, C = 2, 5, 1700, 64
+    l_out = (L + 2 * pad - 15) // stride + 1
+    rows = n * l_out
+    x = (torch.randn(n, L, cin, generator=g) + 0.3).cuda()
+    y = torch.randn(n, l_out, C, generator=g).cuda()
+    dz = (torch.randn(n, l_out, C, generator=g) + 0.2 * torch.randn(C, generator=g)).cuda()
+    mu, rs = torch.randn(C, generator=g).cuda() * 0.1, torch.rand(C, generator=g).cuda() + 0.5
+    gam, bet = torch.rand(C, generator=g).cuda() + 0.5, torch.randn(C, generator=g).cuda() * 0.3
+    stats, aff = torch.cat([mu, rs]).contiguous(), torch.cat([rs * gam, bet - mu * rs * gam]).contiguous()
+    st = _lib.current_stream(x.device)
+    parts = lib.syn_conv1d_first_parts(n, l_out)
+    # two passes
+    ws1, dgb_a = torch.empty(2 * lib.syn_bn_chunks(rows) * C, device="cuda"), torch.empty(3, C, device="cuda")
+    _lib.check(lib.syn_bn_bwd_stats(dz.data_ptr(), None, y.data_ptr(), stats.data_ptr(), gam.data_ptr(), bet.data_ptr(), rows, C, 1, ws1.data_ptr(), dgb_a.data_ptr(), st), "syn_bn_bwd_stats")
+    wsa, dwa = torch.empty(parts * C * cin * 15, device="cuda"), torch.empty(C, cin, 15, device="cuda")
+    _lib.check(lib.syn_conv1d_first_wgrad_bn(x.data_ptr(), dz.data_ptr(), y.data_ptr(), stats.data_ptr(), aff.data_ptr(), dgb_a.data_ptr(), 1, n, L, cin, stride, pad,
+                                             wsa.data_ptr(), dwa.data_ptr(), st), "syn_conv1d_first_wgrad_bn")
+    # one pass
+    wsb, dwb, dgb_b = torch.empty(parts * (2 * C * cin * 15 + 160), device="cuda"), torch.empty(C, cin, 15, device="cuda"), torch.empty(3, C, device="cuda")
+    _lib.check(lib.syn_conv1d_first_wgrad_bn_lin(x.data_ptr(), dz.data_ptr(), y.data_ptr(), stats.data_ptr(), aff.data_ptr(), 1, n, L, cin, stride, pad,
+                                                 wsb.data_ptr(), dwb.data_ptr(), dgb_b.data_ptr(), st), "syn_conv1d_first_wgrad_bn_lin")
+    torch.cuda.synchronize()
+    D = lambda t: t.double()
+    m = float(rows)
+    xh = (D(y) - D(mu)) * D(rs)
+    dp = torch.where(D(y) * D(aff[:C]) + D(aff[C:]) > 0, D(dz), 0.01 * D(dz))
+    dbeta, dgamma = dp.sum((0, 1)), (dp * xh).sum((0, 1))
+    dy = D(aff[:C]) * (dp - dbeta / m - xh * dgamma / m)
+    x4 = x.permute(0, 2, 1).unsqueeze(2).double()
+    want = torch.nn.grad.conv2d_weight(x4, (C, cin, 1, 15), dy.permute(0, 2, 1).unsqueeze(2).contiguous(), stride=(1, stride), padding=(0, pad)).squeeze(2)
+    ea, eb = rel_l2(dwa.double().cpu(), want.cpu()), rel_l2(dwb.double().cpu(), want.cpu())
+    eg = max(rel_l2(dgb_b[0].double().cpu(), dgamma.cpu()), rel_l2(dgb_b[1].double().cpu(), dbeta.cpu()))
+    print(f"block 0 conv1, {n} clips: dW vs float64 - two passes {ea:.2e}, one pass {eb:.2e}; dgamma / dbeta {eg:.2e}")
+    assert eb < 1e-5 and eg < 1e-5 and float(dgb_b[2].abs().max()) == 0.0
+    assert rel_l2(dgb_b[:2].cpu(), dgb_a[:2].cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("n,L", [(32, 13437), (5, 2000)])
 def test_paired_strided_weight_gradients_equal_two_single_launches(n, L):
     """syn_conv1d_train_wgrad_pair (round 6): conv1's and the shortcut convolution's weight gradients of block 1 from one launch that stages their common input
