@@ -669,12 +669,23 @@ __global__ __launch_bounds__(kThreads) void k_gemm_pair(const GPair p) {
     else gemm_body<MT, EPI_PLAIN, MODE == 1>(p.g[z], blockIdx.x, blockIdx.y);
 }
 
-// Four independent plain GEMMs in one launch on MT x 128 tiles: the weight gradients of one transformer block (syn_train_stack_wgrad)
-struct GQuad { GArgs g[4]; int gx[4], gy[4]; };
-__global__ __launch_bounds__(kThreads) void k_gemm_quad(const GQuad p) {
-    const int z = blockIdx.z;
-    if ((int)blockIdx.x >= p.gx[z] || (int)blockIdx.y >= p.gy[z]) return;
-    gemm_n128(p.g[z], blockIdx.x, blockIdx.y);
+// Independent plain GEMMs in one launch on MT x 128 tiles: the four weight gradients of EVERY transformer block (syn_train_stack_wgrad; r5: a launch per block).
+// The weight gradients of all eight blocks are open at once when the backward chain kernel
+// has finished, and a block's quad launch is one round of ~256 workgroups - eight launches were eight rounds with a tail and a boundary each.  A 1-d grid
+// without empty workgroups: id -> (block, GEMM, tile); with a multiple of 8 workgroups the ids are dealt so that an XCD's workgroups are NEIGHBOURS in
+// (GEMM, tile) order - tiles along x share their 128-column operand slab in that XCD's L2.
+struct GQuadAll { const __bf16* X[SYN_LAYERS][4]; const uint4* W[SYN_LAYERS][4]; float* Y[SYN_LAYERS][4]; int ns[4], ks[4], mt[4], gx[4], cum[5], M, l0; };
+__global__ __launch_bounds__(kThreads) void k_gemm_quad_all(const GQuadAll p) {
+    const int total = gridDim.x;
+    int b = blockIdx.x;
+    if (total % 8 == 0) b = (b & 7) * (total >> 3) + (b >> 3);
+    const int per = p.cum[4], l = p.l0 + b / per, r = b % per;
+    int i = 0;
+    while (r >= p.cum[i + 1]) ++i;
+    const int loc = r - p.cum[i], bx = loc % p.gx[i], by = loc / p.gx[i];
+    GArgs a = {};
+    a.X = p.X[l][i]; a.ldx = p.M; a.x_rows = p.ns[i]; a.W = p.W[l][i]; a.K = p.M; a.M = p.ns[i]; a.Yf = p.Y[l][i]; a.ldyf = p.ks[i]; a.mt128 = p.mt[i];
+    gemm_n128(a, bx, by);
 }
 
 // A forward GEMM of the training step fills a quarter to three quarters of the chip (16-row tiles x n / 512 columns), and the
@@ -1631,7 +1642,7 @@ void n128_setup() {
         allow_lds(k_gemm_n128, kN128Lds);
         allow_lds(k_gemm_pair<16, 2>, kN128Lds);
         allow_lds(k_gemm_and_pack<16, 2>, kN128Lds);
-        allow_lds(k_gemm_quad, kN128Lds);
+        allow_lds(k_gemm_quad_all, kN128Lds);
     }
 }
 
@@ -2362,32 +2373,33 @@ int syn_train_stack_wgrad(const syn_train_stack_grad* t, void* stream) {
     stk::SmallOut so;
     memset(&so, 0, sizeof(so));
     if (t->first_block < t->last_block || t->last_block < 0 || t->first_block >= SYN_LAYERS) return fail_msg("syn_train_stack_wgrad: SYN_LAYERS > first_block >= last_block >= 0");
+    GQuadAll q;
+    memset(&q, 0, sizeof(q));
+    const int ns[4] = {512, 1024, 512, 1536}, ks[4] = {1024, 512, 512, 512};           // dW [n][k]: fc2, fc1, proj, qkv
+    int lds = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int mt = pick_mt128(ns[i], ks[i], M, 8);                // (64-row tiles for all four: 126 us for 8 launches against 182 with proj on 32-row tiles)
+        if (!mt) return fail_msg("syn_train_stack_wgrad: row count too large for the resident GEMM");
+        q.ns[i] = ns[i]; q.ks[i] = ks[i]; q.mt[i] = mt; q.gx[i] = (ns[i] + mt - 1) / mt;
+        q.cum[i + 1] = q.cum[i] + q.gx[i] * (ks[i] / 128);
+        lds = mt * M * 2 > lds ? mt * M * 2 : lds;
+    }
+    q.M = M; q.l0 = t->last_block;
     for (int l = t->last_block; l <= t->first_block; ++l) {
         const syn_train_block_save& S = f.save[l];
         const syn_train_block_grad& G = t->grad[l];
         if (!G.dw_fc2 || !G.dw_fc1 || !G.dw_proj || !G.dw_qkv || !G.d_ln2_g || !G.d_ln2_b || !G.d_fc2_b || !G.d_fc1_b || !G.d_ln1_g || !G.d_ln1_b || !G.d_proj_b) return fail_msg("syn_train_stack_wgrad: a block's gradient buffers are incomplete");
-        GQuad q;
-        memset(&q, 0, sizeof(q));
         const void* xs[4] = {G.dyt_fc2, G.dyt_fc1, G.dyt_proj, G.dyt_qkv};
         const void* ws[4] = {S.xt_gelu, S.xt_ln2, S.xt_attn, S.xt_ln1};
-        const int ns[4] = {512, 1024, 512, 1536}, ks[4] = {1024, 512, 512, 512};       // dW [n][k]
         float* ys[4] = {G.dw_fc2, G.dw_fc1, G.dw_proj, G.dw_qkv};
-        int gx = 0, gy = 0, lds = 0;
-        for (int i = 0; i < 4; ++i) {
-            GArgs& a = q.g[i];
-            a.X = (const __bf16*)xs[i]; a.ldx = M; a.x_rows = ns[i]; a.W = (const uint4*)ws[i]; a.K = M; a.M = ns[i]; a.Yf = ys[i]; a.ldyf = ks[i];
-            const int mt = pick_mt128(ns[i], ks[i], M, 8);            // (64-row tiles for all four: 126 us for the 8 launches against 182 with proj on 32-row tiles)
-            if (!mt) return fail_msg("syn_train_stack_wgrad: row count too large for the resident GEMM");
-            a.mt128 = mt; q.gx[i] = (ns[i] + mt - 1) / mt; q.gy[i] = ks[i] / 128;
-            gx = q.gx[i] > gx ? q.gx[i] : gx; gy = q.gy[i] > gy ? q.gy[i] : gy;
-            lds = mt * M * 2 > lds ? mt * M * 2 : lds;
-        }
-        hipLaunchKernelGGL(k_gemm_quad, dim3(gx, gy, 4), dim3(kThreads), lds, s, q);
+        for (int i = 0; i < 4; ++i) { q.X[l][i] = (const __bf16*)xs[i]; q.W[l][i] = (const uint4*)ws[i]; q.Y[l][i] = ys[i]; }
         // bias / LayerNorm gradients: column sums over the sequences, in sequence order
         float* const outs[7] = {G.d_ln2_g, G.d_ln2_b, G.d_fc2_b, G.d_fc1_b, G.d_ln1_g, G.d_ln1_b, G.d_proj_b};
         so.part[l] = G.part;
         for (int i = 0; i < 7; ++i) so.p[l][i] = outs[i];
     }
+    // every block's four weight-gradient GEMMs in ONE launch (k_gemm_quad_all)
+    hipLaunchKernelGGL(k_gemm_quad_all, dim3(q.cum[4] * (t->first_block - t->last_block + 1)), dim3(kThreads), lds, s, q);
     hipLaunchKernelGGL(stk::k_part_sums, dim3((stk::kPartCols + 255) / 256, t->first_block - t->last_block + 1), dim3(256), 0, s, f.n_seq, t->last_block, so);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : fail("syn_train_stack_wgrad", e);
