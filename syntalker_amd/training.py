@@ -1390,13 +1390,10 @@ class WavBlockFn(torch.autograd.Function):
         dz1 = _wb_dgrad(dy2, blk.conv2, l1)
         gw2 = _wb_wgrad(y1, dy2, blk.conv2, False, in_aff=af1, in_act=1, sums=sums)
         # bn1 + activation (no shortcut entered it: the sign comes from y1)
-        ws1 = torch.empty(2 * lib.syn_bn_chunks(rows) * c, device=dev, dtype=torch.float32)
         dgb1 = torch.empty(3, c, device=dev, dtype=torch.float32)
-        g1, b1 = blk.bn1.weight.detach(), blk.bn1.bias.detach()
         if first and blk.conv1.stride[0] == 5:
-            # block 0: nothing but conv1's weight gradient reads dy1 (the waveform takes no gradient) - it forms dy1 itself from (dz1, y1)
-            # ... and linear in bn1's two backward sums: ONE pass over (dz1, y1) accumulates the gradient's three terms and the sums side by side
-            # (`syn_conv1d_first_wgrad_bn_lin`; a statistics pass and a second read of both 117 MB tensors before)
+            # block 0: nothing but conv1's weight gradient reads dy1 (the waveform takes no gradient), and the BatchNorm backward is linear in bn1's two sums:
+            # ONE pass over (dz1, y1) accumulates the gradient's three terms and the sums side by side (`syn_conv1d_first_wgrad_bn_lin`)
             cv = blk.conv1
             nn_, l_in, cin = x3.shape
             wsg = torch.empty(lib.syn_conv1d_first_parts(nn_, l1) * (2 * 64 * cin * 15 + 160), device=dev, dtype=torch.float32)
@@ -1407,6 +1404,8 @@ class WavBlockFn(torch.autograd.Function):
             dy1 = None
         else:
             dy1 = torch.empty_like(y1)
+            ws1 = torch.empty(2 * lib.syn_bn_chunks(rows) * c, device=dev, dtype=torch.float32)
+            g1, b1 = blk.bn1.weight.detach(), blk.bn1.bias.detach()
             _lib.check(lib.syn_bn_act_bwd(dz1.data_ptr(), None, y1.data_ptr(), st1.data_ptr(), g1.data_ptr(), b1.data_ptr(), rows, c, 1, ws1.data_ptr(),
                                           dgb1.data_ptr(), dy1.data_ptr(), None, _lib.current_stream(dev)), "syn_bn_act_bwd")
             pair = _wb_wgrad_pair(x3, dy1, dsh, blk.conv1, blk.downsample[0], sums) if (ds and not first) else None
