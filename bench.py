@@ -421,7 +421,7 @@ def run_train(args, rank, local, world, dev, dist):
             "loss": round(loss, 5), "step_split": split,
             "roofline": {"bound": "mfma", "achieved": round(value / world * F_TRAIN / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                          "frac": round(value / world * F_TRAIN / PEAK_BF16, 4), "traffic": None,
-                         "note": "whole step (~180 launches, the largest 9 % of it: profiles/r06_train_step_split.txt), F_train = 17.7 GFLOP per sample; no single dominant kernel"}}
+                         "note": "whole step (~170 launches, the largest 10 % of it: profiles/r06_train_step_split.txt), F_train = 17.7 GFLOP per sample; no single dominant kernel"}}
 
 
 def run_guided(args, rank, local, world, dev, dist):
@@ -592,7 +592,7 @@ def main():
     ap.add_argument("--prime", type=int, default=0, help="untimed 10-step replays in front of the --warmup steps (default 0: W is the only warm-up)")
     ap.add_argument("--train-graph", action=argparse.BooleanOptionalAction, default=None,
                     help="train mode: replay the whole step (incl. DDP's bucketed all-reduces) from one hipGraph; default on at every world size "
-                         "(the step is ~180 launches: issued from Python it is host-bound, 7-9 ms against 4.3 ms replayed); --no-train-graph = the eager step")
+                         "(the step is ~170 launches: issued from Python it is host-bound, 7-9 ms against 4.2 ms replayed); --no-train-graph = the eager step")
     ap.add_argument("--force-ddp", action="store_true",
                     help="train mode with one GPU: still wrap the model in DDP over a 1-rank RCCL process group, i.e. time the wrapper the multi-GPU run uses")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="process-group backend of a multi-rank run (nccl = RCCL; gloo: functional checks)")
