@@ -243,11 +243,17 @@ def test_c_abi_library_exports_every_declared_symbol():
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "sz.c")
-        open(src, "w").write('#include <stdio.h>\n#include "syn_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(syn_step), '
-                             'sizeof(syn_layer), sizeof(syn_model), sizeof(syn_wavenc), sizeof(syn_vq_model));return 0;}\n')
+        open(src, "w").write('#include <stdio.h>\n#include "syn_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu", sizeof(syn_step), '
+                             'sizeof(syn_layer), sizeof(syn_model), sizeof(syn_wavenc), sizeof(syn_vq_model));'
+                             'printf(" %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(syn_train_block_save), sizeof(syn_train_stack), sizeof(syn_train_block_grad), '
+                             'sizeof(syn_train_stack_grad), sizeof(syn_opt_list), sizeof(syn_concat_src), sizeof(syn_wgrad_sum_job), sizeof(syn_bn_finalize_job), '
+                             'sizeof(syn_conv_pack_req), sizeof(syn_wav_conv), sizeof(syn_cond_weights), sizeof(syn_vq_conv));return 0;}\n')
         subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), src, "-o", os.path.join(td, "sz")], check=True)
         sizes = [int(v) for v in subprocess.run([os.path.join(td, "sz")], capture_output=True, text=True, check=True).stdout.split()]
-    assert sizes == [ctypes.sizeof(c) for c in (_lib.SynStep, _lib.SynLayer, _lib.SynModel, _lib.SynWavEnc, _lib.SynVqModel)], sizes
+    mirrors = (_lib.SynStep, _lib.SynLayer, _lib.SynModel, _lib.SynWavEnc, _lib.SynVqModel, _lib.SynTrainBlockSave, _lib.SynTrainStack, _lib.SynTrainBlockGrad,
+               _lib.SynTrainStackGrad, _lib.SynOptList, _lib.SynConcatSrc, _lib.SynWgradSumJob, _lib.SynBnFinalizeJob, _lib.SynConvPackReq, _lib.SynWavConv,
+               _lib.SynCondWeights, _lib.SynVqConv)                    # every struct the ctypes bindings mirror (r6: syn_wgrad_sum_job grew a field)
+    assert sizes == [ctypes.sizeof(c) for c in mirrors], (sizes, [ctypes.sizeof(c) for c in mirrors])
     assert sizes[0] == 16 + 8 * 23 + 8 and sizes[2] == 8 * 5 + 88 * 8 + 16 + 24
 
 
