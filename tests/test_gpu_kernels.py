@@ -1014,15 +1014,15 @@ def test_first_layer_weight_gradient_at_the_bench_shape_vs_fp64(n, L, fold):
     assert e < 1e-5
 
 
-@pytest.mark.parametrize("n,L", [(32, 68266), (3, 20011)])
-def test_block0_conv1_weight_gradient_and_bn1_sums_in_one_pass(n, L):
+@pytest.mark.parametrize("n,L,cin", [(32, 68266, 2), (3, 20011, 2), (1, 977, 1)])
+def test_block0_conv1_weight_gradient_and_bn1_sums_in_one_pass(n, L, cin):
     """syn_conv1d_first_wgrad_bn_lin (round 6): dW of block 0's conv1 = scale (S1 - dbeta / M S2 - dgamma / M S3) with the three sums and bn1's dbeta / dgamma
     accumulated in ONE pass over (dz, y) - against the two passes it replaces (syn_bn_bwd_stats, then syn_conv1d_first_wgrad_bn with the finished sums) and against
     float64.  The subtraction is where accuracy could go: the waveform here has a DC offset (S2 far from zero) and dz a per-channel mean (dbeta far from zero)."""
     from syntalker_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(n + L)
-    cin, stride, pad, C = 2, 5, 1700, 64
+    stride, pad, C = 5, 1700, 64
     l_out = (L + 2 * pad - 15) // stride + 1
     rows = n * l_out
     x = (torch.randn(n, L, cin, generator=g) + 0.3).cuda()
@@ -1091,15 +1091,15 @@ def test_paired_strided_weight_gradients_equal_two_single_launches(n, L):
     assert lib.syn_conv1d_train_wgrad_pair(x.data_ptr(), dya.data_ptr(), dyb.data_ptr(), n, L, cin, 3, 0, cout, ws.data_ptr(), st) != 0      # (block 1's geometry only)
 
 
-@pytest.mark.parametrize("n,L", [(32, 68266), (3, 20011)])
-def test_block0_backward_tail_folded_into_the_shortcut_weight_gradient(n, L):
+@pytest.mark.parametrize("n,L,cin", [(32, 68266, 2), (3, 20011, 2), (1, 977, 1)])
+def test_block0_backward_tail_folded_into_the_shortcut_weight_gradient(n, L, cin):
     """syn_conv1d_first_wgrad_tail (round 6): block 0's tail backward (both BatchNorms' data gradients from dout, y2, y_sc) and the shortcut convolution's
     weight gradient as ONE kernel - dy2 written, the shortcut's dy fed straight into the matrix products.  Against the two-kernel path it replaces
     (syn_bn_block_bwd's apply pass, then syn_conv1d_first_wgrad on the stored dshortcut) and against float64."""
     from syntalker_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(n + L)
-    cin, stride, pad, C = 2, 5, 1700, 64
+    stride, pad, C = 5, 1700, 64
     l_out = (L + 2 * pad - 15) // stride + 1
     rows = n * l_out
     x = torch.randn(n, L, cin, generator=g).cuda()
